@@ -1,0 +1,196 @@
+// oracle_capi.cpp -- TEST INFRASTRUCTURE ONLY: extern "C" shim so tests/,
+// smoke() and bench.py's cpu_baseline leg can drive the oracle through ctypes.
+// The product library (toyslam_amd/csrc) never links or loads this.
+#include <cstring>
+#include <vector>
+
+#include "ndt_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+std::vector<Pt> to_pts(const float* p, size_t n, size_t stride_floats) {
+  std::vector<Pt> v(n);
+  for (size_t i = 0; i < n; i++) {
+    v[i].x = p[i * stride_floats + 0];
+    v[i].y = p[i * stride_floats + 1];
+    v[i].z = p[i * stride_floats + 2];
+    v[i].w = 1.0f;
+  }
+  return v;
+}
+void colmajor_to_T(const float* m, float T[4][4]) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) T[r][c] = m[c * 4 + r];
+}
+void T_to_colmajor(const float T[4][4], float* m) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) m[c * 4 + r] = T[r][c];
+}
+}  // namespace
+
+extern "C" {
+
+void* oracle_create() { return new NDT(); }
+void oracle_destroy(void* h) { delete static_cast<NDT*>(h); }
+
+void oracle_set_params(void* h, float resolution, double step_size, double outlier_ratio, double trans_eps,
+                       int max_iter, int search_method, int num_threads) {
+  NDT* n = static_cast<NDT*>(h);
+  n->set_resolution(resolution);
+  n->step_size = step_size;
+  n->outlier_ratio = outlier_ratio;
+  n->transformation_epsilon = trans_eps;
+  n->max_iterations = max_iter;
+  n->search_method = static_cast<SearchMethod>(search_method);
+  n->num_threads = num_threads;
+}
+
+void oracle_set_grid_params(void* h, int min_points_per_voxel, double eig_ratio) {
+  NDT* n = static_cast<NDT*>(h);
+  n->grid.min_points_per_voxel = min_points_per_voxel;
+  n->grid.min_covar_eigvalue_mult = eig_ratio;
+}
+
+int oracle_set_target(void* h, const float* pts, size_t n, size_t stride_floats, int is_dense) {
+  NDT* nd = static_cast<NDT*>(h);
+  nd->set_target(to_pts(pts, n, stride_floats), is_dense != 0);
+  return nd->grid.overflow ? 1 : 0;
+}
+
+int oracle_set_source(void* h, const float* pts, size_t n, size_t stride_floats) {
+  static_cast<NDT*>(h)->set_source(to_pts(pts, n, stride_floats));
+  return 0;
+}
+
+// guess / final_T are 4x4 column-major (Eigen::Matrix4f storage).
+int oracle_align(void* h, const float* guess, float* final_T, int* converged, int* n_iter, double* trans_prob,
+                 float* out_cloud /* N*4 or NULL */, int* n_evals, int* n_hess) {
+  NDT* nd = static_cast<NDT*>(h);
+  float G[4][4];
+  colmajor_to_T(guess, G);
+  std::vector<Pt> out;
+  AlignResult r = nd->align(G, out_cloud ? &out : nullptr);
+  T_to_colmajor(r.final_T, final_T);
+  if (converged) *converged = r.converged ? 1 : 0;
+  if (n_iter) *n_iter = r.nr_iterations;
+  if (trans_prob) *trans_prob = r.trans_probability;
+  if (n_evals) *n_evals = r.n_evals;
+  if (n_hess) *n_hess = r.n_hessian_recomputes;
+  if (out_cloud) std::memcpy(out_cloud, out.data(), out.size() * sizeof(Pt));
+  return 0;
+}
+
+// One computeDerivatives evaluation at pose p: the source is transformed by
+// T(p) exactly as computeStepLengthMT does (ndt_omp_impl.hpp:827-837).
+// If trans_cloud != NULL it is used as the already-transformed cloud instead.
+int oracle_eval(void* h, const double* p, const float* trans_cloud, int compute_hessian, double* score, double* g,
+                double* H, double* mean_neighbors) {
+  NDT* nd = static_cast<NDT*>(h);
+  nd->compute_gauss();
+  std::vector<Pt> tc;
+  if (trans_cloud) {
+    tc = to_pts(trans_cloud, nd->source.size(), 4);
+  } else {
+    float T[4][4];
+    pose_to_matrix(p, T);
+    transform_cloud(nd->source, tc, T);
+  }
+  *score = nd->compute_derivatives(g, H, tc, p, compute_hessian != 0);
+  if (mean_neighbors) *mean_neighbors = nd->mean_neighbors;
+  return 0;
+}
+
+// Serial all-f64 Hessian (computeHessian) at pose p.
+int oracle_hessian_f64(void* h, const double* p, double* H) {
+  NDT* nd = static_cast<NDT*>(h);
+  nd->compute_gauss();
+  float T[4][4];
+  pose_to_matrix(p, T);
+  std::vector<Pt> tc;
+  transform_cloud(nd->source, tc, T);
+  nd->compute_angle_derivatives(p);
+  nd->compute_hessian(H, tc);
+  return 0;
+}
+
+double oracle_calculate_score(void* h, const float* cloud, size_t n, size_t stride_floats) {
+  NDT* nd = static_cast<NDT*>(h);
+  nd->compute_gauss();
+  return nd->calculate_score(to_pts(cloud, n, stride_floats));
+}
+
+size_t oracle_grid_size(void* h) { return static_cast<NDT*>(h)->grid.leaves.size(); }
+
+void oracle_grid_info(void* h, int* min_b, int* max_b, int* div_b) {
+  NDT* nd = static_cast<NDT*>(h);
+  for (int k = 0; k < 3; k++) {
+    min_b[k] = nd->grid.min_b[k];
+    max_b[k] = nd->grid.max_b[k];
+    div_b[k] = nd->grid.div_b[k];
+  }
+}
+
+// Leaves in ascending linear-index order.  cov/icov are row-major 3x3.
+void oracle_grid_dump(void* h, long long* idx, int* nr_points, double* mean, double* cov, double* icov, double* evals) {
+  NDT* nd = static_cast<NDT*>(h);
+  size_t i = 0;
+  for (const auto& kv : nd->grid.leaves) {
+    idx[i] = static_cast<long long>(kv.first);
+    nr_points[i] = kv.second.nr_points;
+    for (int k = 0; k < 3; k++) {
+      mean[i * 3 + k] = kv.second.mean[k];
+      evals[i * 3 + k] = kv.second.evals[k];
+    }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        cov[i * 9 + r * 3 + c] = kv.second.cov.m[r][c];
+        icov[i * 9 + r * 3 + c] = kv.second.icov.m[r][c];
+      }
+    i++;
+  }
+}
+
+void oracle_gauss(void* h, double* d) {
+  NDT* nd = static_cast<NDT*>(h);
+  nd->compute_gauss();
+  d[0] = nd->gauss_d1;
+  d[1] = nd->gauss_d2;
+  d[2] = nd->gauss_d3;
+}
+
+// ---- small restated-Eigen pieces, exported for unit tests -----------------
+void oracle_svd6_solve(const double* H, const double* b, double* x) { svd6_solve(H, b, x); }
+void oracle_eig3(const double* a /*row-major*/, double* evals, double* evecs) {
+  M3 A, V;
+  V3 e;
+  std::memcpy(A.m, a, sizeof(A.m));
+  eig3_sym(A, e, V);
+  std::memcpy(evals, e.v, sizeof(e.v));
+  std::memcpy(evecs, V.m, sizeof(V.m));
+}
+void oracle_inv3(const double* a, double* out) {
+  M3 A;
+  std::memcpy(A.m, a, sizeof(A.m));
+  M3 r = inv3(A);
+  std::memcpy(out, r.m, sizeof(r.m));
+}
+void oracle_pose_to_matrix(const double* p, float* T_colmajor) {
+  float T[4][4];
+  pose_to_matrix(p, T);
+  T_to_colmajor(T, T_colmajor);
+}
+void oracle_euler_from_matrix(const float* T_colmajor, float* ang) {
+  float T[4][4];
+  colmajor_to_T(T_colmajor, T);
+  euler_xyz_from_matrix(T, ang);
+}
+void oracle_transform_cloud(const float* in, size_t n, const float* T_colmajor, float* out) {
+  float T[4][4];
+  colmajor_to_T(T_colmajor, T);
+  std::vector<Pt> a = to_pts(in, n, 4), b;
+  transform_cloud(a, b, T);
+  std::memcpy(out, b.data(), n * sizeof(Pt));
+}
+
+}  // extern "C"
