@@ -1,0 +1,175 @@
+/* ndt_mi355.h -- C-ABI of the MI355X-native NDT scan-matching core.
+ *
+ * This is the drop-in boundary for ToySLAM's
+ *   pclomp::NormalDistributionsTransform<PointSource, PointTarget>
+ * (reference: ndt_omp/include/pclomp/ndt_omp.h:70-502, implementation
+ * ndt_omp_impl.hpp, voxel grid voxel_grid_covariance_omp{.h,_impl.hpp}).
+ * The header-only adapter include/pclomp/ndt_omp.h re-declares that class on
+ * top of these entry points; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain C types only; every function returns an ndt_status (0 = ok) unless
+ *    noted; ndt_last_error() gives a thread-local message for the last failure.
+ *  - point buffers: `n` records of `stride_bytes` bytes, three f32 x,y,z at
+ *    offset 0 of each record (pcl::PointXYZ: stride 16; PointXYZI/XYZRGB: 32).
+ *  - 4x4 transforms are 16 f32 in COLUMN-major order (Eigen::Matrix4f::data()).
+ *  - 6x6 Hessians are 36 f64 row-major; pose vectors are
+ *    [tx, ty, tz, roll, pitch, yaw] f64 (ndt_omp_impl.hpp:107-111).
+ *  - a handle is thread-compatible (one caller at a time), like the reference
+ *    object; distinct handles may be used from distinct threads.
+ *  - there is NO CPU fallback: every compute entry point fails with
+ *    NDT_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef NDT_MI355_H_
+#define NDT_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ndt_context* ndt_handle;
+
+typedef enum {
+  NDT_OK = 0,
+  NDT_ERR_INVALID = 1,       /* bad argument / call order                          */
+  NDT_ERR_NO_DEVICE = 2,     /* no usable HIP device (never falls back to the CPU) */
+  NDT_ERR_HIP = 3,           /* HIP runtime error, see ndt_last_error()            */
+  NDT_ERR_GRID_OVERFLOW = 4, /* dx*dy*dz > INT32_MAX: voxel_grid_covariance_omp_impl.hpp:75-84 */
+  NDT_ERR_NO_INPUT = 5,      /* target/source missing: _impl.hpp:54-60             */
+  NDT_ERR_COMM = 6           /* collective callback failed                         */
+} ndt_status;
+
+/* pclomp::NeighborSearchMethod, ndt_omp.h:52-57 (same numeric values). */
+typedef enum { NDT_KDTREE = 0, NDT_DIRECT26 = 1, NDT_DIRECT7 = 2, NDT_DIRECT1 = 3 } ndt_search_method;
+
+const char* ndt_last_error(void);
+/* Number of usable gfx950 devices (0 when none; never an error). */
+int ndt_device_count(void);
+
+/* ---- lifetime ----------------------------------------------------------- */
+/* NormalDistributionsTransform() ctor, ndt_omp_impl.hpp:47-76: resolution 1.0,
+ * step 0.1, outlier 0.55, epsilon 0.1, max_iterations 35, DIRECT7.
+ * `device` = HIP device ordinal.  Creating a handle does not touch the GPU
+ * until the first target/source upload. */
+ndt_status ndt_create(int device, ndt_handle* out);
+/* Copy-construction (ndt_omp_mapping_node.cpp:151-169 returns the object by
+ * value): parameters and results are copied, the immutable device grid and the
+ * source cloud are shared (ref-counted). */
+ndt_status ndt_clone(ndt_handle src, ndt_handle* out);
+void ndt_destroy(ndt_handle h);
+
+/* ---- parameters (setters mirror ndt_omp.h:115-191 + pcl::Registration) ---- */
+ndt_status ndt_set_resolution(ndt_handle h, float resolution);       /* ndt_omp.h:132-142, rebuilds the grid if a source is set */
+ndt_status ndt_set_step_size(ndt_handle h, double step_size);        /* :165-169 */
+ndt_status ndt_set_outlier_ratio(ndt_handle h, double ratio);        /* :183-187 */
+ndt_status ndt_set_transformation_epsilon(ndt_handle h, double eps); /* pcl::Registration */
+ndt_status ndt_set_maximum_iterations(ndt_handle h, int n);          /* pcl::Registration */
+ndt_status ndt_set_neighborhood_search_method(ndt_handle h, int m);  /* :189-191; KDTREE is not implemented -> NDT_ERR_INVALID at align */
+ndt_status ndt_set_num_threads(ndt_handle h, int n);                 /* :115-117; stored, unused on the GPU */
+ndt_status ndt_set_min_points_per_voxel(ndt_handle h, int n);        /* voxel_grid_covariance_omp.h:227-239 (clamped to >= 3) */
+ndt_status ndt_set_cov_eig_value_inflation_ratio(ndt_handle h, double r); /* .h:253-257 */
+float ndt_get_resolution(ndt_handle h);
+double ndt_get_step_size(ndt_handle h);
+double ndt_get_outlier_ratio(ndt_handle h);
+
+/* ---- inputs --------------------------------------------------------------
+ * setInputTarget (ndt_omp.h:122-127): uploads the cloud and builds the voxel
+ * grid on the GPU (VoxelGridCovariance::applyFilter, _impl.hpp:48-370).
+ * `is_dense` = pcl::PointCloud::is_dense (non-finite points are skipped when 0). */
+ndt_status ndt_set_input_target(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, int is_dense);
+ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t stride_bytes);
+/* Same, for clouds already resident in HBM (device pointers on the handle's device). */
+ndt_status ndt_set_input_target_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense);
+ndt_status ndt_set_input_source_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+
+/* ---- registration --------------------------------------------------------
+ * pcl::Registration::align(output, guess) -> computeTransformation
+ * (ndt_omp_impl.hpp:80-171) with the More-Thuente line search (:772-932).
+ * guess == NULL means Identity.  out_cloud (optional) receives the source
+ * transformed by the last line-search trial, n_source records of
+ * out_stride_bytes (x,y,z,1.0f written at offset 0). */
+ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformation, int* has_converged,
+                     int* final_num_iteration, double* transformation_probability, void* out_cloud,
+                     size_t out_stride_bytes);
+/* Results of the last align (hasConverged / getFinalTransformation /
+ * getFinalNumIteration / getTransformationProbability). */
+ndt_status ndt_get_result(ndt_handle h, float* final_transformation, int* has_converged, int* final_num_iteration,
+                          double* transformation_probability);
+/* Device pointer (n_source x float4) of the last align's transformed source. */
+ndt_status ndt_get_output_device(ndt_handle h, const void** d_cloud, size_t* n);
+/* Work counters of the last align: derivative evaluations E, f64 Hessian
+ * recomputes, mean valid neighbours per point (h-bar) of the last evaluation. */
+ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hessian_recomputes, double* mean_neighbors);
+
+/* calculateScore(cloud), ndt_omp_impl.hpp:935-983 (cloud is used as given). */
+ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride_bytes, double* score);
+
+/* ---- batch (map-build mode: many sources against the one target) ----------
+ * Registers n_scans sources in lock-step, one fused derivative launch per
+ * line-search step for the whole batch.  Scan k is points
+ * [offsets[k], offsets[k+1]) of `pts`.  guesses == NULL -> Identity.
+ * Per-scan outputs are arrays of n_scans entries (any may be NULL). */
+ndt_status ndt_align_batch(ndt_handle h, const void* pts, const size_t* offsets /* n_scans+1 */, size_t n_scans,
+                           size_t stride_bytes, const float* guesses /* n_scans*16 or NULL */,
+                           float* final_transformations /* n_scans*16 */, int* has_converged,
+                           int* final_num_iteration, double* transformation_probability);
+ndt_status ndt_align_batch_device(ndt_handle h, const void* d_pts, const size_t* offsets, size_t n_scans,
+                                  size_t stride_bytes, const float* guesses, float* final_transformations,
+                                  int* has_converged, int* final_num_iteration, double* transformation_probability);
+
+/* Optional exchange step for multi-GPU lock-step batches / point-sharded scans:
+ * after every fused evaluation the packed [n_rows][NDT_EVAL_STRIDE] f64 result
+ * buffer is handed to `fn` for an in-place SUM all-reduce across ranks
+ * (RCCL on the device buffer when `on_device` != 0, host buffer otherwise).
+ * fn returns 0 on success. */
+#define NDT_EVAL_STRIDE 32 /* score, g[6], H upper-tri[21], n_neighbors, 3 spare */
+typedef int (*ndt_allreduce_fn)(void* buf, size_t n_doubles, int on_device, void* user);
+ndt_status ndt_set_allreduce(ndt_handle h, ndt_allreduce_fn fn, void* user, int on_device);
+
+/* ---- inspection / test entry points --------------------------------------
+ * One computeDerivatives evaluation (ndt_omp_impl.hpp:179-285) at pose p; the
+ * source is transformed by T(p) as computeStepLengthMT does (:827-837).
+ * H may be NULL (compute_hessian = false). */
+ndt_status ndt_eval(ndt_handle h, const double* p, double* score, double* gradient, double* hessian,
+                    double* mean_neighbors);
+/* Same with an explicit 4x4 (column-major) applied to the source while the
+ * angle derivatives come from p -- the initial evaluation of align with a
+ * non-identity guess (:95-119). */
+ndt_status ndt_eval_with_matrix(ndt_handle h, const float* T, const double* p, double* score, double* gradient,
+                                double* hessian, double* mean_neighbors);
+/* computeHessian (:540-645): the all-f64 Hessian at pose p. */
+ndt_status ndt_eval_hessian_f64(ndt_handle h, const double* p, double* hessian);
+
+/* Target grid (VoxelGridCovariance::leaves_): number of occupied voxels and a
+ * dump in ascending linear-index order.  cov/icov are row-major 3x3 f64;
+ * nr_points is -1 for rejected voxels as in _impl.hpp:337-341,360-364. */
+ndt_status ndt_grid_size(ndt_handle h, size_t* n_leaves, size_t* n_valid);
+ndt_status ndt_grid_info(ndt_handle h, int* min_b /*3*/, int* max_b /*3*/, int* div_b /*3*/);
+ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mean, double* cov, double* icov,
+                         double* evals);
+
+/* Host-side scalar pieces of the driver (no GPU needed), exported so that the
+ * CPU test-suite can check them against the oracle. */
+void ndt_host_solve6(const double* H /*36 row-major*/, const double* b /*6*/, double* x /*6*/); /* JacobiSVD.solve, :127-129 */
+void ndt_host_pose_to_matrix(const double* p /*6*/, float* T /*16 col-major*/);                  /* :146-149, 827-830 */
+void ndt_host_matrix_to_pose(const float* T /*16 col-major*/, double* p /*6*/);                  /* :103-111 */
+void ndt_host_angle_derivatives(const double* p /*6*/, float* j_ang /*8*3*/, float* h_ang /*15*3*/,
+                                double* j_ang_d /*8*3*/, double* h_ang_d /*15*3*/);              /* :288-395 */
+void ndt_host_gauss(float resolution, double outlier_ratio, double* d /*3: d1,d2,d3*/);          /* :86-93 */
+/* Runs the Newton + More-Thuente driver against a caller-supplied evaluator
+ * (test hook: lets the CPU suite drive the PRODUCT driver with oracle
+ * evaluations).  kind: 0 = derivatives with Hessian, 1 = without, 2 = f64
+ * Hessian only.  T is the 4x4 (col-major) to apply to the source. */
+typedef int (*ndt_eval_cb)(void* user, int kind, const float* T, const double* p, double* score, double* g, double* H);
+ndt_status ndt_host_run_driver(ndt_eval_cb cb, void* user, size_t n_source, const float* guess, float resolution,
+                               double step_size, double outlier_ratio, double trans_eps, int max_iter,
+                               float* final_transformation, int* has_converged, int* final_num_iteration,
+                               double* transformation_probability, int* n_evals, int* n_hessian_recomputes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDT_MI355_H_ */

@@ -1,0 +1,49 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pair():
+    """Reference scan pair (ndt_omp/data/*.pcd) after the 0.1 m downsample of apps/align.cpp:60-69."""
+    d = np.load(os.path.join(GOLDEN, "pair_0p1.npz"))
+    return d["target"], d["source"]
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN, "oracle_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_grid():
+    return dict(np.load(os.path.join(GOLDEN, "grid_1p0.npz")))
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The in-tree HIP library (cross-compiles without a GPU)."""
+    from toyslam_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def rot_err(Ta, Tb):
+    return float(np.abs(np.asarray(Ta)[:3, :3] - np.asarray(Tb)[:3, :3]).max())
+
+
+def trans_err(Ta, Tb):
+    return float(np.abs(np.asarray(Ta)[:3, 3] - np.asarray(Tb)[:3, 3]).max())

@@ -1,0 +1,372 @@
+"""GPU: the HIP path (through the C-ABI) against the CPU oracle on the same inputs, against the
+committed golden vectors, and -- at BASELINE.json's full size -- through size-independent properties.
+
+Tolerances (north_star): final transform within 1e-4 on rotation entries and 1e-3 m on translation.
+Per-evaluation sums are compared far tighter: the f32 per-neighbour math is the same formulae with
+FMA contraction on the GPU (<= 1e-6 relative on the f64 sums); integer/index work is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def mods(built_lib):
+    assert built_lib.ndt_device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    from oracle import pyoracle as po
+    from toyslam_amd import clouds, ndt
+    return ndt, po, clouds
+
+
+def make_pair(mods, t, s, **kw):
+    ndt, po, _ = mods
+    g = ndt.NormalDistributionsTransform()
+    o = po.OracleNDT(num_threads=8)
+    setters = dict(resolution=g.setResolution, step_size=g.setStepSize, trans_eps=g.setTransformationEpsilon,
+                   max_iter=g.setMaximumIterations, search_method=g.setNeighborhoodSearchMethod,
+                   outlier_ratio=g.setOutlierRatio)
+    for k, v in kw.items():
+        setters[k](v)
+    o.set(**kw)
+    g.setInputTarget(t)
+    o.set_target(t)
+    g.setInputSource(s)
+    o.set_source(s)
+    return g, o
+
+
+def close_sums(a, b, rel=2e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-30)
+
+
+def test_native_library_is_in_tree(built_lib):
+    import os
+    from toyslam_amd import _lib
+    assert os.path.dirname(_lib.LIB_PATH).endswith("toyslam_amd") and os.path.exists(_lib.LIB_PATH)
+
+
+# ------------------------------------------------------------------ K1: voxel grid
+def test_grid_bit_exact_indices_and_sums(mods, pair, golden_grid):
+    t, s = pair
+    g, o = make_pair(mods, t, s)
+    gg, og = g.grid(), o.grid()
+    assert np.array_equal(gg["idx"], og["idx"]) and np.array_equal(gg["n"], og["n"])      # integer work: exact
+    assert np.array_equal(gg["min_b"], og["min_b"]) and np.array_equal(gg["div_b"], og["div_b"])
+    assert gg["n_valid"] == int((og["n"] >= 6).sum())
+    # index-ordered f64 sums: the mean is bit-identical to the reference's sequential accumulation
+    assert np.array_equal(gg["mean"], og["mean"])
+    scale = np.abs(og["icov"]).max(axis=(1, 2), keepdims=True) + 1e-300
+    assert np.abs(gg["cov"] - og["cov"]).max() < 1e-12
+    assert (np.abs(gg["icov"] - og["icov"]) / scale).max() < 1e-10
+    assert np.allclose(gg["evals"], og["evals"], rtol=1e-10, atol=1e-14)
+    # and against the committed golden grid
+    assert np.array_equal(gg["idx"], golden_grid["idx"]) and np.array_equal(gg["mean"], golden_grid["mean"])
+
+
+@pytest.mark.parametrize("res", [0.5, 2.0])
+def test_grid_other_resolutions(mods, pair, res):
+    t, s = pair
+    g, o = make_pair(mods, t, s, resolution=res)
+    gg, og = g.grid(), o.grid()
+    assert np.array_equal(gg["idx"], og["idx"]) and np.array_equal(gg["n"], og["n"])
+    assert np.array_equal(gg["mean"], og["mean"])
+    scale = np.abs(og["icov"]).max(axis=(1, 2), keepdims=True) + 1e-300
+    assert (np.abs(gg["icov"] - og["icov"]) / scale).max() < 1e-9
+
+
+def test_grid_large_leaves_and_nonfinite(mods):
+    """Leaves above the in-thread sort limit, rejected (degenerate) voxels and NaN skipping."""
+    ndt, po, _ = mods
+    rng = np.random.default_rng(11)
+    dense = (rng.random((5000, 3)) * [0.9, 0.9, 0.9] + [3.05, 3.05, 0.05]).astype(np.float32)   # one voxel, 5000 pts
+    plane = np.c_[rng.random((400, 2)) * 4, np.full(400, 0.5)].astype(np.float32)               # exactly planar
+    line = np.c_[np.linspace(6.1, 6.9, 50), np.full(50, 1.5), np.full(50, 0.5)].astype(np.float32)
+    same = np.tile(np.array([[8.5, 8.5, 0.5]], np.float32), (20, 1))                            # zero covariance
+    pts = np.concatenate([dense, plane, line, same, rng.random((3000, 3)).astype(np.float32) * [10, 10, 1]])
+    pts[::97] = np.nan
+    g = ndt.NormalDistributionsTransform()
+    o = po.OracleNDT()
+    g.setInputTarget(pts, is_dense=False)
+    o.set_target(pts, is_dense=False)
+    gg, og = g.grid(), o.grid()
+    assert np.array_equal(gg["idx"], og["idx"]) and np.array_equal(gg["n"], og["n"])
+    small = og["n"] <= 64
+    assert np.array_equal(gg["mean"][small], og["mean"][small])
+    assert np.allclose(gg["mean"], og["mean"], rtol=1e-14, atol=1e-14)
+    ok = og["n"] >= 6
+    scale = np.abs(og["icov"]).max(axis=(1, 2), keepdims=True) + 1e-300
+    assert (np.abs(gg["icov"] - og["icov"])[ok] / scale[ok]).max() < 1e-8
+
+
+# ------------------------------------------------------------------ K2: derivatives
+@pytest.mark.parametrize("key", ["DIRECT7/zero", "DIRECT7/small", "DIRECT7/large", "DIRECT1/zero", "DIRECT1/small",
+                                 "DIRECT26/small", "DIRECT26/large"])
+def test_eval_matches_oracle_and_golden(mods, pair, golden, key):
+    ndt, po, _ = mods
+    t, s = pair
+    method = {"DIRECT7": po.DIRECT7, "DIRECT1": po.DIRECT1, "DIRECT26": po.DIRECT26}[key.split("/")[0]]
+    g, o = make_pair(mods, t, s, search_method=method)
+    e = golden["evals"][key]
+    score, grad, H, nn = g.eval(e["p"], True)
+    so, go, Ho, nno = o.eval(e["p"], True)
+    assert nn == nno == e["mean_neighbors"]                      # neighbour search: exact
+    assert score == pytest.approx(so, rel=1e-6) and score == pytest.approx(e["score"], rel=1e-6)
+    assert close_sums(grad, go) and close_sums(H, Ho) and close_sums(H, e["H"])
+    assert np.array_equal(H, H.T)
+    # compute_hessian = false leaves the Hessian untouched, same score/gradient
+    s2, g2, H2, _ = g.eval(e["p"], False)
+    assert s2 == score and np.array_equal(g2, grad) and H2 is None
+    # all-f64 Hessian (computeHessian); the device keeps icov in f32 -> 1e-6
+    assert close_sums(g.hessian_f64(e["p"]), o.hessian_f64(e["p"]), rel=1e-5)
+
+
+def test_eval_is_deterministic(mods, pair):
+    t, s = pair
+    g, _ = make_pair(mods, t, s)
+    p = [0.4, 0.1, -0.02, 0.004, -0.001, -0.01]
+    a = g.eval(p, True)
+    for _ in range(3):
+        b = g.eval(p, True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_eval_with_guess_matrix(mods, pair):
+    """Initial evaluation of align(guess): cloud moved by the guess matrix, angles from eulerAngles."""
+    ndt, po, clouds = mods
+    t, s = pair
+    g, o = make_pair(mods, t, s)
+    G = clouds.make_T([0.3, 0.1, -0.05], np.deg2rad([-0.4, 0.3, 0.8])).astype(np.float32)
+    p = ndt.host_matrix_to_pose(G)
+    tc = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)], G)
+    so, go, Ho, _ = o.eval(p, True, tc)
+    sg, gg, Hg, _ = g.eval(p, True, T=G)
+    assert sg == pytest.approx(so, rel=1e-6) and close_sums(gg, go) and close_sums(Hg, Ho)
+
+
+def test_calculate_score(mods, pair, golden):
+    ndt, po, _ = mods
+    t, s = pair
+    g, o = make_pair(mods, t, s)
+    moved = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)], po.pose_to_matrix([0.4, 0.1, -0.02, 0.004, -0.001, -0.01]))
+    a = g.calculateScore(moved)
+    assert a == pytest.approx(o.calculate_score(moved[:, :3]), rel=1e-6)
+    assert a == pytest.approx(golden["calculate_score_small_DIRECT7"], rel=1e-6)
+
+
+def test_eval_linearity_in_points(mods, pair):
+    """Size-independent property: the sums over a cloud equal the sum over its two halves."""
+    t, s = pair
+    g, _ = make_pair(mods, t, s)
+    p = [0.4, 0.1, -0.02, 0.004, -0.001, -0.01]
+    full = g.eval(p, True)
+    h = len(s) // 2
+    g.setInputSource(s[:h])
+    a = g.eval(p, True)
+    g.setInputSource(s[h:])
+    b = g.eval(p, True)
+    assert full[0] == pytest.approx(a[0] + b[0], rel=1e-12)
+    assert np.allclose(full[1], a[1] + b[1], rtol=1e-10, atol=1e-9) and np.allclose(full[2], a[2] + b[2], rtol=1e-10, atol=1e-8)
+
+
+# ------------------------------------------------------------------ full registration
+ALIGN_CASES = ["DIRECT7/default", "DIRECT1/default", "DIRECT7/node_params", "DIRECT7/guess", "DIRECT7/guess_neg_roll",
+               "DIRECT7/tight", "DIRECT26/default"]
+
+
+@pytest.mark.parametrize("name", ALIGN_CASES)
+def test_align_matches_oracle_and_golden(mods, pair, golden, name):
+    ndt, po, _ = mods
+    t, s = pair
+    a = golden["aligns"][name]
+    g, o = make_pair(mods, t, s, search_method=a["method"], trans_eps=a["trans_eps"], max_iter=a["max_iter"],
+                     step_size=a["step_size"])
+    G = None if a["guess"] is None else np.array(a["guess"], dtype=np.float32)
+    ro = o.align(G)
+    out = g.align(G, n_out=len(s))
+    T = g.getFinalTransformation()
+    assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL
+    assert rot_err(T, a["T"]) < ROT_TOL and trans_err(T, a["T"]) < TRANS_TOL
+    assert g.hasConverged() == ro["converged"] == a["converged"]
+    assert g.getFinalNumIteration() == ro["iterations"]
+    st = g.stats()
+    assert st["n_evals"] == ro["n_evals"] and st["n_hessian_recomputes"] == ro["n_hessian_recomputes"]
+    assert g.getTransformationProbability() == pytest.approx(ro["trans_probability"], rel=1e-5)
+    # align(output): the source moved by the final transformation, w = 1
+    expect = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)], T)
+    assert np.array_equal(out, expect)
+
+
+def test_readme_fitness_on_gpu(mods, pair, golden):
+    """The reference's only known answer, now through the HIP path."""
+    from scipy.spatial import cKDTree
+    ndt, po, _ = mods
+    t, s = pair
+    for name, method in (("DIRECT7", po.DIRECT7), ("DIRECT1", po.DIRECT1)):
+        g = ndt.NormalDistributionsTransform()
+        g.setResolution(1.0)
+        g.setNeighborhoodSearchMethod(method)
+        g.setInputTarget(t)
+        g.setInputSource(s)
+        out = g.align(n_out=len(s))
+        d, _ = cKDTree(t.astype(np.float64)).query(out[:, :3].astype(np.float64))
+        fit = float(np.mean((d.astype(np.float32) ** 2).astype(np.float64)))
+        assert fit == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "surfaces"])
+def test_synthetic_align_vs_oracle(mods, kind):
+    ndt, po, clouds = mods
+    tgt = clouds.target_uniform(200000, half=(20.0, 20.0, 5.0)) if kind == "uniform" else \
+        clouds.target_surfaces(200000, extent=60.0, n_boxes=25)
+    src = clouds.source_from_target(tgt, 20000)
+    g, o = make_pair(mods, tgt, src, trans_eps=1e-5, max_iter=30)
+    ro = o.align()
+    g.align()
+    T = g.getFinalTransformation()
+    assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL
+    assert g.getFinalNumIteration() == ro["iterations"]
+    if kind == "surfaces":
+        assert rot_err(T, clouds.T_GT_DEFAULT) < 2e-3 and trans_err(T, clouds.T_GT_DEFAULT) < 2e-2
+
+
+def test_point_stride_32_and_clone(mods, pair):
+    """PointXYZI/XYZRGB are 32-byte records; copies share the device grid (value semantics of the nodes)."""
+    ndt, _, _ = mods
+    t, s = pair
+    t8 = np.zeros((len(t), 8), np.float32)
+    t8[:, :3] = t
+    t8[:, 4] = 77.0
+    s8 = np.zeros((len(s), 8), np.float32)
+    s8[:, :3] = s
+    a = ndt.NormalDistributionsTransform()
+    a.setInputTarget(t8)
+    a.setInputSource(s8)
+    a.align()
+    b = ndt.NormalDistributionsTransform()
+    b.setInputTarget(t)
+    b.setInputSource(s)
+    b.align()
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    c = a.copy()
+    assert c.hasConverged() and np.array_equal(c.getFinalTransformation(), a.getFinalTransformation())
+    c.setTransformationEpsilon(0.01)
+    c.setMaximumIterations(64)
+    c.align()
+    assert c.getFinalNumIteration() >= a.getFinalNumIteration()
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())   # the copy did not disturb a
+
+
+def test_edge_cases(mods, pair):
+    ndt, po, _ = mods
+    t, s = pair
+    from toyslam_amd import NdtError
+    g = ndt.NormalDistributionsTransform()
+    with pytest.raises(NdtError):
+        g.align()                                              # no inputs
+    g.setInputTarget(np.zeros((0, 3), np.float32))             # empty target -> empty grid
+    g.setInputSource(s[:100])
+    g.align()
+    assert g.hasConverged() and g.getFinalNumIteration() == 0
+    assert np.array_equal(g.getFinalTransformation(), np.eye(4, dtype=np.float32))
+    g.setInputTarget(t)
+    g.setInputSource(np.zeros((0, 3), np.float32))             # empty source
+    g.align()
+    assert g.getFinalNumIteration() == 0
+    g.setInputSource(s[:5] + 1000.0)                           # far outside the grid: no neighbours at all
+    assert g.eval(np.zeros(6))[0] == 0.0
+    g.setInputTarget(t[:5])                                    # every voxel below min_points_per_voxel
+    g.setInputSource(s[:100])
+    assert g.eval(np.zeros(6))[0] == 0.0
+    bad = s[:200].copy()
+    bad[3] = np.nan                                            # a NaN source point contributes nothing
+    g.setInputTarget(t)
+    g.setInputSource(bad)
+    o = po.OracleNDT()
+    o.set_target(t)
+    o.set_source(np.delete(bad, 3, axis=0))
+    assert g.eval(np.zeros(6))[0] == pytest.approx(o.eval(np.zeros(6))[0], rel=1e-6)
+    g.setNeighborhoodSearchMethod(ndt.KDTREE)
+    with pytest.raises(NdtError):
+        g.align()                                              # not implemented: fails loudly, no silent substitute
+    g.setNeighborhoodSearchMethod(7)                           # unknown value: the reference's `default:` = DIRECT7
+    g.setInputSource(s)
+    o.set_source(s)
+    assert g.eval(np.zeros(6))[0] == pytest.approx(o.eval(np.zeros(6))[0], rel=1e-6)
+
+
+def test_set_resolution_rebuild_rule(mods, pair):
+    """ndt_omp.h:132-142: setResolution rebuilds the grid only when a source is already set."""
+    ndt, po, _ = mods
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    g.setResolution(2.0)                 # no source yet: grid stays at 1.0 m
+    assert len(g.grid()["idx"]) == 1098
+    g.setInputSource(s)
+    g.setResolution(0.5)                 # now it rebuilds
+    o = po.OracleNDT(resolution=0.5)
+    o.set_target(t)
+    assert len(g.grid()["idx"]) == len(o.grid()["idx"])
+
+
+# ------------------------------------------------------------------ batch (map-build)
+def test_batch_equals_individual(mods, pair):
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(4)
+    scans, guesses = [], []
+    for k in range(5):
+        T = clouds.random_T(rng, 0.2, 0.5)
+        scans.append(clouds.apply_T(np.linalg.inv(T), s[k::5].copy()))
+        guesses.append(np.eye(4, dtype=np.float32) if k % 2 == 0 else clouds.make_T([0.05, 0, 0], [0, 0, 0.002]).astype(np.float32))
+    g = ndt.NormalDistributionsTransform()
+    g.setTransformationEpsilon(0.01)
+    g.setMaximumIterations(40)
+    g.setInputTarget(t)
+    res = g.alignBatch(scans, guesses)
+    for k in range(5):
+        g.setInputSource(scans[k])
+        g.align(guesses[k])
+        assert np.array_equal(res["T"][k], g.getFinalTransformation())       # same kernels, same order: identical
+        assert res["iterations"][k] == g.getFinalNumIteration() and res["converged"][k] == g.hasConverged()
+        o = po.OracleNDT(trans_eps=0.01, max_iter=40, num_threads=8)
+        o.set_target(t)
+        o.set_source(scans[k])
+        ro = o.align(guesses[k])
+        assert rot_err(res["T"][k], ro["T"]) < ROT_TOL and trans_err(res["T"][k], ro["T"]) < TRANS_TOL
+
+
+# ------------------------------------------------------------------ BASELINE size
+def test_full_size_properties(mods):
+    """config[1]: 100 k-pt source vs 1 M-pt target, 1.0 m voxels, 30 Newton passes (max_iter 28, eps 0).
+    The oracle needs minutes at this size, so: recovery of the known T_gt, run-to-run bit-identity,
+    linearity of the sums in the points, and h-bar in the expected range."""
+    ndt, po, clouds = mods
+    tgt = clouds.target_surfaces(1000000)
+    src = clouds.source_from_target(tgt, 100000)
+    g = ndt.NormalDistributionsTransform()
+    g.setMaximumIterations(28)
+    g.setTransformationEpsilon(0.0)
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align()
+    T1 = g.getFinalTransformation()
+    assert g.getFinalNumIteration() == 30 and g.stats()["n_evals"] >= 31
+    assert rot_err(T1, clouds.T_GT_DEFAULT) < 5e-4 and trans_err(T1, clouds.T_GT_DEFAULT) < 5e-3
+    g.align()
+    assert np.array_equal(T1, g.getFinalTransformation())
+    p = ndt.host_matrix_to_pose(T1)
+    full = g.eval(p, True)
+    assert 1.0 < full[3] <= 7.0
+    g.setInputSource(src[:40000])
+    a = g.eval(p, True)
+    g.setInputSource(src[40000:])
+    b = g.eval(p, True)
+    assert full[0] == pytest.approx(a[0] + b[0], rel=1e-12)
+    assert np.allclose(full[2], a[2] + b[2], rtol=1e-10, atol=1e-6)

@@ -1,0 +1,823 @@
+// ndt_capi.hip -- C-ABI (include/ndt_mi355.h) over the HIP kernels and the host
+// driver.  There is deliberately no CPU fallback: without a usable gfx950
+// device every compute entry point returns NDT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ndt_driver.hpp"
+#include "ndt_kernels.hpp"
+#include "ndt_mi355.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+ndt_status fail(ndt_status s, const std::string& msg) {
+  g_last_error = msg;
+  return s;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(NDT_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(_e));          \
+  } while (0)
+
+// grow-only device buffer
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+};
+
+struct DeviceCloud {
+  DevBuf<float4> pts;
+  size_t n = 0;
+};
+
+// Immutable once built (shared between cloned handles).
+struct DeviceGrid {
+  ndt::GridGeom geom{};
+  float resolution = 0;
+  int min_pts = 6;
+  double eig_ratio = 0.01;
+  bool empty = true;
+  size_t n_leaves = 0, n_cand = 0, n_valid = 0;
+  std::shared_ptr<DeviceCloud> target;  // kept for the dump pass
+  DevBuf<int> lut;
+  DevBuf<ndt::VoxelRec> recs;
+  DevBuf<int> leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  DevBuf<unsigned> leaf_start;
+  ndt::GridView view() const {
+    ndt::GridView v;
+    v.lut = lut.p;
+    v.recs = recs.p;
+    v.g = geom;
+    return v;
+  }
+};
+
+}  // namespace
+
+struct ndt_context {
+  int device = 0;
+  bool device_ready = false;
+  hipStream_t stream = nullptr;
+  // parameters (ctor defaults ndt_omp_impl.hpp:47-76, voxel_grid_covariance_omp.h:208-223)
+  float resolution = 1.0f;
+  double step_size = 0.1, outlier_ratio = 0.55, trans_eps = 0.1;
+  int max_iter = 35, search = NDT_DIRECT7, num_threads = 1, min_pts = 6;
+  double eig_ratio = 0.01;
+  // inputs
+  std::shared_ptr<DeviceCloud> target, source;
+  int target_dense = 1;
+  std::shared_ptr<DeviceGrid> grid;
+  // scratch
+  DevBuf<double> partials;
+  DevBuf<double> batch_out;
+  DevBuf<ndt::ScanDesc> descs;
+  DevBuf<float4> out_cloud;
+  DevBuf<unsigned char> staging;
+  double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
+  size_t host_result_rows = 0;
+  // results
+  float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  int converged = 0, nr_iterations = 0;
+  double trans_probability = 0;
+  int n_evals = 0, n_hess = 0;
+  double mean_neighbors = 0;
+  size_t out_n = 0;
+  // collective hook
+  ndt_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int allreduce_on_device = 0;
+
+  ~ndt_context() {
+    if (host_result) (void)hipHostFree(host_result);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+int usable_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+ndt_status ensure_device(ndt_context* h) {
+  if (h->device_ready) {
+    HIP_TRY(hipSetDevice(h->device));
+    return NDT_OK;
+  }
+  const int n = usable_devices();
+  if (n <= 0 || h->device >= n)
+    return fail(NDT_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+  HIP_TRY(hipSetDevice(h->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NDT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->device_ready = true;
+  return NDT_OK;
+}
+
+ndt_status ensure_host_rows(ndt_context* h, size_t rows) {
+  if (rows <= h->host_result_rows) return NDT_OK;
+  if (h->host_result) (void)hipHostFree(h->host_result);
+  h->host_result = nullptr;
+  h->host_result_rows = 0;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_result), rows * ndt::kEvalStride * sizeof(double),
+                        hipHostMallocDefault));
+  h->host_result_rows = rows;
+  return NDT_OK;
+}
+
+// upload + repack to dense float4
+ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
+                        std::shared_ptr<DeviceCloud>& out) {
+  if (n > 0 && !pts) return fail(NDT_ERR_INVALID, "null point buffer");
+  if (stride < 12 || stride % 4) return fail(NDT_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (n > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "too many points");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  auto c = std::make_shared<DeviceCloud>();
+  HIP_TRY(c->pts.reserve(n));
+  c->n = n;
+  if (n) {
+    const void* d_src = pts;
+    if (!on_device) {
+      HIP_TRY(h->staging.reserve(n * stride));
+      HIP_TRY(hipMemcpyAsync(h->staging.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+      d_src = h->staging.p;
+    }
+    HIP_TRY(ndt::launch_repack(d_src, n, stride, c->pts.p, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  out = c;
+  return NDT_OK;
+}
+
+// VoxelGridCovariance::filter(true) on the GPU.
+ndt_status build_grid(ndt_context* h) {
+  if (!h->target) return fail(NDT_ERR_NO_INPUT, "no target");
+  auto g = std::make_shared<DeviceGrid>();
+  g->target = h->target;
+  g->resolution = h->resolution;
+  g->min_pts = h->min_pts;
+  g->eig_ratio = h->eig_ratio;
+  const int n = static_cast<int>(h->target->n);
+  ndt::GridGeom& geo = g->geom;
+  for (int k = 0; k < 3; k++) {
+    geo.leaf[k] = h->resolution;
+    geo.inv_leaf[k] = 1.0f / h->resolution;  // [PCL] VoxelGrid::setLeafSize
+  }
+  if (n == 0) {
+    h->grid = g;
+    return NDT_OK;
+  }
+  hipStream_t st = h->stream;
+  // ---- bbox
+  const int nb = std::min(1024, (n + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(h->target->pts.p, n, h->target_dense, d_mm.p, nb, st));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
+      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
+    }
+  if (!(min_p[0] <= max_p[0])) {  // no finite point at all
+    h->grid = g;
+    return NDT_OK;
+  }
+  // ---- geometry, voxel_grid_covariance_omp_impl.hpp:75-103
+  long long d[3];
+  for (int k = 0; k < 3; k++) d[k] = static_cast<long long>((max_p[k] - min_p[k]) * geo.inv_leaf[k]) + 1;
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
+    h->grid = g;  // the reference warns and leaves an empty grid (:79-84)
+    return fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
+  }
+  for (int k = 0; k < 3; k++) {
+    geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+    geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+    geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  if (geo.n_cells <= 0 || geo.n_cells > static_cast<long long>(std::numeric_limits<int32_t>::max()))
+    return fail(NDT_ERR_GRID_OVERFLOW, "voxel grid too large");
+
+  // ---- count
+  DevBuf<unsigned> cell_count, block_sums, totals;
+  DevBuf<int> key;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(h->target->pts.p, n, h->target_dense, geo, key.p, cell_count.p, st));
+  // ---- scan
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  g->n_leaves = tot[1];
+  g->n_cand = tot[2];
+  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(g->leaf_cell.reserve(g->n_leaves));
+  HIP_TRY(g->leaf_start.reserve(g->n_leaves));
+  HIP_TRY(g->leaf_count.reserve(g->n_leaves));
+  HIP_TRY(g->leaf_rec.reserve(g->n_leaves));
+  HIP_TRY(g->sorted_idx.reserve(n));
+  HIP_TRY(g->recs.reserve(g->n_cand));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->lut.p, g->leaf_cell.p,
+                                 g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
+  // ---- scatter + finalize
+  HIP_TRY(ndt::launch_scatter(key.p, n, cell_count.p, g->sorted_idx.p, st));
+  HIP_TRY(hipMemsetAsync(totals.p, 0, sizeof(unsigned), st));
+  ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
+                               static_cast<int>(g->n_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
+                               g->lut.p, totals.p, nodump, st));
+  unsigned nv = 0;
+  HIP_TRY(hipMemcpyAsync(&nv, totals.p, sizeof(nv), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  g->n_valid = nv;
+  g->empty = false;
+  h->grid = g;
+  return NDT_OK;
+}
+
+void colmajor_to_T12(const float* m, float* T12) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) T12[r * 4 + c] = m[c * 4 + r];
+}
+
+void fill_eval_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::EvalParams& P) {
+  colmajor_to_T12(rq.T, P.T);
+  ndt::AngleDerivs ad;
+  ndt::angle_derivatives(rq.p, ad);
+  std::memcpy(P.j, ad.j, sizeof(P.j));
+  std::memcpy(P.h, ad.h, sizeof(P.h));
+  P.d1 = gs.d1;
+  P.d2 = static_cast<float>(gs.d2);
+  P.pad = 0;
+}
+
+void fill_h64_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Hess64Params& P) {
+  colmajor_to_T12(rq.T, P.T);
+  ndt::AngleDerivs ad;
+  ndt::angle_derivatives(rq.p, ad);
+  std::memcpy(P.jd, ad.jd, sizeof(P.jd));
+  std::memcpy(P.hd, ad.hd, sizeof(P.hd));
+  P.d1 = gs.d1;
+  P.d2 = gs.d2;
+}
+
+// packed row -> EvalResult
+void unpack_row(const double* row, bool have_h, ndt::EvalResult& r, double* nn) {
+  r.score = row[0];
+  for (int k = 0; k < 6; k++) r.g[k] = row[1 + k];
+  std::memset(r.H, 0, sizeof(r.H));
+  if (have_h) {
+    int idx = 7;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        r.H[i * 6 + j] = row[idx];
+        r.H[j * 6 + i] = row[idx];
+        idx++;
+      }
+  }
+  if (nn) *nn = row[28];
+}
+
+ndt_status check_ready(ndt_context* h) {
+  if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target: call ndt_set_input_target first");
+  if (!h->source) return fail(NDT_ERR_NO_INPUT, "no input source: call ndt_set_input_source first");
+  if (h->search == NDT_KDTREE)
+    return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented (DIRECT26/DIRECT7/DIRECT1 are)");
+  return ensure_device(h);
+}
+
+// one evaluation of a single scan; blocks until the result is on the host
+ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::EvalResult& res, double* nn_total) {
+  const int n = static_cast<int>(h->source->n);
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  ndt_status s = ensure_host_rows(h, 1);
+  if (s) return s;
+  if (n == 0 || h->grid->empty) {  // nothing contributes
+    std::memset(&res, 0, sizeof(res));
+    if (nn_total) *nn_total = 0;
+    return NDT_OK;
+  }
+  const int nblk = ndt::derivative_blocks(n);
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  const ndt::GridView gv = h->grid->view();
+  if (rq.kind == ndt::EVAL_HESSIAN_F64) {
+    ndt::Hess64Params P;
+    fill_h64_params(rq, gs, P);
+    HIP_TRY(ndt::launch_hessian64(h->source->pts.p, n, gv, P, h->search, nullptr, 1, nblk, h->partials.p, h->stream));
+  } else {
+    ndt::EvalParams P;
+    fill_eval_params(rq, gs, P);
+    HIP_TRY(ndt::launch_derivatives(h->source->pts.p, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1,
+                                    rq.kind, nblk, h->partials.p, h->stream));
+  }
+  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->allreduce) {  // point-sharded scan: sum the packed row across ranks
+    if (h->allreduce(h->host_result, ndt::kEvalStride, 0, h->allreduce_user))
+      return fail(NDT_ERR_COMM, "allreduce callback failed");
+  }
+  unpack_row(h->host_result, rq.kind != ndt::EVAL_NO_HESSIAN, res, nn_total);
+  return NDT_OK;
+}
+
+ndt::SolverParams solver_params(const ndt_context* h) {
+  ndt::SolverParams sp;
+  sp.resolution = h->resolution;
+  sp.step_size = h->step_size;
+  sp.outlier_ratio = h->outlier_ratio;
+  sp.trans_eps = h->trans_eps;
+  sp.max_iter = h->max_iter;
+  return sp;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+const char* ndt_last_error(void) { return g_last_error.c_str(); }
+
+int ndt_device_count(void) { return usable_devices(); }
+
+ndt_status ndt_create(int device, ndt_handle* out) {
+  if (!out || device < 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_context* h = new ndt_context();
+  h->device = device;
+  *out = h;
+  return NDT_OK;
+}
+
+ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
+  if (!src || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_context* h = new ndt_context();
+  h->device = src->device;
+  h->resolution = src->resolution;
+  h->step_size = src->step_size;
+  h->outlier_ratio = src->outlier_ratio;
+  h->trans_eps = src->trans_eps;
+  h->max_iter = src->max_iter;
+  h->search = src->search;
+  h->num_threads = src->num_threads;
+  h->min_pts = src->min_pts;
+  h->eig_ratio = src->eig_ratio;
+  h->target = src->target;
+  h->source = src->source;
+  h->target_dense = src->target_dense;
+  h->grid = src->grid;
+  std::memcpy(h->final_T, src->final_T, sizeof(h->final_T));
+  h->converged = src->converged;
+  h->nr_iterations = src->nr_iterations;
+  h->trans_probability = src->trans_probability;
+  h->n_evals = src->n_evals;
+  h->n_hess = src->n_hess;
+  h->mean_neighbors = src->mean_neighbors;
+  *out = h;
+  return NDT_OK;
+}
+
+void ndt_destroy(ndt_handle h) {
+  if (!h) return;
+  if (h->device_ready) (void)hipSetDevice(h->device);
+  delete h;
+}
+
+ndt_status ndt_set_resolution(ndt_handle h, float resolution) {
+  if (!h || !(resolution > 0)) return fail(NDT_ERR_INVALID, "bad resolution");
+  // ndt_omp.h:132-142 -- rebuilds only when a SOURCE (input_) is set
+  if (h->resolution != resolution) {
+    h->resolution = resolution;
+    if (h->source && h->target) return build_grid(h);
+  }
+  return NDT_OK;
+}
+ndt_status ndt_set_step_size(ndt_handle h, double v) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->step_size = v; return NDT_OK; }
+ndt_status ndt_set_outlier_ratio(ndt_handle h, double v) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->outlier_ratio = v; return NDT_OK; }
+ndt_status ndt_set_transformation_epsilon(ndt_handle h, double v) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->trans_eps = v; return NDT_OK; }
+ndt_status ndt_set_maximum_iterations(ndt_handle h, int v) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->max_iter = v; return NDT_OK; }
+ndt_status ndt_set_neighborhood_search_method(ndt_handle h, int m) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->search = m;  // unknown values behave like DIRECT7: the reference's `default:` label
+  return NDT_OK;
+}
+ndt_status ndt_set_num_threads(ndt_handle h, int n) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->num_threads = n; return NDT_OK; }
+ndt_status ndt_set_min_points_per_voxel(ndt_handle h, int n) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->min_pts = (n > 2) ? n : 3;  // voxel_grid_covariance_omp.h:227-239
+  return NDT_OK;
+}
+ndt_status ndt_set_cov_eig_value_inflation_ratio(ndt_handle h, double r) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->eig_ratio = r; return NDT_OK; }
+float ndt_get_resolution(ndt_handle h) { return h ? h->resolution : 0.f; }
+double ndt_get_step_size(ndt_handle h) { return h ? h->step_size : 0.0; }
+double ndt_get_outlier_ratio(ndt_handle h) { return h ? h->outlier_ratio : 0.0; }
+
+static ndt_status set_target_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, bool on_device) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  h->target = c;
+  h->target_dense = is_dense ? 1 : 0;
+  return build_grid(h);  // init(), ndt_omp.h:276-283
+}
+ndt_status ndt_set_input_target(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
+  return set_target_impl(h, pts, n, stride, is_dense, false);
+}
+ndt_status ndt_set_input_target_device(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
+  return set_target_impl(h, pts, n, stride, is_dense, true);
+}
+ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t stride) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  return upload_cloud(h, pts, n, stride, false, h->source);
+}
+ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, size_t stride) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  return upload_cloud(h, pts, n, stride, true, h->source);
+}
+
+ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformation, int* has_converged,
+                     int* final_num_iteration, double* transformation_probability, void* out_cloud,
+                     size_t out_stride_bytes) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  ndt::ScanSolver solver;
+  solver.start(guess, h->source->n, solver_params(h));
+  double nn = 0;
+  while (!solver.done()) {
+    ndt::EvalResult r;
+    double nn_step = 0;
+    const bool counts_neighbors = solver.request().kind != ndt::EVAL_HESSIAN_F64;
+    s = evaluate_single(h, solver.request(), r, &nn_step);
+    if (s) return s;
+    if (counts_neighbors) nn = nn_step;
+    solver.feed(r);
+  }
+  std::memcpy(h->final_T, solver.final_T, sizeof(h->final_T));
+  h->converged = solver.converged ? 1 : 0;
+  h->nr_iterations = solver.nr_iterations;
+  h->trans_probability = solver.trans_probability;
+  h->n_evals = solver.n_evals;
+  h->n_hess = solver.n_hess;
+  h->mean_neighbors = h->source->n ? nn / static_cast<double>(h->source->n) : 0.0;
+  // the aligned cloud = source transformed by the last trial's matrix (trans_cloud of :833/:878)
+  const int n = static_cast<int>(h->source->n);
+  HIP_TRY(h->out_cloud.reserve(n));
+  float T12[12];
+  colmajor_to_T12(h->final_T, T12);
+  HIP_TRY(ndt::launch_transform(h->source->pts.p, n, T12, h->out_cloud.p, h->stream));
+  h->out_n = n;
+  if (out_cloud && n) {
+    if (out_stride_bytes < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+    HIP_TRY(hipMemcpy2DAsync(out_cloud, out_stride_bytes, h->out_cloud.p, sizeof(float4), sizeof(float4), n,
+                             hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ndt_get_result(h, final_transformation, has_converged, final_num_iteration, transformation_probability);
+}
+
+ndt_status ndt_get_result(ndt_handle h, float* final_transformation, int* has_converged, int* final_num_iteration,
+                          double* transformation_probability) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (final_transformation) std::memcpy(final_transformation, h->final_T, sizeof(h->final_T));
+  if (has_converged) *has_converged = h->converged;
+  if (final_num_iteration) *final_num_iteration = h->nr_iterations;
+  if (transformation_probability) *transformation_probability = h->trans_probability;
+  return NDT_OK;
+}
+
+ndt_status ndt_get_output_device(ndt_handle h, const void** d_cloud, size_t* n) {
+  if (!h || !d_cloud || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *d_cloud = h->out_cloud.p;
+  *n = h->out_n;
+  return NDT_OK;
+}
+
+ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hess, double* mean_neighbors) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (n_evals) *n_evals = h->n_evals;
+  if (n_hess) *n_hess = h->n_hess;
+  if (mean_neighbors) *mean_neighbors = h->mean_neighbors;
+  return NDT_OK;
+}
+
+ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride, double* score) {
+  if (!h || !score) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
+  if (h->search == NDT_KDTREE) return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented");
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, cloud, n, stride, false, c);
+  if (s) return s;
+  if (n == 0 || h->grid->empty) {
+    *score = n ? 0.0 : std::numeric_limits<double>::quiet_NaN();  // 0/0 in the reference
+    return NDT_OK;
+  }
+  s = ensure_host_rows(h, 1);
+  if (s) return s;
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  const int nblk = ndt::derivative_blocks(static_cast<int>(n));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(hipMemsetAsync(h->partials.p, 0, static_cast<size_t>(nblk) * ndt::kEvalStride * sizeof(double), h->stream));
+  HIP_TRY(ndt::launch_calc_score(c->pts.p, static_cast<int>(n), h->grid->view(), gs.d1, gs.d2, gs.d3, h->search, nblk,
+                                 h->partials.p, h->stream));
+  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *score = h->host_result[0] / static_cast<double>(n);
+  return NDT_OK;
+}
+
+// ---- batch ---------------------------------------------------------------
+static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
+                                   bool on_device, const float* guesses, float* final_T, int* conv, int* iters,
+                                   double* tprob) {
+  if (!h || !offsets) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
+  if (h->search == NDT_KDTREE) return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented");
+  if (n_scans == 0) return NDT_OK;
+  if (n_scans > 65535) return fail(NDT_ERR_INVALID, "at most 65535 scans per batch");
+  for (size_t k = 0; k < n_scans; k++)
+    if (offsets[k + 1] < offsets[k]) return fail(NDT_ERR_INVALID, "offsets must be non-decreasing");
+  std::shared_ptr<DeviceCloud> cloud;
+  const unsigned char* base = static_cast<const unsigned char*>(pts) + offsets[0] * stride;
+  const size_t total = offsets[n_scans] - offsets[0];
+  ndt_status s = upload_cloud(h, base, total, stride, on_device, cloud);
+  if (s) return s;
+  s = ensure_host_rows(h, n_scans);
+  if (s) return s;
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  std::vector<ndt::ScanSolver> solvers(n_scans);
+  std::vector<ndt::ScanDesc> descs(n_scans);
+  size_t max_n = 0;
+  for (size_t k = 0; k < n_scans; k++) {
+    const size_t cnt = offsets[k + 1] - offsets[k];
+    solvers[k].start(guesses ? guesses + 16 * k : nullptr, cnt, solver_params(h));
+    descs[k].offset = static_cast<int>(offsets[k] - offsets[0]);
+    descs[k].count = static_cast<int>(cnt);
+    descs[k].pad = 0;
+    max_n = std::max(max_n, cnt);
+  }
+  const int nblk = std::max(1, std::min(ndt::derivative_blocks(static_cast<int>(max_n)),
+                                        std::max(8, 4096 / static_cast<int>(n_scans))));
+  HIP_TRY(h->partials.reserve(n_scans * nblk * ndt::kEvalStride));
+  HIP_TRY(h->batch_out.reserve(n_scans * ndt::kEvalStride));
+  HIP_TRY(h->descs.reserve(n_scans));
+  const ndt::GridView gv = h->grid->view();
+  const bool degenerate = h->grid->empty;
+  for (;;) {
+    bool any[3] = {false, false, false};
+    size_t active = 0;
+    for (size_t k = 0; k < n_scans; k++) {
+      const ndt::EvalRequest& rq = solvers[k].request();
+      descs[k].kind = solvers[k].done() ? ndt::EVAL_NONE : rq.kind;
+      if (solvers[k].done()) continue;
+      active++;
+      any[rq.kind] = true;
+      if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, descs[k].P64);
+      else fill_eval_params(rq, gs, descs[k].P);
+    }
+    if (!active) break;
+    if (degenerate) {
+      std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
+    } else {
+      HIP_TRY(hipMemcpyAsync(h->descs.p, descs.data(), n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
+      ndt::EvalParams dummy = {};
+      ndt::Hess64Params dummy64 = {};
+      if (any[0]) HIP_TRY(ndt::launch_derivatives(cloud->pts.p, 0, gv, dummy, h->search, true, h->descs.p, static_cast<int>(n_scans), 0, nblk, h->partials.p, h->stream));
+      if (any[1]) HIP_TRY(ndt::launch_derivatives(cloud->pts.p, 0, gv, dummy, h->search, false, h->descs.p, static_cast<int>(n_scans), 1, nblk, h->partials.p, h->stream));
+      if (any[2]) HIP_TRY(ndt::launch_hessian64(cloud->pts.p, 0, gv, dummy64, h->search, h->descs.p, static_cast<int>(n_scans), nblk, h->partials.p, h->stream));
+      HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, n_scans * ndt::kEvalStride * sizeof(double), h->stream));
+      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
+      if (h->allreduce && h->allreduce_on_device) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->allreduce(h->batch_out.p, n_scans * ndt::kEvalStride, 1, h->allreduce_user))
+          return fail(NDT_ERR_COMM, "allreduce callback failed");
+      }
+      HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, n_scans * ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->allreduce && !h->allreduce_on_device) {
+        if (h->allreduce(h->host_result, n_scans * ndt::kEvalStride, 0, h->allreduce_user))
+          return fail(NDT_ERR_COMM, "allreduce callback failed");
+      }
+    }
+    for (size_t k = 0; k < n_scans; k++) {
+      if (descs[k].kind == ndt::EVAL_NONE) continue;
+      ndt::EvalResult r;
+      unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, nullptr);
+      solvers[k].feed(r);
+    }
+  }
+  for (size_t k = 0; k < n_scans; k++) {
+    if (final_T) std::memcpy(final_T + 16 * k, solvers[k].final_T, 16 * sizeof(float));
+    if (conv) conv[k] = solvers[k].converged ? 1 : 0;
+    if (iters) iters[k] = solvers[k].nr_iterations;
+    if (tprob) tprob[k] = solvers[k].trans_probability;
+  }
+  return NDT_OK;
+}
+
+ndt_status ndt_align_batch(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
+                           const float* guesses, float* final_T, int* conv, int* iters, double* tprob) {
+  return align_batch_impl(h, pts, offsets, n_scans, stride, false, guesses, final_T, conv, iters, tprob);
+}
+ndt_status ndt_align_batch_device(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
+                                  const float* guesses, float* final_T, int* conv, int* iters, double* tprob) {
+  return align_batch_impl(h, pts, offsets, n_scans, stride, true, guesses, final_T, conv, iters, tprob);
+}
+
+ndt_status ndt_set_allreduce(ndt_handle h, ndt_allreduce_fn fn, void* user, int on_device) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  h->allreduce = fn;
+  h->allreduce_user = user;
+  h->allreduce_on_device = on_device;
+  return NDT_OK;
+}
+
+// ---- inspection ------------------------------------------------------------
+static ndt_status eval_impl(ndt_handle h, const float* T, const double* p, double* score, double* g, double* H,
+                            double* mean_nn, int kind) {
+  if (!h || !p) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  ndt::EvalRequest rq;
+  rq.kind = static_cast<ndt::EvalKind>(kind);
+  std::memcpy(rq.p, p, sizeof(rq.p));
+  if (T) std::memcpy(rq.T, T, sizeof(rq.T));
+  else ndt::pose_to_matrix(p, rq.T);
+  ndt::EvalResult r;
+  double nn = 0;
+  s = evaluate_single(h, rq, r, &nn);
+  if (s) return s;
+  if (score) *score = r.score;
+  if (g) std::memcpy(g, r.g, sizeof(r.g));
+  if (H) std::memcpy(H, r.H, sizeof(r.H));
+  if (mean_nn) *mean_nn = h->source->n ? nn / static_cast<double>(h->source->n) : 0.0;
+  return NDT_OK;
+}
+
+ndt_status ndt_eval(ndt_handle h, const double* p, double* score, double* g, double* H, double* mean_nn) {
+  return eval_impl(h, nullptr, p, score, g, H, mean_nn, H ? ndt::EVAL_WITH_HESSIAN : ndt::EVAL_NO_HESSIAN);
+}
+ndt_status ndt_eval_with_matrix(ndt_handle h, const float* T, const double* p, double* score, double* g, double* H,
+                                double* mean_nn) {
+  if (!T) return fail(NDT_ERR_INVALID, "null matrix");
+  return eval_impl(h, T, p, score, g, H, mean_nn, H ? ndt::EVAL_WITH_HESSIAN : ndt::EVAL_NO_HESSIAN);
+}
+ndt_status ndt_eval_hessian_f64(ndt_handle h, const double* p, double* H) {
+  if (!H) return fail(NDT_ERR_INVALID, "null output");
+  return eval_impl(h, nullptr, p, nullptr, nullptr, H, nullptr, ndt::EVAL_HESSIAN_F64);
+}
+
+ndt_status ndt_grid_size(ndt_handle h, size_t* n_leaves, size_t* n_valid) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  if (n_leaves) *n_leaves = h->grid->n_leaves;
+  if (n_valid) *n_valid = h->grid->n_valid;
+  return NDT_OK;
+}
+
+ndt_status ndt_grid_info(ndt_handle h, int* min_b, int* max_b, int* div_b) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  for (int k = 0; k < 3; k++) {
+    if (min_b) min_b[k] = h->grid->geom.min_b[k];
+    if (max_b) max_b[k] = h->grid->geom.max_b[k];
+    if (div_b) div_b[k] = h->grid->geom.div_b[k];
+  }
+  return NDT_OK;
+}
+
+// Re-runs the finalize pass in dump mode (the records and LUT it rewrites are
+// bit-identical, so sharing handles stay valid).
+ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mean, double* cov, double* icov,
+                         double* evals) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  DeviceGrid* g = h->grid.get();
+  const size_t V = g->n_leaves;
+  if (V == 0) return NDT_OK;
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  DevBuf<int> d_n;
+  DevBuf<double> d_mean, d_cov, d_icov, d_evals;
+  DevBuf<unsigned> d_cnt;
+  HIP_TRY(d_n.reserve(V));
+  HIP_TRY(d_mean.reserve(V * 3));
+  HIP_TRY(d_cov.reserve(V * 9));
+  HIP_TRY(d_icov.reserve(V * 9));
+  HIP_TRY(d_evals.reserve(V * 3));
+  HIP_TRY(d_cnt.reserve(1));
+  HIP_TRY(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned), h->stream));
+  ndt::FinalizeDump dump{d_n.p, d_mean.p, d_cov.p, d_icov.p, d_evals.p};
+  HIP_TRY(ndt::launch_finalize(g->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
+                               static_cast<int>(V), g->sorted_idx.p, g->min_pts, g->eig_ratio, g->recs.p, g->lut.p,
+                               d_cnt.p, dump, h->stream));
+  std::vector<int> cell(V);
+  HIP_TRY(hipMemcpyAsync(cell.data(), g->leaf_cell.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (nr_points) HIP_TRY(hipMemcpyAsync(nr_points, d_n.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (mean) HIP_TRY(hipMemcpyAsync(mean, d_mean.p, V * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (cov) HIP_TRY(hipMemcpyAsync(cov, d_cov.p, V * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (icov) HIP_TRY(hipMemcpyAsync(icov, d_icov.p, V * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (evals) HIP_TRY(hipMemcpyAsync(evals, d_evals.p, V * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (idx)
+    for (size_t i = 0; i < V; i++) idx[i] = cell[i];
+  return NDT_OK;
+}
+
+// ---- host-only pieces (no GPU) -------------------------------------------
+void ndt_host_solve6(const double* H, const double* b, double* x) { ndt::solve6(H, b, x); }
+void ndt_host_pose_to_matrix(const double* p, float* T) { ndt::pose_to_matrix(p, T); }
+void ndt_host_matrix_to_pose(const float* T, double* p) { ndt::matrix_to_pose(T, p); }
+void ndt_host_angle_derivatives(const double* p, float* j_ang, float* h_ang, double* j_ang_d, double* h_ang_d) {
+  ndt::AngleDerivs ad;
+  ndt::angle_derivatives(p, ad);
+  if (j_ang) std::memcpy(j_ang, ad.j, sizeof(ad.j));
+  if (h_ang) std::memcpy(h_ang, ad.h, sizeof(ad.h));
+  if (j_ang_d) std::memcpy(j_ang_d, ad.jd, sizeof(ad.jd));
+  if (h_ang_d) std::memcpy(h_ang_d, ad.hd, sizeof(ad.hd));
+}
+void ndt_host_gauss(float resolution, double outlier_ratio, double* d) {
+  const ndt::Gauss g = ndt::gauss_constants(resolution, outlier_ratio);
+  d[0] = g.d1;
+  d[1] = g.d2;
+  d[2] = g.d3;
+}
+
+ndt_status ndt_host_run_driver(ndt_eval_cb cb, void* user, size_t n_source, const float* guess, float resolution,
+                               double step_size, double outlier_ratio, double trans_eps, int max_iter,
+                               float* final_transformation, int* has_converged, int* final_num_iteration,
+                               double* transformation_probability, int* n_evals, int* n_hess) {
+  if (!cb) return fail(NDT_ERR_INVALID, "null callback");
+  ndt::SolverParams sp;
+  sp.resolution = resolution;
+  sp.step_size = step_size;
+  sp.outlier_ratio = outlier_ratio;
+  sp.trans_eps = trans_eps;
+  sp.max_iter = max_iter;
+  ndt::ScanSolver solver;
+  solver.start(guess, n_source, sp);
+  while (!solver.done()) {
+    const ndt::EvalRequest& rq = solver.request();
+    ndt::EvalResult r;
+    std::memset(&r, 0, sizeof(r));
+    if (cb(user, rq.kind, rq.T, rq.p, &r.score, r.g, r.H)) return fail(NDT_ERR_INVALID, "evaluator callback failed");
+    solver.feed(r);
+  }
+  if (final_transformation) std::memcpy(final_transformation, solver.final_T, 16 * sizeof(float));
+  if (has_converged) *has_converged = solver.converged ? 1 : 0;
+  if (final_num_iteration) *final_num_iteration = solver.nr_iterations;
+  if (transformation_probability) *transformation_probability = solver.trans_probability;
+  if (n_evals) *n_evals = solver.n_evals;
+  if (n_hess) *n_hess = solver.n_hess;
+  return NDT_OK;
+}
+
+}  // extern "C"

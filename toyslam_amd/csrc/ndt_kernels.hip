@@ -1,0 +1,983 @@
+// ndt_kernels.hip -- hand-written HIP kernels of the MI355X NDT core (gfx950,
+// wave64).  Two kernel families:
+//
+//  K1  target voxel grid  (VoxelGridCovariance::applyFilter,
+//      voxel_grid_covariance_omp_impl.hpp:48-370):
+//        bbox -> per-cell count (int atomics on the dense cell array)
+//             -> 3-phase exclusive scan over cells (leaf ordinals, segment
+//                offsets, record ordinals, LUT init)
+//             -> counting-sort scatter of point indices
+//             -> per-leaf finalize: index-ordered f64 sums (bit-identical to
+//                the reference's sequential accumulation), mean, covariance
+//                with the reference's quirks, 3x3 symmetric eigen-solve,
+//                eigenvalue inflation, inverse, validity -> 64-B VoxelRec.
+//  K2  per-evaluation score / gradient / Hessian (computeDerivatives,
+//      ndt_omp_impl.hpp:179-285 with updateDerivatives :484-537 fused with the
+//      f32 point transform), plus the all-f64 Hessian (computeHessian
+//      :540-645) and calculateScore (:935-983).
+//
+// HBM-bound gather work: no MFMA (there is no dense contraction).  Loads are
+// 16-B per lane (float4 points, 3 x dwordx4 per 64-B voxel record), the LUT
+// probe + record gather is served from L2 / Infinity Cache for the target
+// sizes of interest, and the 29 f64 accumulators are reduced with wave64
+// shuffles, then LDS across the 4 waves, then a fixed-order second kernel.
+#include "ndt_kernels.hpp"
+
+#include <cfloat>
+
+namespace ndt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+// Block-level sum of NV doubles per thread -> out[0..NV) (written by thread 0's
+// wave).  Fixed butterfly + fixed wave order: deterministic.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ out, double* lds /*[4][NV]*/) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double v = wave_sum(acc[k]);
+    if (lane == 0) lds[wave * NV + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double v = lds[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; w++) v += lds[w * NV + threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+// ---------------------------------------------------------------------------
+// repack: arbitrary-stride xyz records -> dense float4 (x,y,z,1)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_repack(const unsigned char* __restrict__ src, size_t n, size_t stride,
+                                                   float4* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float* p = reinterpret_cast<const float*>(src + i * stride);
+    dst[i] = make_float4(p[0], p[1], p[2], 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1.a  bounding box  ([PCL] getMinMax3D, _impl.hpp:72)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_bbox(const float4* __restrict__ pts, int n, int dense,
+                                                 float* __restrict__ block_minmax) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    if (!dense && !finite3(p.x, p.y, p.z)) continue;
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ float s[kBlock / kWave][6];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float a = wave_min(mn[k]), b = wave_max(mx[k]);
+    if (lane == 0) { s[wave][k] = a; s[wave][3 + k] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v = (threadIdx.x < 3) ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+    block_minmax[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+// linear voxel index of a target point while BUILDING the grid:
+// floor(x * inv_leaf) - float(min_b), _impl.hpp:218-223 (f32, trap 2)
+__device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, float z) {
+#pragma clang fp contract(off)
+  const int i0 = static_cast<int>(floorf(__fmul_rn(x, g.inv_leaf[0])) - static_cast<float>(g.min_b[0]));
+  const int i1 = static_cast<int>(floorf(__fmul_rn(y, g.inv_leaf[1])) - static_cast<float>(g.min_b[1]));
+  const int i2 = static_cast<int>(floorf(__fmul_rn(z, g.inv_leaf[2])) - static_cast<float>(g.min_b[2]));
+  return i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2];
+}
+
+// ---------------------------------------------------------------------------
+// K1.b  per-cell point count
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts, int n, int dense, GridGeom g,
+                                                  int* __restrict__ key, unsigned* __restrict__ cell_count) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    int c = -1;
+    if (dense || finite3(p.x, p.y, p.z)) {
+      c = build_cell(g, p.x, p.y, p.z);
+      // points are inside the bbox by construction; guard against NaN/garbage
+      if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;
+    }
+    key[i] = c;
+    if (c >= 0) atomicAdd(&cell_count[c], 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1.c  exclusive scan over cells of {points, occupied, candidate} counters
+// ---------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;  // 2048 cells per block
+
+struct U3 {
+  unsigned pts, occ, cand;
+};
+__device__ __forceinline__ U3 operator+(const U3& a, const U3& b) { return {a.pts + b.pts, a.occ + b.occ, a.cand + b.cand}; }
+
+// exclusive block scan of one U3 per thread; returns the exclusive prefix and the block total
+__device__ __forceinline__ U3 block_exclusive_scan(U3 v, U3& total, U3* lds /*[kBlock/kWave]*/) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  U3 inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    unsigned a = __shfl_up(inc.pts, off, kWave), b = __shfl_up(inc.occ, off, kWave), c = __shfl_up(inc.cand, off, kWave);
+    if (lane >= off) { inc.pts += a; inc.occ += b; inc.cand += c; }
+  }
+  if (lane == kWave - 1) lds[wave] = inc;
+  __syncthreads();
+  U3 wave_off = {0, 0, 0};
+  U3 tot = {0, 0, 0};
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; w++) {
+    if (w < wave) wave_off = wave_off + lds[w];
+    tot = tot + lds[w];
+  }
+  __syncthreads();
+  total = tot;
+  return {wave_off.pts + inc.pts - v.pts, wave_off.occ + inc.occ - v.occ, wave_off.cand + inc.cand - v.cand};
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ cell_count, long long n_cells,
+                                                        unsigned min_pts, unsigned* __restrict__ block_sums) {
+  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  U3 t = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const long long c = base + k;
+    if (c < n_cells) {
+      const unsigned v = cell_count[c];
+      t.pts += v;
+      t.occ += (v > 0);
+      t.cand += (v >= min_pts);
+    }
+  }
+  __shared__ U3 lds[kBlock / kWave];
+  U3 total;
+  block_exclusive_scan(t, total, lds);
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x * 3 + 0] = total.pts;
+    block_sums[blockIdx.x * 3 + 1] = total.occ;
+    block_sums[blockIdx.x * 3 + 2] = total.cand;
+  }
+}
+
+// single block: in-place exclusive scan of the per-tile sums; totals[3] out
+__global__ __launch_bounds__(kBlock) void k_scan_blocks(unsigned* __restrict__ block_sums, int n_tiles,
+                                                        unsigned* __restrict__ totals) {
+  __shared__ U3 lds[kBlock / kWave];
+  U3 carry = {0, 0, 0};
+  for (int base = 0; base < n_tiles; base += kBlock) {
+    const int i = base + threadIdx.x;
+    U3 v = {0, 0, 0};
+    if (i < n_tiles) v = {block_sums[i * 3 + 0], block_sums[i * 3 + 1], block_sums[i * 3 + 2]};
+    U3 total;
+    U3 ex = block_exclusive_scan(v, total, lds);
+    if (i < n_tiles) {
+      block_sums[i * 3 + 0] = carry.pts + ex.pts;
+      block_sums[i * 3 + 1] = carry.occ + ex.occ;
+      block_sums[i * 3 + 2] = carry.cand + ex.cand;
+    }
+    carry = carry + total;
+  }
+  if (threadIdx.x == 0) {
+    totals[0] = carry.pts;
+    totals[1] = carry.occ;
+    totals[2] = carry.cand;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* __restrict__ cell_count /* -> cursor */,
+                                                       long long n_cells, unsigned min_pts,
+                                                       const unsigned* __restrict__ block_sums, int* __restrict__ lut,
+                                                       int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
+                                                       int* __restrict__ leaf_count, int* __restrict__ leaf_rec) {
+  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+  unsigned cnt[kScanItems];
+  U3 t = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const long long c = base + k;
+    cnt[k] = (c < n_cells) ? cell_count[c] : 0u;
+    t.pts += cnt[k];
+    t.occ += (cnt[k] > 0);
+    t.cand += (cnt[k] >= min_pts);
+  }
+  __shared__ U3 lds[kBlock / kWave];
+  U3 total;
+  U3 ex = block_exclusive_scan(t, total, lds);
+  U3 run = {block_sums[blockIdx.x * 3 + 0] + ex.pts, block_sums[blockIdx.x * 3 + 1] + ex.occ,
+            block_sums[blockIdx.x * 3 + 2] + ex.cand};
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    const long long c = base + k;
+    if (c < n_cells) {
+      lut[c] = -1;
+      cell_count[c] = run.pts;  // scatter cursor
+      if (cnt[k] > 0) {
+        leaf_cell[run.occ] = static_cast<int>(c);
+        leaf_start[run.occ] = run.pts;
+        leaf_count[run.occ] = static_cast<int>(cnt[k]);
+        leaf_rec[run.occ] = (cnt[k] >= min_pts) ? static_cast<int>(run.cand) : -1;
+      }
+      run.pts += cnt[k];
+      run.occ += (cnt[k] > 0);
+      run.cand += (cnt[k] >= min_pts);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1.d  counting-sort scatter of point indices into per-cell segments
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scatter(const int* __restrict__ key, int n, unsigned* __restrict__ cursor,
+                                                    int* __restrict__ sorted_idx) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int c = key[i];
+    if (c >= 0) sorted_idx[atomicAdd(&cursor[c], 1u)] = i;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1.e  per-leaf finalize (second pass of applyFilter, _impl.hpp:282-367)
+// ---------------------------------------------------------------------------
+struct Sym3 {
+  double xx, xy, xz, yy, yz, zz;
+};
+
+// 3x3 symmetric eigen-decomposition (cyclic Jacobi, f64); eigenvalues ascending
+// in w[], eigenvectors in the columns of V.  Stands in for
+// Eigen::SelfAdjointEigenSolver<Matrix3d> (_impl.hpp:275,333-335): only the
+// eigenvalues and V*diag*V^-1 are consumed, both solver-independent to O(eps).
+__device__ void eig3_jacobi(const double A_in[3][3], double w[3], double V[3][3]) {
+  double A[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      A[i][j] = (i >= j) ? A_in[i][j] : A_in[j][i];  // lower triangle, like Eigen
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 50; sweep++) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    const double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    if (off <= 1e-300 || off <= dia * 1e-18) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; pq++) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+      const double apq = A[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+      const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; k++) {
+        const double akp = A[k][p], akq = A[k][q];
+        A[k][p] = c * akp - s * akq;
+        A[k][q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; k++) {
+        const double apk = A[p][k], aqk = A[q][k];
+        A[p][k] = c * apk - s * aqk;
+        A[q][k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; k++) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  // sort ascending (3 elements)
+  double d[3] = {A[0][0], A[1][1], A[2][2]};
+  int o[3] = {0, 1, 2};
+  if (d[o[0]] > d[o[1]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  if (d[o[1]] > d[o[2]]) { int t = o[1]; o[1] = o[2]; o[2] = t; }
+  if (d[o[0]] > d[o[1]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  double Vs[3][3];
+  for (int j = 0; j < 3; j++) {
+    w[j] = d[o[j]];
+    for (int i = 0; i < 3; i++) Vs[i][j] = V[i][o[j]];
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) V[i][j] = Vs[i][j];
+}
+
+// Matrix3d::inverse() as Eigen evaluates it (cofactors, multiply by 1/det)
+__device__ void inv3_cofactor(const double a[3][3], double r[3][3]) {
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return a[i1][j1] * a[i2][j2] - a[i1][j2] * a[i2][j1];
+  };
+  const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+  const double det = (c00 * a[0][0] + c10 * a[1][0]) + c20 * a[2][0];
+  const double invdet = 1.0 / det;
+  r[0][0] = c00 * invdet; r[0][1] = c10 * invdet; r[0][2] = c20 * invdet;
+  r[1][0] = cof(0, 1) * invdet; r[1][1] = cof(1, 1) * invdet; r[1][2] = cof(2, 1) * invdet;
+  r[2][0] = cof(0, 2) * invdet; r[2][1] = cof(1, 2) * invdet; r[2][2] = cof(2, 2) * invdet;
+}
+
+constexpr int kSortLimit = 64;  // leaves up to this size are summed in ascending point order
+
+__global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ pts, const int* __restrict__ leaf_cell,
+                                                     const unsigned* __restrict__ leaf_start,
+                                                     const int* __restrict__ leaf_count,
+                                                     const int* __restrict__ leaf_rec, int n_leaves,
+                                                     int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
+                                                     VoxelRec* __restrict__ recs, int* __restrict__ lut,
+                                                     unsigned* __restrict__ n_valid, FinalizeDump dump) {
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n_leaves) return;
+  const unsigned start = leaf_start[o];
+  const int cnt = leaf_count[o];
+  int* seg = sorted_idx + start;
+
+  // The scatter's atomic cursor leaves the segment in arrival order; restore
+  // ascending point order so the f64 sums below round exactly like the
+  // reference's sequential first pass (_impl.hpp:209-263).
+  if (cnt <= kSortLimit) {
+    for (int i = 1; i < cnt; i++) {
+      const int v = seg[i];
+      int j = i - 1;
+      while (j >= 0 && seg[j] > v) { seg[j + 1] = seg[j]; j--; }
+      seg[j + 1] = v;
+    }
+  } else {  // heap sort, in place
+    auto sift = [&](int root, int end) {
+      for (;;) {
+        int child = 2 * root + 1;
+        if (child > end) break;
+        if (child + 1 <= end && seg[child] < seg[child + 1]) child++;
+        if (seg[root] < seg[child]) { const int t = seg[root]; seg[root] = seg[child]; seg[child] = t; root = child; }
+        else break;
+      }
+    };
+    for (int s = (cnt - 2) / 2; s >= 0; s--) sift(s, cnt - 1);
+    for (int end = cnt - 1; end > 0; end--) {
+      const int t = seg[0]; seg[0] = seg[end]; seg[end] = t;
+      sift(0, end - 1);
+    }
+  }
+
+  // first-pass sums: mean_ += pt ; cov_ += pt*pt^T with cov_ seeded Identity (.h:107)
+  double sx = 0, sy = 0, sz = 0;
+  double cxx = 1, cxy = 0, cxz = 0, cyy = 1, cyz = 0, czz = 1;
+  float fx = 0, fy = 0, fz = 0;  // centroid.head<4>() += pt  (f32, :240-244)
+  for (int i = 0; i < cnt; i++) {
+    const float4 p = pts[seg[i]];
+    const double x = p.x, y = p.y, z = p.z;
+    sx += x; sy += y; sz += z;
+    cxx += x * x; cxy += x * y; cxz += x * z; cyy += y * y; cyz += y * z; czz += z * z;
+    fx += p.x; fy += p.y; fz += p.z;
+  }
+  const double n = cnt;
+  const double ps[3] = {sx, sy, sz};
+  const double mean[3] = {sx / n, sy / n, sz / n};  // :293
+  fx /= static_cast<float>(cnt); fy /= static_cast<float>(cnt); fz /= static_cast<float>(cnt);  // :289
+
+  double cov[3][3] = {{cxx, cxy, cxz}, {cxy, cyy, cyz}, {cxz, cyz, czz}};
+  double icov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double evals[3] = {0, 0, 0};
+  int nr_points = cnt;
+
+  if (cnt >= min_pts) {
+    // :329-330
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) cov[i][j] = (cov[i][j] - 2 * (ps[i] * mean[j])) / n + mean[i] * mean[j];
+    const double f = (n - 1.0) / n;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) cov[i][j] *= f;
+    double w[3], V[3][3];
+    eig3_jacobi(cov, w, V);
+    if (w[0] < 0 || w[1] < 0 || w[2] <= 0) {  // :337-341
+      nr_points = -1;
+    } else {
+      const double min_ev = eig_ratio * w[2];  // :345-356
+      if (w[0] < min_ev) {
+        w[0] = min_ev;
+        if (w[1] < min_ev) w[1] = min_ev;
+        double Vi[3][3], VL[3][3];
+        inv3_cofactor(V, Vi);
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) VL[i][j] = V[i][j] * w[j];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) cov[i][j] = (VL[i][0] * Vi[0][j] + VL[i][1] * Vi[1][j]) + VL[i][2] * Vi[2][j];
+      }
+      evals[0] = w[0]; evals[1] = w[1]; evals[2] = w[2];
+      inv3_cofactor(cov, icov);  // :359
+      double mx = -DBL_MAX, mn = DBL_MAX;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { mx = fmax(mx, icov[i][j]); mn = fmin(mn, icov[i][j]); }
+      if (mx == static_cast<double>(INFINITY) || mn == -static_cast<double>(INFINITY)) nr_points = -1;  // :360-364
+    }
+    if (nr_points >= min_pts) {
+      const int r = leaf_rec[o];
+      VoxelRec rec;
+      rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
+      rec.icov[0] = static_cast<float>(icov[0][0]); rec.icov[1] = static_cast<float>(icov[0][1]);
+      rec.icov[2] = static_cast<float>(icov[0][2]); rec.icov[3] = static_cast<float>(icov[1][1]);
+      rec.icov[4] = static_cast<float>(icov[1][2]); rec.icov[5] = static_cast<float>(icov[2][2]);
+      rec.centroid[0] = fx; rec.centroid[1] = fy; rec.centroid[2] = fz;
+      rec.n = cnt;
+      recs[r] = rec;
+      lut[leaf_cell[o]] = r;
+      atomicAdd(n_valid, 1u);
+    }
+  }
+  if (dump.nr_points) {
+    dump.nr_points[o] = nr_points;
+    for (int k = 0; k < 3; k++) {
+      dump.mean[o * 3 + k] = mean[k];
+      dump.evals[o * 3 + k] = evals[k];
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        dump.cov[o * 9 + i * 3 + j] = cov[i][j];
+        dump.icov[o * 9 + i * 3 + j] = icov[i][j];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2  derivatives
+// ---------------------------------------------------------------------------
+// neighbour offsets: DIRECT7 order of getNeighborhoodAtPoint7 (_impl.hpp:423-430);
+// DIRECT26 = [PCL] getAllNeighborCellIndices(): 13 "half" offsets then their negatives.
+__device__ __constant__ signed char kOff7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+__device__ __constant__ signed char kOff26[26][3] = {
+    {-1, -1, -1}, {-1, 0, -1}, {-1, 1, -1}, {0, -1, -1}, {0, 0, -1}, {0, 1, -1}, {1, -1, -1}, {1, 0, -1}, {1, 1, -1},
+    {-1, -1, 0},  {0, -1, 0},  {1, -1, 0},  {-1, 0, 0},
+    {1, 1, 1},    {1, 0, 1},   {1, -1, 1},  {0, 1, 1},   {0, 0, 1},  {0, -1, 1}, {-1, 1, 1},  {-1, 0, 1}, {-1, -1, 1},
+    {1, 1, 0},    {0, 1, 0},   {-1, 1, 0},  {1, 0, 0}};
+
+template <int NNB>
+__device__ __forceinline__ void nb_offset(int k, int& dx, int& dy, int& dz) {
+  if (NNB == 26) { dx = kOff26[k][0]; dy = kOff26[k][1]; dz = kOff26[k][2]; }
+  else { dx = kOff7[k][0]; dy = kOff7[k][1]; dz = kOff7[k][2]; }
+}
+
+// [PCL 1.10] Transformer<float>::se3: x*c0 + (y*c1 + (z*c2 + c3)), f32, unfused.
+__device__ __forceinline__ void xform_point(const float* T, float x, float y, float z, float& ox, float& oy, float& oz) {
+#pragma clang fp contract(off)
+  ox = __fadd_rn(__fmul_rn(x, T[0]), __fadd_rn(__fmul_rn(y, T[1]), __fadd_rn(__fmul_rn(z, T[2]), T[3])));
+  oy = __fadd_rn(__fmul_rn(x, T[4]), __fadd_rn(__fmul_rn(y, T[5]), __fadd_rn(__fmul_rn(z, T[6]), T[7])));
+  oz = __fadd_rn(__fmul_rn(x, T[8]), __fadd_rn(__fmul_rn(y, T[9]), __fadd_rn(__fmul_rn(z, T[10]), T[11])));
+}
+
+// voxel coordinate while SEARCHING: floor(x / leaf), _impl.hpp:379-381 (division, trap 2)
+__device__ __forceinline__ void search_ijk(const GridGeom& g, float x, float y, float z, int& i, int& j, int& k) {
+  i = static_cast<int>(floorf(__fdiv_rn(x, g.leaf[0])));
+  j = static_cast<int>(floorf(__fdiv_rn(y, g.leaf[1])));
+  k = static_cast<int>(floorf(__fdiv_rn(z, g.leaf[2])));
+}
+
+// record index of voxel (i+dx, j+dy, k+dz) or -1  (_impl.hpp:382-399)
+__device__ __forceinline__ int probe(const GridView& gv, int i, int j, int k, int dx, int dy, int dz) {
+  const int ci = i + dx, cj = j + dy, ck = k + dz;
+  if (ci < gv.g.min_b[0] || ci > gv.g.max_b[0] || cj < gv.g.min_b[1] || cj > gv.g.max_b[1] || ck < gv.g.min_b[2] ||
+      ck > gv.g.max_b[2])
+    return -1;
+  const int cell = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
+  return gv.lut[cell];
+}
+
+// coarse reject so that i+d cannot overflow and far-away points cost nothing
+__device__ __forceinline__ bool near_grid(const GridGeom& g, int i, int j, int k) {
+  return i >= g.min_b[0] - 1 && i <= g.max_b[0] + 1 && j >= g.min_b[1] - 1 && j <= g.max_b[1] + 1 && k >= g.min_b[2] - 1 &&
+         k <= g.max_b[2] + 1;
+}
+
+struct RecRegs {
+  double mx, my, mz;
+  float c00, c01, c02, c11, c12, c22;
+};
+__device__ __forceinline__ RecRegs load_rec(const VoxelRec* __restrict__ recs, int r) {
+  const float4* p = reinterpret_cast<const float4*>(recs + r);
+  const float4 a = p[0], b = p[1], c = p[2];
+  RecRegs o;
+  o.mx = __hiloint2double(__float_as_int(a.y), __float_as_int(a.x));
+  o.my = __hiloint2double(__float_as_int(a.w), __float_as_int(a.z));
+  o.mz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+  o.c00 = b.z; o.c01 = b.w; o.c02 = c.x; o.c11 = c.y; o.c12 = c.z; o.c22 = c.w;
+  return o;
+}
+
+// per-point pieces of computePointDerivatives (f32, ndt_omp_impl.hpp:398-440):
+// xj = j_ang * x (8), xh = h_ang * x (15)
+struct PointDeriv {
+  float j[8];
+  float h[15];
+};
+template <class P>
+__device__ __forceinline__ void point_derivatives(const P& prm, float x, float y, float z, PointDeriv& d, bool want_h) {
+#pragma unroll
+  for (int r = 0; r < 8; r++) d.j[r] = (prm.j[r][0] * x + prm.j[r][1] * y) + prm.j[r][2] * z;
+  if (want_h) {
+#pragma unroll
+    for (int r = 0; r < 15; r++) d.h[r] = (prm.h[r][0] * x + prm.h[r][1] * y) + prm.h[r][2] * z;
+  }
+}
+
+// updateDerivatives (ndt_omp_impl.hpp:484-537) for one (point, voxel) pair.
+// f32 arithmetic in the reference's operation order with the structural zeros
+// of J_E / H_E skipped (those products are exact zeros there); f64 accumulation.
+// acc: [0]=score [1..6]=gradient [7..27]=Hessian upper triangle [28]=neighbour count
+template <bool WANT_H>
+__device__ __forceinline__ void accumulate_neighbor(double (&acc)[kNumAcc], const PointDeriv& d, float x0, float x1,
+                                                    float x2, const RecRegs& r, double d1, float d2) {
+  // xc = x'^T C   (x_trans4 * c_inv4)
+  const float xc0 = (x0 * r.c00 + x1 * r.c01) + x2 * r.c02;
+  const float xc1 = (x0 * r.c01 + x1 * r.c11) + x2 * r.c12;
+  const float xc2 = (x0 * r.c02 + x1 * r.c12) + x2 * r.c22;
+  const float q = (x0 * xc0 + x1 * xc1) + x2 * xc2;
+  float e = expf(-d2 * q * 0.5f);                              // :499
+  const float score_inc = static_cast<float>(-d1 * static_cast<double>(e));  // :501
+  e = d2 * e;                                                  // :503
+  if (e > 1.0f || e < 0.0f || e != e) return;                  // :506-507 (adds nothing, not even the score)
+  e = static_cast<float>(static_cast<double>(e) * d1);         // :510
+  acc[0] += static_cast<double>(score_inc);
+  acc[28] += 1.0;
+
+  // CJ = C * J_E columns 3..5 (columns 0..2 are the columns of C)
+  const float* j = d.j;
+  const float cj03 = r.c01 * j[0] + r.c02 * j[1], cj13 = r.c11 * j[0] + r.c12 * j[1], cj23 = r.c12 * j[0] + r.c22 * j[1];
+  const float cj04 = (r.c00 * j[2] + r.c01 * j[3]) + r.c02 * j[4];
+  const float cj14 = (r.c01 * j[2] + r.c11 * j[3]) + r.c12 * j[4];
+  const float cj24 = (r.c02 * j[2] + r.c12 * j[3]) + r.c22 * j[4];
+  const float cj05 = (r.c00 * j[5] + r.c01 * j[6]) + r.c02 * j[7];
+  const float cj15 = (r.c01 * j[5] + r.c11 * j[6]) + r.c12 * j[7];
+  const float cj25 = (r.c02 * j[5] + r.c12 * j[6]) + r.c22 * j[7];
+  // g = x'^T CJ
+  float g[6];
+  g[0] = xc0; g[1] = xc1; g[2] = xc2;
+  g[3] = (x0 * cj03 + x1 * cj13) + x2 * cj23;
+  g[4] = (x0 * cj04 + x1 * cj14) + x2 * cj24;
+  g[5] = (x0 * cj05 + x1 * cj15) + x2 * cj25;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc[1 + k] += static_cast<double>(e * g[k]);  // :515
+
+  if (WANT_H) {
+    // JCJ(b,a) = J_E[:,b] . CJ[:,a]   needed for a <= b
+    const float CJ[3][6] = {{r.c00, r.c01, r.c02, cj03, cj04, cj05},
+                            {r.c01, r.c11, r.c12, cj13, cj14, cj15},
+                            {r.c02, r.c12, r.c22, cj23, cj24, cj25}};
+    // x'^T C H_E blocks (symmetric 3x3 in the angle indices): a b c / b d e / c e f
+    const float* h = d.h;
+    const float xa = xc1 * h[0] + xc2 * h[1];
+    const float xb = xc1 * h[2] + xc2 * h[3];
+    const float xcc = xc1 * h[4] + xc2 * h[5];
+    const float xd = (xc0 * h[6] + xc1 * h[7]) + xc2 * h[8];
+    const float xe = (xc0 * h[9] + xc1 * h[10]) + xc2 * h[11];
+    const float xf = (xc0 * h[12] + xc1 * h[13]) + xc2 * h[14];
+    const float xH[3][3] = {{xa, xb, xcc}, {xb, xd, xe}, {xcc, xe, xf}};
+    int idx = 7;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int jj = i; jj < 6; jj++) {
+        // JCJ(jj, i)
+        float jcj;
+        if (jj < 3) jcj = CJ[jj][i];
+        else if (jj == 3) jcj = j[0] * CJ[1][i] + j[1] * CJ[2][i];
+        else if (jj == 4) jcj = (j[2] * CJ[0][i] + j[3] * CJ[1][i]) + j[4] * CJ[2][i];
+        else jcj = (j[5] * CJ[0][i] + j[6] * CJ[1][i]) + j[7] * CJ[2][i];
+        const float xh = (i >= 3) ? xH[i - 3][jj - 3] : 0.0f;
+        const float term = e * (((-d2 * g[i]) * g[jj] + xh) + jcj);  // :529-531
+        acc[idx++] += static_cast<double>(term);
+      }
+    }
+  }
+}
+
+template <int NNB, bool WANT_H, class P>
+__device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
+                                                 int first, int stride, double (&acc)[kNumAcc]) {
+  for (int i = first; i < n; i += stride) {
+    const float4 pt = src[i];
+    float tx, ty, tz;
+    xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    int vi, vj, vk;
+    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    int rec[NNB];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NNB; k++) {
+      int dx, dy, dz;
+      nb_offset<NNB>(k, dx, dy, dz);
+      rec[k] = probe(gv, vi, vj, vk, dx, dy, dz);
+      any |= (rec[k] >= 0);
+    }
+    if (!any) continue;
+    PointDeriv d;
+    point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
+#pragma unroll
+    for (int k = 0; k < NNB; k++) {
+      if (rec[k] < 0) continue;
+      const RecRegs r = load_rec(gv.recs, rec[k]);
+      // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
+      const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
+      const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
+      const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
+      accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, r, prm.d1, prm.d2);
+    }
+  }
+}
+
+template <int NNB, bool WANT_H, bool BATCH>
+__global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
+                                                        const ScanDesc* __restrict__ descs, int kind,
+                                                        double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * kNumAcc];
+  __shared__ EvalParams sP;
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  double* out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * kEvalStride;
+  if (BATCH) {
+    const ScanDesc* dsc = descs + blockIdx.y;
+    if (dsc->kind != kind) return;  // block-uniform
+    const int* sp = reinterpret_cast<const int*>(&dsc->P);
+    int* dp = reinterpret_cast<int*>(&sP);
+    for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
+    __syncthreads();
+    derivatives_body<NNB, WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+  } else {
+    derivatives_body<NNB, WANT_H>(src, n, gv, P, first, stride, acc);
+  }
+  block_reduce_store<kNumAcc>(acc, out, lds);
+}
+
+// ---------------------------------------------------------------------------
+// computeHessian / updateHessian, all f64 (ndt_omp_impl.hpp:540-645, 443-481)
+// acc layout identical to k_derivatives (only [7..27] are written).
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ void hessian64_neighbor(double (&acc)[kNumAcc], const P& prm, double px, double py, double pz,
+                                                   double x0, double x1, double x2, const double C[3][3]) {
+  auto dot = [](const double a[3], double b0, double b1, double b2) { return (a[0] * b0 + a[1] * b1) + a[2] * b2; };
+  double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+  J[1][3] = dot(prm.jd[0], px, py, pz); J[2][3] = dot(prm.jd[1], px, py, pz);
+  J[0][4] = dot(prm.jd[2], px, py, pz); J[1][4] = dot(prm.jd[3], px, py, pz); J[2][4] = dot(prm.jd[4], px, py, pz);
+  J[0][5] = dot(prm.jd[5], px, py, pz); J[1][5] = dot(prm.jd[6], px, py, pz); J[2][5] = dot(prm.jd[7], px, py, pz);
+  double xh[15];
+#pragma unroll
+  for (int r = 0; r < 15; r++) xh[r] = dot(prm.hd[r], px, py, pz);
+  const double xt[3] = {x0, x1, x2};
+  double Cx[3];
+  for (int i = 0; i < 3; i++) Cx[i] = (C[i][0] * x0 + C[i][1] * x1) + C[i][2] * x2;
+  double e = prm.d2 * exp(-prm.d2 * ((x0 * Cx[0] + x1 * Cx[1]) + x2 * Cx[2]) / 2);  // :622
+  if (e > 1 || e < 0 || e != e) return;                                             // :625-626
+  e *= prm.d1;
+  // H_E vectors a..f (blocks (3,3)=a (3,4)=b (3,5)=c (4,4)=d (4,5)=e (5,5)=f)
+  const double hv[6][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]},
+                           {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
+  const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  double CJ[3][6], xCJ[6];
+  for (int k = 0; k < 6; k++) {
+    for (int i = 0; i < 3; i++) CJ[i][k] = (C[i][0] * J[0][k] + C[i][1] * J[1][k]) + C[i][2] * J[2][k];
+    xCJ[k] = (xt[0] * CJ[0][k] + xt[1] * CJ[1][k]) + xt[2] * CJ[2][k];
+  }
+  int idx = 7;
+  for (int i = 0; i < 6; i++)
+    for (int jj = i; jj < 6; jj++) {
+      double xCH = 0.0;
+      if (i >= 3) {
+        const double* hb = hv[hsel[i - 3][jj - 3]];
+        double Ch[3];
+        for (int r = 0; r < 3; r++) Ch[r] = (C[r][0] * hb[0] + C[r][1] * hb[1]) + C[r][2] * hb[2];
+        xCH = (xt[0] * Ch[0] + xt[1] * Ch[1]) + xt[2] * Ch[2];
+      }
+      const double jcj = (J[0][jj] * CJ[0][i] + J[1][jj] * CJ[1][i]) + J[2][jj] * CJ[2][i];
+      acc[idx++] += e * (-prm.d2 * xCJ[i] * xCJ[jj] + xCH + jcj);  // :639-641
+    }
+}
+
+template <int NNB, bool BATCH>
+__global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__ src, int n, GridView gv, Hess64Params P,
+                                                      const ScanDesc* __restrict__ descs, double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * kNumAcc];
+  __shared__ Hess64Params sP;
+  double acc[kNumAcc];
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  double* out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * kEvalStride;
+  const Hess64Params* prm = &P;
+  if (BATCH) {
+    const ScanDesc* dsc = descs + blockIdx.y;
+    if (dsc->kind != 2) return;
+    const int* sp = reinterpret_cast<const int*>(&dsc->P64);
+    int* dp = reinterpret_cast<int*>(&sP);
+    for (int t = threadIdx.x; t < static_cast<int>(sizeof(Hess64Params) / 4); t += kBlock) dp[t] = sp[t];
+    __syncthreads();
+    src += dsc->offset;
+    n = dsc->count;
+    prm = &sP;
+  }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 pt = src[i];
+    float tx, ty, tz;
+    xform_point(prm->T, pt.x, pt.y, pt.z, tx, ty, tz);
+    int vi, vj, vk;
+    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    for (int k = 0; k < NNB; k++) {
+      int dx, dy, dz;
+      nb_offset<NNB>(k, dx, dy, dz);
+      const int rix = probe(gv, vi, vj, vk, dx, dy, dz);
+      if (rix < 0) continue;
+      const RecRegs r = load_rec(gv.recs, rix);
+      // f64 path reads the f64 icov; the record keeps its f32 rounding
+      const double C[3][3] = {{r.c00, r.c01, r.c02}, {r.c01, r.c11, r.c12}, {r.c02, r.c12, r.c22}};
+      hessian64_neighbor(acc, *prm, pt.x, pt.y, pt.z, static_cast<double>(tx) - r.mx, static_cast<double>(ty) - r.my,
+                         static_cast<double>(tz) - r.mz, C);
+    }
+  }
+  block_reduce_store<kNumAcc>(acc, out, lds);
+}
+
+// ---------------------------------------------------------------------------
+// fixed-order reduction of the per-block partials
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ partials, int n_blocks,
+                                                   const ScanDesc* __restrict__ descs, double* __restrict__ out) {
+  const int scan = blockIdx.x;
+  if (descs && descs[scan].kind == 3) return;  // EVAL_NONE: row left untouched
+  constexpr int kParts = kBlock / kEvalStride;  // 8
+  const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
+  const double* base = partials + static_cast<size_t>(scan) * n_blocks * kEvalStride;
+  double v = 0.0;
+  if (k < kNumAcc)
+    for (int b = part; b < n_blocks; b += kParts) v += base[static_cast<size_t>(b) * kEvalStride + k];
+  __shared__ double s[kParts][kEvalStride];
+  s[part][k] = v;
+  __syncthreads();
+  if (threadIdx.x < kEvalStride) {
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < kParts; p++) t += s[p][threadIdx.x];
+    out[static_cast<size_t>(scan) * kEvalStride + threadIdx.x] = t;
+  }
+}
+
+// transformed source cloud ("output" of align), w = 1
+__global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__ src, int n, EvalParams P,
+                                                      float4* __restrict__ dst) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 pt = src[i];
+    float tx, ty, tz;
+    xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    dst[i] = make_float4(tx, ty, tz, 1.0f);
+  }
+}
+
+// calculateScore (ndt_omp_impl.hpp:935-983): cloud used as given, f64 throughout
+template <int NNB>
+__global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict__ cloud, int n, GridView gv, double d1,
+                                                       double d2, double d3, double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * 1];
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 pt = cloud[i];
+    int vi, vj, vk;
+    search_ijk(gv.g, pt.x, pt.y, pt.z, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    int rec[NNB];
+    int cnt = 0;
+    for (int k = 0; k < NNB; k++) {
+      int dx, dy, dz;
+      nb_offset<NNB>(k, dx, dy, dz);
+      rec[k] = probe(gv, vi, vj, vk, dx, dy, dz);
+      cnt += (rec[k] >= 0);
+    }
+    for (int k = 0; k < NNB; k++) {
+      if (rec[k] < 0) continue;
+      const RecRegs r = load_rec(gv.recs, rec[k]);
+      const double x0 = static_cast<double>(pt.x) - r.mx, x1 = static_cast<double>(pt.y) - r.my,
+                   x2 = static_cast<double>(pt.z) - r.mz;
+      const double c0 = (static_cast<double>(r.c00) * x0 + static_cast<double>(r.c01) * x1) + static_cast<double>(r.c02) * x2;
+      const double c1 = (static_cast<double>(r.c01) * x0 + static_cast<double>(r.c11) * x1) + static_cast<double>(r.c12) * x2;
+      const double c2 = (static_cast<double>(r.c02) * x0 + static_cast<double>(r.c12) * x1) + static_cast<double>(r.c22) * x2;
+      const double e = exp(-d2 * ((x0 * c0 + x1 * c1) + x2 * c2) / 2);
+      acc[0] += (-d1 * e - d3) / cnt;
+    }
+  }
+  block_reduce_store<1>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
+}
+
+inline int grid_for(size_t n, int max_blocks) {
+  size_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > static_cast<size_t>(max_blocks)) b = max_blocks;
+  return static_cast<int>(b);
+}
+
+}  // namespace
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+int derivative_blocks(int n) { return grid_for(static_cast<size_t>(n), 1024); }
+
+hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_repack, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream,
+                     static_cast<const unsigned char*>(d_src), n, stride_bytes, d_dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, pts, n, dense, d_block_minmax);
+  return hipGetLastError();
+}
+
+hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_cell_count,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, pts, n, dense, g, d_key, d_cell_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
+                              int n_tiles, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_reduce, dim3(n_tiles), dim3(kBlock), 0, stream, d_cell_count, n_cells,
+                     static_cast<unsigned>(min_pts), d_block_sums);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kBlock), 0, stream, d_block_sums, n_tiles, d_totals);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
+                             const unsigned* d_block_sums, int n_tiles, int* d_lut, int* d_leaf_cell,
+                             unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(kBlock), 0, stream, d_cell_count_to_cursor, n_cells,
+                     static_cast<unsigned>(min_pts), d_block_sums, d_lut, d_leaf_cell, d_leaf_start, d_leaf_count,
+                     d_leaf_rec);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter(const int* d_key, int n, unsigned* d_cursor, int* d_sorted_idx, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scatter, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, d_key, n, d_cursor, d_sorted_idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
+                           const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
+                           FinalizeDump dump, hipStream_t stream) {
+  if (n_leaves == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
+                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
+                     d_n_valid, dump);
+  return hipGetLastError();
+}
+
+int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile - 1) / kScanTile); }
+
+template <int NNB, bool WANT_H>
+static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
+                           int n_scans, int kind, int n_blocks, double* partials, hipStream_t stream) {
+  if (descs)
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src, n, gv,
+                       P, descs, kind, partials);
+  else
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n, gv, P,
+                       descs, kind, partials);
+}
+
+hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
+                              bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
+                              double* partials, hipStream_t stream) {
+  // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
+  if (search == 1) {
+    if (want_hessian) launch_deriv_t<26, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<26, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  } else if (search == 3) {
+    if (want_hessian) launch_deriv_t<1, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<1, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  } else {
+    if (want_hessian) launch_deriv_t<7, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  }
+  return hipGetLastError();
+}
+
+template <int NNB>
+static void launch_h64_t(const float4* src, int n, const GridView& gv, const Hess64Params& P, const ScanDesc* descs,
+                         int n_scans, int n_blocks, double* partials, hipStream_t stream) {
+  if (descs)
+    hipLaunchKernelGGL((k_hessian64<NNB, true>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src, n, gv, P, descs,
+                       partials);
+  else
+    hipLaunchKernelGGL((k_hessian64<NNB, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n, gv, P, descs,
+                       partials);
+}
+
+hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
+                            const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream) {
+  if (search == 1) launch_h64_t<26>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
+  else if (search == 3) launch_h64_t<1>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
+  else launch_h64_t<7>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce, dim3(n_scans), dim3(kBlock), 0, stream, partials, n_blocks, descs, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  EvalParams P = {};
+  for (int i = 0; i < 12; i++) P.T[i] = T12[i];
+  hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, src, n, P, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3, int search,
+                             int n_blocks, double* partials, hipStream_t stream) {
+  if (search == 1)
+    hipLaunchKernelGGL(k_calc_score<26>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+  else if (search == 3)
+    hipLaunchKernelGGL(k_calc_score<1>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+  else
+    hipLaunchKernelGGL(k_calc_score<7>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+  return hipGetLastError();
+}
+
+}  // namespace ndt

@@ -1,0 +1,120 @@
+// ndt_kernels.hpp -- device-side data layout shared by the HIP kernels and the
+// C-ABI glue of the MI355X NDT core (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ndt {
+
+// One valid target voxel, exactly one 64-byte sector (half a 128-B L2 line):
+//   mean  : 3 x f64  -- the reference subtracts the f64 mean from the f32 point
+//                       in f64 and only then rounds to f32 (ndt_omp_impl.hpp:262,492)
+//   icov  : 6 x f32  -- upper triangle xx,xy,xz,yy,yz,zz of Sigma^-1, stored as the
+//                       f32 the reference casts to per use (:494)
+//   cx,cy,cz : f32 centroid (voxel_centroids_ entry), n : point count
+struct alignas(64) VoxelRec {
+  double mean[3];
+  float icov[6];
+  float centroid[3];
+  int n;
+};
+static_assert(sizeof(VoxelRec) == 64, "VoxelRec must be one 64-B sector");
+
+// VoxelGridCovariance geometry (voxel_grid_covariance_omp_impl.hpp:87-103).
+struct GridGeom {
+  float leaf[3];
+  float inv_leaf[3];
+  int min_b[3];
+  int max_b[3];
+  int div_b[3];
+  int mul[3];
+  long long n_cells;
+};
+
+struct GridView {
+  const int* lut;        // n_cells entries: record index or -1
+  const VoxelRec* recs;  // valid voxels
+  GridGeom g;
+};
+
+// Per-evaluation constants of computeDerivatives (ndt_omp_impl.hpp:179-285).
+struct EvalParams {
+  float T[12];      // row-major 3x4 f32 transform applied to the source
+  float j[8][3];    // j_ang  (:338-346)
+  float h[15][3];   // h_ang  (:373-393), row 6 with +sy
+  double d1;        // gauss_d1_ (used as double, :501,510)
+  float d2;         // gauss_d2_ cast to float (:496)
+  int pad;
+};
+
+// computeHessian's all-f64 constants (:540-645).
+struct Hess64Params {
+  float T[12];
+  double jd[8][3];
+  double hd[15][3];
+  double d1, d2;
+};
+
+// Batched launches: one descriptor per scan.
+struct ScanDesc {
+  int offset;  // first point of the scan in the concatenated source
+  int count;
+  int kind;    // ndt::EvalKind of this step (EVAL_NONE = skip)
+  int pad;
+  EvalParams P;
+  Hess64Params P64;
+};
+
+// Packed result row: score, g[6], H upper triangle row-major [21], n_neighbors,
+// 3 spare  (NDT_EVAL_STRIDE doubles).
+constexpr int kEvalStride = 32;
+constexpr int kNumAcc = 29;
+
+// --- launchers (ndt_kernels.hip) -------------------------------------------
+// All launch on `stream` and return the first HIP error.
+hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream);
+
+struct GridBuildScratch;  // opaque, owned by the grid
+hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
+hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_cell_count,
+                        hipStream_t stream);
+hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
+                              int n_tiles, hipStream_t stream);
+hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream);
+hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
+                             const unsigned* d_block_sums, int n_tiles, int* d_lut, int* d_leaf_cell,
+                             unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream);
+hipError_t launch_scatter(const int* d_key, int n, unsigned* d_cursor, int* d_sorted_idx, hipStream_t stream);
+
+struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
+  int* nr_points;
+  double* mean;
+  double* cov;
+  double* icov;
+  double* evals;
+};
+hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
+                           const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
+                           FinalizeDump dump, hipStream_t stream);
+
+// K2: derivatives.  search: NDT_DIRECT26/7/1.  Single scan (descs == nullptr,
+// params by value) or batch (grid.y = n_scans, blocks whose desc.kind !=
+// kind are skipped).  partials: [n_scans][n_blocks][kEvalStride].
+hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
+                              bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
+                              double* partials, hipStream_t stream);
+hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
+                            const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
+// Sums the per-block partials in a fixed order: out[scan][kEvalStride].
+hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
+                         hipStream_t stream);
+hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream);
+hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
+                             int search, int n_blocks, double* partials, hipStream_t stream);
+
+int derivative_blocks(int n);  // grid size used for n source points
+int scan_tiles(long long n_cells);  // number of 2048-cell tiles of the cell scan
+
+}  // namespace ndt

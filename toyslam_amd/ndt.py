@@ -1,0 +1,321 @@
+"""Python host-side mirror of pclomp::NormalDistributionsTransform over the C-ABI.
+
+Method names follow the reference class (ndt_omp/include/pclomp/ndt_omp.h:70-502
+and the pcl::Registration methods its callers use) so that tests read like the
+reference's call sites (ndt_omp/apps/align.cpp:14-33,
+lidar_subscriber/src/ndt_omp_mapping_node.cpp:151-169).  All compute happens in
+libndt_mi355.so on the GPU; nothing here falls back to numpy.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIRECT1, DIRECT7, DIRECT26, KDTREE, NdtError, check  # noqa: F401
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _cloud(a):
+    """(N, >=3) float32 C-contiguous view; stride = row bytes (16 for XYZ+pad, 32 for XYZI...)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must be (N, >=3)")
+    return a
+
+
+def _colmajor(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).reshape(16)
+
+
+def _from_colmajor(v):
+    return np.asarray(v, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class NormalDistributionsTransform:
+    """Drop-in shaped like pclomp::NormalDistributionsTransform<PointT, PointT>."""
+
+    def __init__(self, device=0, _handle=None):
+        self._L = _lib.lib()
+        if _handle is None:
+            h = C.c_void_p()
+            check(self._L.ndt_create(device, C.byref(h)))
+            self._h = h
+        else:
+            self._h = _handle
+        self._keep = []  # keeps callback objects alive
+
+    def __del__(self):
+        try:
+            self._L.ndt_destroy(self._h)
+        except Exception:
+            pass
+
+    def copy(self):
+        """Copy-construction (the nodes return the object by value): shares the device grid."""
+        h = C.c_void_p()
+        check(self._L.ndt_clone(self._h, C.byref(h)))
+        return NormalDistributionsTransform(_handle=h)
+
+    # ---- pclomp setters / getters (ndt_omp.h:115-209) -------------------------
+    def setNumThreads(self, n):
+        check(self._L.ndt_set_num_threads(self._h, int(n)))
+
+    def setResolution(self, r):
+        check(self._L.ndt_set_resolution(self._h, float(r)))
+
+    def getResolution(self):
+        return self._L.ndt_get_resolution(self._h)
+
+    def setStepSize(self, s):
+        check(self._L.ndt_set_step_size(self._h, float(s)))
+
+    def getStepSize(self):
+        return self._L.ndt_get_step_size(self._h)
+
+    def setOutlierRatio(self, r):
+        check(self._L.ndt_set_outlier_ratio(self._h, float(r)))
+
+    def getOutlierRatio(self):
+        return self._L.ndt_get_outlier_ratio(self._h)
+
+    def setNeighborhoodSearchMethod(self, m):
+        check(self._L.ndt_set_neighborhood_search_method(self._h, int(m)))
+
+    def setTransformationEpsilon(self, e):
+        check(self._L.ndt_set_transformation_epsilon(self._h, float(e)))
+
+    def setMaximumIterations(self, n):
+        check(self._L.ndt_set_maximum_iterations(self._h, int(n)))
+
+    def setMinPointPerVoxel(self, n):
+        check(self._L.ndt_set_min_points_per_voxel(self._h, int(n)))
+
+    def setCovEigValueInflationRatio(self, r):
+        check(self._L.ndt_set_cov_eig_value_inflation_ratio(self._h, float(r)))
+
+    # ---- inputs -------------------------------------------------------------------
+    def setInputTarget(self, cloud, is_dense=True):
+        a = _cloud(cloud)
+        check(self._L.ndt_set_input_target(self._h, a.ctypes.data, a.shape[0], a.strides[0], int(is_dense)))
+
+    def setInputSource(self, cloud):
+        a = _cloud(cloud)
+        check(self._L.ndt_set_input_source(self._h, a.ctypes.data, a.shape[0], a.strides[0]))
+
+    def setInputTargetDevice(self, dev_ptr, n, stride_bytes, is_dense=True):
+        check(self._L.ndt_set_input_target_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense)))
+
+    def setInputSourceDevice(self, dev_ptr, n, stride_bytes):
+        check(self._L.ndt_set_input_source_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes))
+
+    # ---- registration -------------------------------------------------------------
+    def align(self, guess=None, n_out=None):
+        """align(output[, guess]).  Returns the aligned cloud (N,4) when n_out is given, else None."""
+        g = None if guess is None else _colmajor(guess)
+        out = np.zeros((n_out, 4), dtype=np.float32) if n_out else None
+        check(self._L.ndt_align(self._h, _f(g) if g is not None else None, None, None, None, None,
+                                out.ctypes.data if out is not None else None, 16))
+        return out
+
+    def _result(self):
+        T = np.zeros(16, dtype=np.float32)
+        conv, it = C.c_int(0), C.c_int(0)
+        tp = C.c_double(0)
+        check(self._L.ndt_get_result(self._h, _f(T), C.byref(conv), C.byref(it), C.byref(tp)))
+        return _from_colmajor(T), bool(conv.value), it.value, tp.value
+
+    def hasConverged(self):
+        return self._result()[1]
+
+    def getFinalTransformation(self):
+        return self._result()[0]
+
+    def getFinalNumIteration(self):
+        return self._result()[2]
+
+    def getTransformationProbability(self):
+        return self._result()[3]
+
+    def stats(self):
+        ne, nh = C.c_int(0), C.c_int(0)
+        nn = C.c_double(0)
+        check(self._L.ndt_get_stats(self._h, C.byref(ne), C.byref(nh), C.byref(nn)))
+        return dict(n_evals=ne.value, n_hessian_recomputes=nh.value, mean_neighbors=nn.value)
+
+    def output_device(self):
+        p = C.c_void_p()
+        n = C.c_size_t(0)
+        check(self._L.ndt_get_output_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def calculateScore(self, cloud):
+        a = _cloud(cloud)
+        s = C.c_double(0)
+        check(self._L.ndt_calculate_score(self._h, a.ctypes.data, a.shape[0], a.strides[0], C.byref(s)))
+        return s.value
+
+    # ---- batch (map-build) ---------------------------------------------------------
+    def alignBatch(self, clouds=None, guesses=None, device_ptr=None, offsets=None, stride_bytes=16):
+        """Register many sources against the one target in lock-step.
+
+        clouds: list of (N_k, >=3) arrays (host), or device_ptr + offsets for HBM-resident data."""
+        if clouds is not None:
+            cols = {c.shape[1] for c in clouds}
+            if len(cols) != 1:
+                raise ValueError("all clouds must have the same column count")
+            cat = _cloud(np.concatenate(clouds, axis=0))
+            offsets = np.zeros(len(clouds) + 1, dtype=np.uintp)
+            offsets[1:] = np.cumsum([c.shape[0] for c in clouds])
+            ptr, stride, fn = cat.ctypes.data, cat.strides[0], self._L.ndt_align_batch
+        else:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uintp)
+            ptr, stride, fn = C.c_void_p(device_ptr), stride_bytes, self._L.ndt_align_batch_device
+        B = len(offsets) - 1
+        g = None
+        if guesses is not None:
+            g = np.ascontiguousarray(np.stack([_colmajor(x) for x in guesses]))
+        T = np.zeros((B, 16), dtype=np.float32)
+        conv = np.zeros(B, dtype=np.int32)
+        it = np.zeros(B, dtype=np.int32)
+        tp = np.zeros(B, dtype=np.float64)
+        check(fn(self._h, ptr, offsets.ctypes.data_as(C.POINTER(C.c_size_t)), B, stride,
+                 _f(g) if g is not None else None, _f(T), _i(conv), _i(it), _d(tp)))
+        return dict(T=np.stack([_from_colmajor(T[k]) for k in range(B)]), converged=conv.astype(bool),
+                    iterations=it, trans_probability=tp)
+
+    def setAllreduce(self, fn, on_device=False):
+        """fn(buffer_address, n_doubles, on_device) -> 0 on success; None removes the hook."""
+        if fn is None:
+            cb = _lib.ALLREDUCE_FN(0)
+        else:
+            def tramp(buf, n, dev, _user):
+                try:
+                    return int(fn(buf, n, bool(dev)) or 0)
+                except Exception:  # never unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.ALLREDUCE_FN(tramp)
+        self._keep = [cb]
+        check(self._L.ndt_set_allreduce(self._h, cb, None, int(on_device)))
+
+    # ---- inspection ------------------------------------------------------------------
+    def eval(self, p, compute_hessian=True, T=None):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        score, nn = C.c_double(0), C.c_double(0)
+        g = np.zeros(6)
+        H = np.zeros(36) if compute_hessian else None
+        if T is None:
+            check(self._L.ndt_eval(self._h, _d(p), C.byref(score), _d(g), _d(H) if compute_hessian else None,
+                                   C.byref(nn)))
+        else:
+            Tc = _colmajor(T)
+            check(self._L.ndt_eval_with_matrix(self._h, _f(Tc), _d(p), C.byref(score), _d(g),
+                                               _d(H) if compute_hessian else None, C.byref(nn)))
+        return score.value, g, (H.reshape(6, 6) if compute_hessian else None), nn.value
+
+    def hessian_f64(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        H = np.zeros(36)
+        check(self._L.ndt_eval_hessian_f64(self._h, _d(p), _d(H)))
+        return H.reshape(6, 6)
+
+    def grid(self):
+        nl, nv = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.ndt_grid_size(self._h, C.byref(nl), C.byref(nv)))
+        n = nl.value
+        idx = np.zeros(n, dtype=np.int64)
+        npts = np.zeros(n, dtype=np.int32)
+        mean = np.zeros((n, 3))
+        cov = np.zeros((n, 3, 3))
+        icov = np.zeros((n, 3, 3))
+        evals = np.zeros((n, 3))
+        if n:
+            check(self._L.ndt_grid_dump(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _i(npts), _d(mean), _d(cov),
+                                        _d(icov), _d(evals)))
+        mb, xb, db = (np.zeros(3, dtype=np.int32) for _ in range(3))
+        check(self._L.ndt_grid_info(self._h, _i(mb), _i(xb), _i(db)))
+        return dict(idx=idx, n=npts, mean=mean, cov=cov, icov=icov, evals=evals, min_b=mb, max_b=xb, div_b=db,
+                    n_valid=nv.value)
+
+
+# ---- host-only scalar pieces (no GPU needed) ---------------------------------------
+def host_solve6(H, b):
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(36)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(6)
+    _lib.lib().ndt_host_solve6(_d(H), _d(b), _d(x))
+    return x
+
+
+def host_pose_to_matrix(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    T = np.zeros(16, dtype=np.float32)
+    _lib.lib().ndt_host_pose_to_matrix(_d(p), _f(T))
+    return _from_colmajor(T)
+
+
+def host_matrix_to_pose(T):
+    Tc = _colmajor(T)
+    p = np.zeros(6)
+    _lib.lib().ndt_host_matrix_to_pose(_f(Tc), _d(p))
+    return p
+
+
+def host_angle_derivatives(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    j = np.zeros((8, 3), dtype=np.float32)
+    h = np.zeros((15, 3), dtype=np.float32)
+    jd = np.zeros((8, 3))
+    hd = np.zeros((15, 3))
+    _lib.lib().ndt_host_angle_derivatives(_d(p), _f(j), _f(h), _d(jd), _d(hd))
+    return j, h, jd, hd
+
+
+def host_gauss(resolution, outlier_ratio):
+    d = np.zeros(3)
+    _lib.lib().ndt_host_gauss(float(resolution), float(outlier_ratio), _d(d))
+    return d
+
+
+def host_run_driver(evaluator, n_source, guess=None, resolution=1.0, step_size=0.1, outlier_ratio=0.55,
+                    trans_eps=0.1, max_iter=35):
+    """Run the PRODUCT Newton/More-Thuente driver against a Python evaluator
+    evaluator(kind, T(4x4), p(6)) -> (score, g(6), H(6x6))."""
+    def tramp(_user, kind, Tp, pp, score, g, H):
+        try:
+            T = _from_colmajor(np.ctypeslib.as_array(Tp, shape=(16,)))
+            p = np.ctypeslib.as_array(pp, shape=(6,)).copy()
+            s, gg, HH = evaluator(kind, T, p)
+            score[0] = s
+            for k in range(6):
+                g[k] = gg[k]
+            HH = np.asarray(HH, dtype=np.float64).reshape(36)
+            for k in range(36):
+                H[k] = HH[k]
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = _lib.EVAL_CB(tramp)
+    g = None if guess is None else _colmajor(guess)
+    T = np.zeros(16, dtype=np.float32)
+    conv, it, ne, nh = (C.c_int(0) for _ in range(4))
+    tp = C.c_double(0)
+    check(_lib.lib().ndt_host_run_driver(cb, None, n_source, _f(g) if g is not None else None, resolution, step_size,
+                                         outlier_ratio, trans_eps, max_iter, _f(T), C.byref(conv), C.byref(it),
+                                         C.byref(tp), C.byref(ne), C.byref(nh)))
+    return dict(T=_from_colmajor(T), converged=bool(conv.value), iterations=it.value, trans_probability=tp.value,
+                n_evals=ne.value, n_hessian_recomputes=nh.value)
