@@ -119,9 +119,10 @@ def test_eval_matches_oracle_and_golden(mods, pair, golden, key):
     assert score == pytest.approx(so, rel=1e-6) and score == pytest.approx(e["score"], rel=1e-6)
     assert close_sums(grad, go) and close_sums(H, Ho) and close_sums(H, e["H"])
     assert np.array_equal(H, H.T)
-    # compute_hessian = false leaves the Hessian untouched, same score/gradient
+    # compute_hessian = false: same score/gradient (a different kernel instantiation, so the f32
+    # FMA contraction may differ in the last ulp of individual terms)
     s2, g2, H2, _ = g.eval(e["p"], False)
-    assert s2 == score and np.array_equal(g2, grad) and H2 is None
+    assert s2 == pytest.approx(score, rel=1e-7) and close_sums(g2, grad, rel=1e-7) and H2 is None
     # all-f64 Hessian (computeHessian); the device keeps icov in f32 -> 1e-6
     assert close_sums(g.hessian_f64(e["p"]), o.hessian_f64(e["p"]), rel=1e-5)
 

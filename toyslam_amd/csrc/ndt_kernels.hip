@@ -114,10 +114,12 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const float4* __restrict__ pts,
 // linear voxel index of a target point while BUILDING the grid:
 // floor(x * inv_leaf) - float(min_b), _impl.hpp:218-223 (f32, trap 2)
 __device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, float z) {
+  // plain operators under contract(off): the product must be rounded to f32 before floor()
 #pragma clang fp contract(off)
-  const int i0 = static_cast<int>(floorf(__fmul_rn(x, g.inv_leaf[0])) - static_cast<float>(g.min_b[0]));
-  const int i1 = static_cast<int>(floorf(__fmul_rn(y, g.inv_leaf[1])) - static_cast<float>(g.min_b[1]));
-  const int i2 = static_cast<int>(floorf(__fmul_rn(z, g.inv_leaf[2])) - static_cast<float>(g.min_b[2]));
+  const float fx = x * g.inv_leaf[0], fy = y * g.inv_leaf[1], fz = z * g.inv_leaf[2];
+  const int i0 = static_cast<int>(floorf(fx) - static_cast<float>(g.min_b[0]));
+  const int i1 = static_cast<int>(floorf(fy) - static_cast<float>(g.min_b[1]));
+  const int i2 = static_cast<int>(floorf(fz) - static_cast<float>(g.min_b[2]));
   return i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2];
 }
 
@@ -490,10 +492,18 @@ __device__ __forceinline__ void nb_offset(int k, int& dx, int& dy, int& dz) {
 
 // [PCL 1.10] Transformer<float>::se3: x*c0 + (y*c1 + (z*c2 + c3)), f32, unfused.
 __device__ __forceinline__ void xform_point(const float* T, float x, float y, float z, float& ox, float& oy, float& oz) {
+  // Plain operators lexically inside contract(off): every product and sum is rounded to f32 on its
+  // own, like the SSE code of the reference build (the __f*_rn wrappers would be inlined with the
+  // translation unit's default contract(fast) and fuse).
 #pragma clang fp contract(off)
-  ox = __fadd_rn(__fmul_rn(x, T[0]), __fadd_rn(__fmul_rn(y, T[1]), __fadd_rn(__fmul_rn(z, T[2]), T[3])));
-  oy = __fadd_rn(__fmul_rn(x, T[4]), __fadd_rn(__fmul_rn(y, T[5]), __fadd_rn(__fmul_rn(z, T[6]), T[7])));
-  oz = __fadd_rn(__fmul_rn(x, T[8]), __fadd_rn(__fmul_rn(y, T[9]), __fadd_rn(__fmul_rn(z, T[10]), T[11])));
+  const float ax = z * T[2], ay = z * T[6], az = z * T[10];
+  const float bx = ax + T[3], by = ay + T[7], bz = az + T[11];
+  const float cx = y * T[1], cy = y * T[5], cz = y * T[9];
+  const float dx = cx + bx, dy = cy + by, dz = cz + bz;
+  const float ex = x * T[0], ey = x * T[4], ez = x * T[8];
+  ox = ex + dx;
+  oy = ey + dy;
+  oz = ez + dz;
 }
 
 // voxel coordinate while SEARCHING: floor(x / leaf), _impl.hpp:379-381 (division, trap 2)

@@ -107,11 +107,11 @@ class NormalDistributionsTransform:
     # ---- inputs -------------------------------------------------------------------
     def setInputTarget(self, cloud, is_dense=True):
         a = _cloud(cloud)
-        check(self._L.ndt_set_input_target(self._h, a.ctypes.data, a.shape[0], a.strides[0], int(is_dense)))
+        check(self._L.ndt_set_input_target(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, int(is_dense)))
 
     def setInputSource(self, cloud):
         a = _cloud(cloud)
-        check(self._L.ndt_set_input_source(self._h, a.ctypes.data, a.shape[0], a.strides[0]))
+        check(self._L.ndt_set_input_source(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4))
 
     def setInputTargetDevice(self, dev_ptr, n, stride_bytes, is_dense=True):
         check(self._L.ndt_set_input_target_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense)))
@@ -162,7 +162,7 @@ class NormalDistributionsTransform:
     def calculateScore(self, cloud):
         a = _cloud(cloud)
         s = C.c_double(0)
-        check(self._L.ndt_calculate_score(self._h, a.ctypes.data, a.shape[0], a.strides[0], C.byref(s)))
+        check(self._L.ndt_calculate_score(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, C.byref(s)))
         return s.value
 
     # ---- batch (map-build) ---------------------------------------------------------
@@ -177,7 +177,7 @@ class NormalDistributionsTransform:
             cat = _cloud(np.concatenate(clouds, axis=0))
             offsets = np.zeros(len(clouds) + 1, dtype=np.uintp)
             offsets[1:] = np.cumsum([c.shape[0] for c in clouds])
-            ptr, stride, fn = cat.ctypes.data, cat.strides[0], self._L.ndt_align_batch
+            ptr, stride, fn = cat.ctypes.data, cat.shape[1] * 4, self._L.ndt_align_batch
         else:
             offsets = np.ascontiguousarray(offsets, dtype=np.uintp)
             ptr, stride, fn = C.c_void_p(device_ptr), stride_bytes, self._L.ndt_align_batch_device
