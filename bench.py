@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- scan registrations/sec of the MI355X NDT core (BASELINE.json metric).
+
+A "step" is ONE registration (pcl::Registration::align) of one synthetic 100k-point source scan
+against a 1M-point target whose voxel grid is already resident in HBM -- exactly the region
+ndt_omp/apps/align.cpp:20-29 times -- at 1.0 m voxels, DIRECT7, with the Newton loop pinned to
+30 outer passes (max_iterations 28, transformation_epsilon 0: ndt_omp_impl.hpp:158-164 then runs
+max_iterations + 2 passes).  configs[1] of BASELINE.json.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--set U|S] [--workload single|batch]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): registrations of different scans are
+independent, so every rank registers its own scan against its own replica of the target grid with
+no collective in the data path ("scaling": "weak"); value = N*K / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Extra legs on rank 0 (outside the timed region):
+  roofline     -- average duration of the dominant kernel (k_derivatives<DIRECT7, hessian>) from
+                  HIP events on the library's own stream, over a second pass of the same steps.
+  cpu_baseline -- the oracle (oracle/, a faithful OpenMP port of the reference's algorithm; the real
+                  pclomp cannot be built here) on the same inputs on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "scan registrations/sec (100k-pt src vs 1M-pt target, 30 Newton iters)"
+M_TARGET, N_SOURCE, RESOLUTION, MAX_ITER, EPS = 1000000, 100000, 1.0, 28, 0.0
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_eval(n_points, mean_neighbors):
+    """16 B point + 7 x 4 B voxel-slot probes + 36 B per valid neighbour record."""
+    return n_points * (16 + 7 * 4 + 36 * mean_neighbors)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--set", default="U", choices=["U", "S"], help="U = uniform box (headline), S = surface scene")
+    ap.add_argument("--workload", default="single", choices=["single", "batch"])
+    ap.add_argument("--batch", type=int, default=64, help="scans per GPU for --workload batch (config 4 shape)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from toyslam_amd import clouds, ndt
+
+    def barrier():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- inputs (synthetic, seeded; resident in HBM before the timed region) ----
+    tgt = clouds.target_uniform(M_TARGET) if args.set == "U" else clouds.target_surfaces(M_TARGET)
+    reg = ndt.NormalDistributionsTransform(device=local_rank)
+    reg.setResolution(RESOLUTION)
+    reg.setNeighborhoodSearchMethod(ndt.DIRECT7)
+    reg.setMaximumIterations(MAX_ITER)
+    reg.setTransformationEpsilon(EPS)
+    t0 = time.perf_counter()
+    reg.setInputTarget(tgt)
+    t_build_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    reg.setInputTarget(tgt)
+    t_build = time.perf_counter() - t0
+
+    if args.workload == "single":
+        src = clouds.source_from_target(tgt, N_SOURCE, seed=clouds.SEED + 1 + 7 * rank)
+        reg.setInputSource(src)
+
+        def step():
+            reg.align()
+        regs_per_step = 1
+    else:
+        rng = np.random.default_rng(clouds.SEED + 100 + rank)
+        scans = []
+        for k in range(args.batch):
+            T = clouds.random_T(rng, 0.5, 2.0)
+            scans.append(clouds.source_from_target(tgt, N_SOURCE, T_gt=T, seed=clouds.SEED + 1000 * rank + k))
+        cat = np.ascontiguousarray(np.concatenate(scans, axis=0))
+        dev = torch.from_numpy(np.c_[cat, np.ones(len(cat), np.float32)]).cuda()
+        offsets = np.arange(args.batch + 1, dtype=np.uintp) * N_SOURCE
+
+        def step():
+            reg.alignBatch(device_ptr=dev.data_ptr(), offsets=offsets, stride_bytes=16)
+        regs_per_step = args.batch
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        st = reg.stats() if args.workload == "single" else {}
+        value = world * args.steps * regs_per_step / dt
+        out = {
+            "metric": METRIC, "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes "
+                                    "(max_iterations 28, epsilon 0), set " + args.set) if args.workload == "single" else
+                       ("map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set)),
+                       "target_points": M_TARGET, "source_points": N_SOURCE, "resolution_m": RESOLUTION,
+                       "search": "DIRECT7", "outer_passes": MAX_ITER + 2, "sharding": "one scan stream per GPU, target grid replicated"},
+            "target_build_ms": t_build * 1e3, "target_build_first_call_ms": t_build_first * 1e3,
+        }
+        if args.workload == "single":
+            out["evaluations_per_registration"] = st["n_evals"]
+            out["f64_hessian_recomputes"] = st["n_hessian_recomputes"]
+            out["mean_neighbors"] = st["mean_neighbors"]
+            # ---- roofline leg: HIP events on the library's stream, second pass of the same steps ----
+            reg.profile(True)
+            reg.profile_read(0)
+            for _ in range(min(args.steps, 10)):
+                reg.align()
+            n_launch, ms = reg.profile_read(0)
+            reg.profile(False)
+            full = reg.eval(ndt.host_matrix_to_pose(reg.getFinalTransformation()), True)
+            hbar = full[3]
+            avg_s = ms * 1e-3 / max(n_launch, 1)
+            bytes_per_launch = algorithmic_bytes_per_eval(N_SOURCE, hbar)
+            achieved = bytes_per_launch / avg_s / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_derivatives<DIRECT7, hessian>", "avg_kernel_us": avg_s * 1e6,
+                               "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                               "mean_neighbors": hbar,
+                               "how": "hipEvent pairs on the library stream around each launch, separate pass"}
+            out["registration_algorithmic_GBs"] = st["n_evals"] * bytes_per_launch / (dt / args.steps) / 1e9
+            # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import pyoracle as po
+                cores = len(os.sched_getaffinity(0))
+                o = po.OracleNDT(resolution=RESOLUTION, search_method=po.DIRECT7, num_threads=cores,
+                                 trans_eps=EPS, max_iter=MAX_ITER)
+                tb = time.perf_counter()
+                o.set_target(tgt)
+                tb = time.perf_counter() - tb
+                o.set_source(src)
+                r = o.align()  # warm-up, also the parity reference
+                times = []
+                budget = time.perf_counter() + 20.0
+                while len(times) < 5 and (not times or time.perf_counter() < budget):
+                    ta = time.perf_counter()
+                    o.align()
+                    times.append(time.perf_counter() - ta)
+                med = float(np.median(times))
+                T = reg.getFinalTransformation()
+                out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
+                                       "sample": "%d full registrations of the same workload (median), after 1 warm-up; "
+                                                 "align only, target grid resident" % len(times),
+                                       "ms_per_registration": med * 1e3, "target_build_ms": tb * 1e3,
+                                       "evaluations": r["n_evals"]}
+                out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T[:3, :3] - r["T"][:3, :3]).max()),
+                                           "trans_max_abs_m": float(np.abs(T[:3, 3] - r["T"][:3, 3]).max()),
+                                           "iterations_gpu": reg.getFinalNumIteration(), "iterations_oracle": r["iterations"],
+                                           "evals_gpu": st["n_evals"], "evals_oracle": r["n_evals"]}
+                out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

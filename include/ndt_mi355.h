@@ -151,6 +151,14 @@ ndt_status ndt_grid_info(ndt_handle h, int* min_b /*3*/, int* max_b /*3*/, int* 
 ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mean, double* cov, double* icov,
                          double* evals);
 
+/* Live kernel timing with HIP events recorded on the handle's own stream
+ * (bench.py's roofline leg).  While enabled, every derivative-kernel launch is
+ * bracketed by an event pair; kind 0 = derivatives with Hessian (the dominant
+ * kernel), 1 = without, 2 = f64 Hessian.  Off by default (the event pairs cost
+ * host time). */
+ndt_status ndt_profile_enable(ndt_handle h, int on);
+ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset);
+
 /* Host-side scalar pieces of the driver (no GPU needed), exported so that the
  * CPU test-suite can check them against the oracle. */
 void ndt_host_solve6(const double* H /*36 row-major*/, const double* b /*6*/, double* x /*6*/); /* JacobiSVD.solve, :127-129 */

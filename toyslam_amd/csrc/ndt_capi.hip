@@ -113,6 +113,11 @@ struct ndt_context {
   int n_evals = 0, n_hess = 0;
   double mean_neighbors = 0;
   size_t out_n = 0;
+  // live kernel timing (HIP events on `stream`)
+  bool profiling = false;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  long long prof_n[3] = {0, 0, 0};
+  double prof_ms[3] = {0, 0, 0};
   // collective hook
   ndt_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -120,6 +125,8 @@ struct ndt_context {
 
   ~ndt_context() {
     if (host_result) (void)hipHostFree(host_result);
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -350,6 +357,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   const int nblk = ndt::derivative_blocks(n);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   const ndt::GridView gv = h->grid->view();
+  if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   if (rq.kind == ndt::EVAL_HESSIAN_F64) {
     ndt::Hess64Params P;
     fill_h64_params(rq, gs, P);
@@ -360,8 +368,15 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     HIP_TRY(ndt::launch_derivatives(h->source->pts.p, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1,
                                     rq.kind, nblk, h->partials.p, h->stream));
   }
+  if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
   HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->profiling) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->prof_n[rq.kind]++;
+    h->prof_ms[rq.kind] += ms;
+  }
   if (h->allreduce) {  // point-sharded scan: sum the packed row across ranks
     if (h->allreduce(h->host_result, ndt::kEvalStride, 0, h->allreduce_user))
       return fail(NDT_ERR_COMM, "allreduce callback failed");
@@ -769,6 +784,29 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (idx)
     for (size_t i = 0; i < V; i++) idx[i] = cell[i];
+  return NDT_OK;
+}
+
+ndt_status ndt_profile_enable(ndt_handle h, int on) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (on) {
+    ndt_status s = ensure_device(h);
+    if (s) return s;
+    if (!h->ev_a) HIP_TRY(hipEventCreate(&h->ev_a));
+    if (!h->ev_b) HIP_TRY(hipEventCreate(&h->ev_b));
+  }
+  h->profiling = on != 0;
+  return NDT_OK;
+}
+
+ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset) {
+  if (!h || kind < 0 || kind > 2) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (n_launches) *n_launches = h->prof_n[kind];
+  if (total_ms) *total_ms = h->prof_ms[kind];
+  if (reset) {
+    h->prof_n[kind] = 0;
+    h->prof_ms[kind] = 0;
+  }
   return NDT_OK;
 }
 

@@ -210,6 +210,16 @@ class NormalDistributionsTransform:
         self._keep = [cb]
         check(self._L.ndt_set_allreduce(self._h, cb, None, int(on_device)))
 
+    def profile(self, on):
+        check(self._L.ndt_profile_enable(self._h, int(on)))
+
+    def profile_read(self, kind=0, reset=True):
+        """(launches, total_ms) of the derivative kernel of `kind`, from HIP events on the handle's stream."""
+        n = C.c_longlong(0)
+        ms = C.c_double(0)
+        check(self._L.ndt_profile_read(self._h, kind, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value
+
     # ---- inspection ------------------------------------------------------------------
     def eval(self, p, compute_hessian=True, T=None):
         p = np.ascontiguousarray(p, dtype=np.float64)
