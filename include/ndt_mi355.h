@@ -159,6 +159,10 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
 ndt_status ndt_profile_enable(ndt_handle h, int on);
 ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset);
 
+/* Device self-test of the wave64 fold reduction used by every kernel epilogue: n_blocks blocks
+ * of known per-thread values; block_sums receives n_blocks x NDT_EVAL_STRIDE doubles (slots 0..28). */
+ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums);
+
 /* Host-side scalar pieces of the driver (no GPU needed), exported so that the
  * CPU test-suite can check them against the oracle. */
 void ndt_host_solve6(const double* H /*36 row-major*/, const double* b /*6*/, double* x /*6*/); /* JacobiSVD.solve, :127-129 */

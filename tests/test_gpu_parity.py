@@ -51,6 +51,17 @@ def test_native_library_is_in_tree(built_lib):
     assert os.path.dirname(_lib.LIB_PATH).endswith("toyslam_amd") and os.path.exists(_lib.LIB_PATH)
 
 
+def test_wave_fold_reduction_selftest(mods):
+    """The VALU-only reduce-scatter used by every kernel epilogue: exact on half-integers."""
+    ndt, _, _ = mods
+    nb = 5
+    got = ndt.NormalDistributionsTransform().selftest_reduce(nb)
+    gt = np.arange(nb * 256, dtype=np.int64)
+    for k in range(29):
+        vals = 0.5 * ((gt * 131 + k * 17 + (gt >> 3) * k) % 1009).astype(np.float64) - 100.0
+        assert np.array_equal(got[:, k], vals.reshape(nb, 256).sum(axis=1)), k
+
+
 # ------------------------------------------------------------------ K1: voxel grid
 def test_grid_bit_exact_indices_and_sums(mods, pair, golden_grid):
     t, s = pair

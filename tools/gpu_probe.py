@@ -36,7 +36,16 @@ def main():
     for _ in range(50):
         g.hessian_f64(p)
     print("hessian_f64 %.1f us" % ((time.time() - t0) / 50 * 1e6))
-    for _ in range(2):
+    g.profile(True); g.profile_read(0); g.profile_read(1)
+    g.align()
+    n0, ms0 = g.profile_read(0); n1, ms1 = g.profile_read(1)
+    g.profile(False)
+    print("event-timed K2: with-H %d launches avg %.2f us ; no-H %d launches avg %.2f us" % (n0, ms0 / max(n0, 1) * 1e3, n1, ms1 / max(n1, 1) * 1e3))
+    ts = []
+    for _ in range(20):
+        t0 = time.time(); g.align(); ts.append(time.time() - t0)
+    print("align median %.3f ms min %.3f ms" % (np.median(ts) * 1e3, np.min(ts) * 1e3))
+    for _ in range(1):
         t0 = time.time(); g.align(); t1 = time.time()
         st = g.stats()
         T = g.getFinalTransformation()

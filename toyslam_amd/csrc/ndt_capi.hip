@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -57,8 +59,13 @@ struct DevBuf {
 };
 
 struct DeviceCloud {
-  DevBuf<float4> pts;
+  DevBuf<float4> pts;     // caller's order (align's output cloud keeps it)
+  DevBuf<float4> sorted;  // lattice-cell order, what the derivative kernels read
   size_t n = 0;
+  size_t n_sorted = 0;    // finite points only
+  std::vector<size_t> scan_counts;  // batch uploads: finite points of each scan (sorted in place per scan)
+  const float4* k2_pts() const { return n_sorted ? sorted.p : pts.p; }
+  int k2_n() const { return static_cast<int>(n_sorted ? n_sorted : n); }
 };
 
 // Immutable once built (shared between cloned handles).
@@ -106,6 +113,7 @@ struct ndt_context {
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
   size_t host_result_rows = 0;
+  unsigned long long eval_seq = 0;
   // results
   float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int converged = 0, nr_iterations = 0;
@@ -190,6 +198,100 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   out = c;
+  return NDT_OK;
+}
+
+// Spatial ordering of a source range: counting sort by the cell of a lattice of pitch ~resolution
+// laid over the range's own bounding box (x fastest), stable inside a cell.  Rigid transforms
+// preserve locality, so whatever the pose, consecutive lanes of the derivative kernels land in
+// the same or adjacent target voxels.  Only the order of the f64 summation changes.
+ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitch, float4* d_out, size_t* n_out) {
+  *n_out = 0;
+  if (n == 0) return NDT_OK;
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(n);
+  const int nb = std::min(1024, (ni + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(d_pts, ni, 0, d_mm.p, nb, st));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
+      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
+    }
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point
+  ndt::GridGeom geo{};
+  for (;; pitch *= 2.0f) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      geo.leaf[k] = pitch;
+      geo.inv_leaf[k] = 1.0f / pitch;
+      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+      cells *= geo.div_b[k];
+    }
+    if (cells <= 4.0e6) break;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(d_pts, ni, 0, geo, key.p, cell_count.p, st));
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const size_t n_leaves = tot[1];
+  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *n_out = tot[0];
+  return NDT_OK;
+}
+
+ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
+  static const bool enabled = [] { const char* v = getenv("NDT_SORT_SOURCE"); return v ? atoi(v) != 0 : true; }();
+  c->n_sorted = 0;
+  if (!enabled || c->n == 0) return NDT_OK;
+  HIP_TRY(c->sorted.reserve(c->n));
+  if (!offsets) {
+    size_t got = 0;
+    ndt_status s = order_range(h, c->pts.p, c->n, h->resolution, c->sorted.p, &got);
+    if (s) return s;
+    c->n_sorted = got;
+  } else {  // every scan of a batch is ordered on its own, in place of its segment
+    c->scan_counts.assign(n_scans, 0);
+    size_t total = 0;
+    for (size_t k = 0; k < n_scans; k++) {
+      const size_t off = offsets[k] - offsets[0], cnt = offsets[k + 1] - offsets[k];
+      ndt_status s = order_range(h, c->pts.p + off, cnt, h->resolution, c->sorted.p + off, &c->scan_counts[k]);
+      if (s) return s;
+      total += c->scan_counts[k];
+    }
+    c->n_sorted = total;
+  }
   return NDT_OK;
 }
 
@@ -305,7 +407,8 @@ void fill_eval_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Eva
   std::memcpy(P.h, ad.h, sizeof(P.h));
   P.d1 = gs.d1;
   P.d2 = static_cast<float>(gs.d2);
-  P.pad = 0;
+  static const int dbg = [] { const char* v = getenv("NDT_DBG_MODE"); return v ? atoi(v) : 0; }();
+  P.pad = dbg;  // diagnostic phase-skipping (0 in production)
 }
 
 void fill_h64_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Hess64Params& P) {
@@ -345,32 +448,56 @@ ndt_status check_ready(ndt_context* h) {
 
 // one evaluation of a single scan; blocks until the result is on the host
 ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::EvalResult& res, double* nn_total) {
-  const int n = static_cast<int>(h->source->n);
+  const int n = h->source->k2_n();
+  const float4* src = h->source->k2_pts();
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   ndt_status s = ensure_host_rows(h, 1);
   if (s) return s;
-  if (n == 0 || h->grid->empty) {  // nothing contributes
+  if (h->source->n == 0 || n == 0 || h->grid->empty) {  // nothing contributes
     std::memset(&res, 0, sizeof(res));
     if (nn_total) *nn_total = 0;
     return NDT_OK;
   }
-  const int nblk = ndt::derivative_blocks(n);
+  const int nblk = ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   const ndt::GridView gv = h->grid->view();
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   if (rq.kind == ndt::EVAL_HESSIAN_F64) {
     ndt::Hess64Params P;
     fill_h64_params(rq, gs, P);
-    HIP_TRY(ndt::launch_hessian64(h->source->pts.p, n, gv, P, h->search, nullptr, 1, nblk, h->partials.p, h->stream));
+    HIP_TRY(ndt::launch_hessian64(src, n, gv, P, h->search, nullptr, 1, nblk, h->partials.p, h->stream));
   } else {
     ndt::EvalParams P;
     fill_eval_params(rq, gs, P);
-    HIP_TRY(ndt::launch_derivatives(h->source->pts.p, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1,
+    HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1,
                                     rq.kind, nblk, h->partials.p, h->stream));
   }
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
+  if (spin_wait && !h->profiling) {
+    // Latency path: the reduce kernel writes the row and then a sequence number straight into
+    // pinned host memory; poll it instead of paying a stream synchronisation per evaluation.
+    const unsigned long long seq = ++h->eval_seq;
+    HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream, seq));
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(h->stream) != hipErrorNotReady) {  // finished (or failed) without the flag
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+          return fail(NDT_ERR_HIP, "evaluation finished without publishing its result");
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+          return fail(NDT_ERR_HIP, "timed out waiting for the evaluation result");
+      }
+    }
+  } else {
+    HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   if (h->profiling) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
@@ -492,13 +619,21 @@ ndt_status ndt_set_input_target(ndt_handle h, const void* pts, size_t n, size_t 
 ndt_status ndt_set_input_target_device(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
   return set_target_impl(h, pts, n, stride, is_dense, true);
 }
-ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t stride) {
+static ndt_status set_source_impl(ndt_handle h, const void* pts, size_t n, size_t stride, bool on_device) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
-  return upload_cloud(h, pts, n, stride, false, h->source);
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  s = order_cloud(h, c.get(), nullptr, 0);
+  if (s) return s;
+  h->source = c;
+  return NDT_OK;
+}
+ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t stride) {
+  return set_source_impl(h, pts, n, stride, false);
 }
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, size_t stride) {
-  if (!h) return fail(NDT_ERR_INVALID, "null handle");
-  return upload_cloud(h, pts, n, stride, true, h->source);
+  return set_source_impl(h, pts, n, stride, true);
 }
 
 ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformation, int* has_converged,
@@ -581,7 +716,7 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
   s = ensure_host_rows(h, 1);
   if (s) return s;
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
-  const int nblk = ndt::derivative_blocks(static_cast<int>(n));
+  const int nblk = ndt::derivative_blocks(static_cast<int>(n), NDT_DIRECT1);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   HIP_TRY(hipMemsetAsync(h->partials.p, 0, static_cast<size_t>(nblk) * ndt::kEvalStride * sizeof(double), h->stream));
   HIP_TRY(ndt::launch_calc_score(c->pts.p, static_cast<int>(n), h->grid->view(), gs.d1, gs.d2, gs.d3, h->search, nblk,
@@ -608,6 +743,10 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   const size_t total = offsets[n_scans] - offsets[0];
   ndt_status s = upload_cloud(h, base, total, stride, on_device, cloud);
   if (s) return s;
+  s = order_cloud(h, cloud.get(), offsets, n_scans);
+  if (s) return s;
+  const bool use_sorted = cloud->n_sorted > 0 && !cloud->scan_counts.empty();
+  const float4* batch_pts = use_sorted ? cloud->sorted.p : cloud->pts.p;
   s = ensure_host_rows(h, n_scans);
   if (s) return s;
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
@@ -618,11 +757,11 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     const size_t cnt = offsets[k + 1] - offsets[k];
     solvers[k].start(guesses ? guesses + 16 * k : nullptr, cnt, solver_params(h));
     descs[k].offset = static_cast<int>(offsets[k] - offsets[0]);
-    descs[k].count = static_cast<int>(cnt);
+    descs[k].count = static_cast<int>(use_sorted ? cloud->scan_counts[k] : cnt);
     descs[k].pad = 0;
     max_n = std::max(max_n, cnt);
   }
-  const int nblk = std::max(1, std::min(ndt::derivative_blocks(static_cast<int>(max_n)),
+  const int nblk = std::max(1, std::min(ndt::derivative_blocks(static_cast<int>(max_n), h->search),
                                         std::max(8, 4096 / static_cast<int>(n_scans))));
   HIP_TRY(h->partials.reserve(n_scans * nblk * ndt::kEvalStride));
   HIP_TRY(h->batch_out.reserve(n_scans * ndt::kEvalStride));
@@ -648,9 +787,9 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       HIP_TRY(hipMemcpyAsync(h->descs.p, descs.data(), n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
-      if (any[0]) HIP_TRY(ndt::launch_derivatives(cloud->pts.p, 0, gv, dummy, h->search, true, h->descs.p, static_cast<int>(n_scans), 0, nblk, h->partials.p, h->stream));
-      if (any[1]) HIP_TRY(ndt::launch_derivatives(cloud->pts.p, 0, gv, dummy, h->search, false, h->descs.p, static_cast<int>(n_scans), 1, nblk, h->partials.p, h->stream));
-      if (any[2]) HIP_TRY(ndt::launch_hessian64(cloud->pts.p, 0, gv, dummy64, h->search, h->descs.p, static_cast<int>(n_scans), nblk, h->partials.p, h->stream));
+      if (any[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, static_cast<int>(n_scans), 0, nblk, h->partials.p, h->stream));
+      if (any[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, static_cast<int>(n_scans), 1, nblk, h->partials.p, h->stream));
+      if (any[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, static_cast<int>(n_scans), nblk, h->partials.p, h->stream));
       HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, n_scans * ndt::kEvalStride * sizeof(double), h->stream));
       HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
       if (h->allreduce && h->allreduce_on_device) {
@@ -784,6 +923,20 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (idx)
     for (size_t i = 0; i < V; i++) idx[i] = cell[i];
+  return NDT_OK;
+}
+
+ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums) {
+  if (!h || n_blocks <= 0 || !block_sums) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  DevBuf<double> d;
+  HIP_TRY(d.reserve(static_cast<size_t>(n_blocks) * ndt::kEvalStride));
+  HIP_TRY(hipMemsetAsync(d.p, 0, static_cast<size_t>(n_blocks) * ndt::kEvalStride * sizeof(double), h->stream));
+  HIP_TRY(ndt::launch_selftest_reduce(n_blocks, d.p, h->stream));
+  HIP_TRY(hipMemcpyAsync(block_sums, d.p, static_cast<size_t>(n_blocks) * ndt::kEvalStride * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
 }
 

@@ -24,6 +24,7 @@
 #include "ndt_kernels.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace ndt {
 
@@ -51,23 +52,105 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// Block-level sum of NV doubles per thread -> out[0..NV) (written by thread 0's
-// wave).  Fixed butterfly + fixed wave order: deterministic.
+// ---------------------------------------------------------------------------
+// Wave64 "reduce-scatter" of up to 32 f64 accumulators per lane, VALU only.
+//
+// A plain butterfly costs 6 cross-lane steps per value (29 x 6 x 2 ds_bpermute for the K2
+// accumulators: measured LDS-bound, the LDS pipe was busy for the whole kernel).  Instead each
+// step folds PAIRS of values: the lane keeps one value of the pair (chosen by one lane-id bit),
+// hands the other to its partner, and the number of live values halves:
+//   32 -> 16  v_permlane32_swap   (partner l ^ 32, keep by bit 5)
+//   16 ->  8  v_permlane16_swap   (partner l ^ 16, keep by bit 4)
+//    8 ->  4  DPP row_ror:8       (partner l ^ 8,  keep by bit 3 = banks 2,3)
+//    4 ->  2  DPP row_half_mirror (partner l ^ 7,  keep by bit 2 = banks 1,3)
+//    2 ->  1  DPP quad_perm[2,3,0,1] + v_cndmask   (partner l ^ 2, keep by bit 1)
+//    final    DPP quad_perm[1,0,3,2]               (partner l ^ 1)
+// ~120 VALU instructions for 29 values instead of ~520 LDS-routed ones; the order of the f64
+// additions is fixed by the lane ids, so the result is deterministic.
+// Afterwards lane l holds the wave total of value fold_index(l).
+// ---------------------------------------------------------------------------
+typedef unsigned fold_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double mk_f64(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+__device__ __forceinline__ double fold32(double a, double b) {  // lanes 0-31: sum_a(l, l+32); lanes 32-63: sum_b
+  const fold_u2 r0 = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2loint(a)), static_cast<unsigned>(__double2loint(b)), false, false);
+  const fold_u2 r1 = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(__double2hiint(a)), static_cast<unsigned>(__double2hiint(b)), false, false);
+  return mk_f64(r0[0], r1[0]) + mk_f64(r0[1], r1[1]);
+}
+__device__ __forceinline__ double fold16(double a, double b) {  // even rows: sum_a(l, l+16); odd rows: sum_b
+  const fold_u2 r0 = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2loint(a)), static_cast<unsigned>(__double2loint(b)), false, false);
+  const fold_u2 r1 = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(__double2hiint(a)), static_cast<unsigned>(__double2hiint(b)), false, false);
+  return mk_f64(r0[0], r1[0]) + mk_f64(r0[1], r1[1]);
+}
+// lanes whose DPP bank is in BANK_B keep b, the others keep a; the partner (permutation CTRL,
+// which must flip the selecting lane bit) supplies its copy of the kept value
+template <int CTRL, int BANK_B>
+__device__ __forceinline__ double fold_dpp(double a, double b) {
+  const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const int own_lo = __builtin_amdgcn_update_dpp(alo, blo, 0xE4, 0xF, BANK_B, false);
+  const int own_hi = __builtin_amdgcn_update_dpp(ahi, bhi, 0xE4, 0xF, BANK_B, false);
+  const int oth_lo = __builtin_amdgcn_update_dpp(blo, alo, 0xE4, 0xF, BANK_B, false);
+  const int oth_hi = __builtin_amdgcn_update_dpp(bhi, ahi, 0xE4, 0xF, BANK_B, false);
+  const int p_lo = __builtin_amdgcn_update_dpp(0, oth_lo, CTRL, 0xF, 0xF, false);
+  const int p_hi = __builtin_amdgcn_update_dpp(0, oth_hi, CTRL, 0xF, 0xF, false);
+  return mk_f64(own_lo, own_hi) + mk_f64(p_lo, p_hi);
+}
+template <int CTRL>
+__device__ __forceinline__ double fold_sel(double a, double b, bool keep_b) {
+  const double own = keep_b ? b : a, oth = keep_b ? a : b;
+  const int p_lo = __builtin_amdgcn_update_dpp(0, __double2loint(oth), CTRL, 0xF, 0xF, false);
+  const int p_hi = __builtin_amdgcn_update_dpp(0, __double2hiint(oth), CTRL, 0xF, 0xF, false);
+  return own + mk_f64(p_lo, p_hi);
+}
+__device__ __forceinline__ int fold_index(int lane) {
+  return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) |
+         (((lane >> 1) & 1) << 4);
+}
+
 template <int NV>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ out, double* lds /*[4][NV]*/) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+__device__ __forceinline__ double wave_fold(const double (&acc)[NV]) {
+  static_assert(NV >= 1 && NV <= 32, "wave_fold handles up to 32 values");
+  constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+  const int lane = threadIdx.x & (kWave - 1);
+  double r1[16], r2[8], r3[4], r4[2];
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    double v = wave_sum(acc[k]);
-    if (lane == 0) lds[wave * NV + k] = v;
-  }
+  for (int i = 0; i < 16; i++) r1[i] = (i < N1) ? fold32(acc[(2 * i < NV) ? 2 * i : 0], (2 * i + 1 < NV) ? acc[(2 * i + 1 < NV) ? 2 * i + 1 : 0] : 0.0) : 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r2[i] = (i < N2) ? fold16(r1[2 * i], (2 * i + 1 < N1) ? r1[2 * i + 1] : 0.0) : 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r3[i] = (i < N3) ? fold_dpp<0x128, 0xC>(r2[2 * i], (2 * i + 1 < N2) ? r2[2 * i + 1] : 0.0) : 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++) r4[i] = (i < N4) ? fold_dpp<0x141, 0xA>(r3[2 * i], (2 * i + 1 < N3) ? r3[2 * i + 1] : 0.0) : 0.0;
+  const double r5 = fold_sel<0x4E>(r4[0], (N4 > 1) ? r4[1] : 0.0, (lane & 2) != 0);
+  const int q_lo = __builtin_amdgcn_update_dpp(0, __double2loint(r5), 0xB1, 0xF, 0xF, false);
+  const int q_hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r5), 0xB1, 0xF, 0xF, false);
+  return r5 + mk_f64(q_lo, q_hi);
+}
+
+// Block-level sum of NV (<= 32) doubles per thread -> out[0..NV).  Fixed fold + fixed wave order:
+// deterministic.  lds: [kBlock / kWave][32] doubles.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ out, double* lds) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double tot = wave_fold<NV>(acc);
+  if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
   __syncthreads();
   if (threadIdx.x < NV) {
     double v = lds[threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < kBlock / kWave; w++) v += lds[w * NV + threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v += lds[w * 32 + threadIdx.x];
     out[threadIdx.x] = v;
   }
+}
+
+// test hook: every thread contributes acc[k] = f(global thread, k); out[block][32]
+__global__ __launch_bounds__(kBlock) void k_selftest_reduce(double* __restrict__ out) {
+  __shared__ double lds[(kBlock / kWave) * 32];
+  double acc[kNumAcc];
+  const int gt = blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.5 * static_cast<double>((gt * 131 + k * 17 + (gt >> 3) * k) % 1009) - 100.0;
+  block_reduce_store<kNumAcc>(acc, out + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
 }
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
@@ -351,7 +434,50 @@ __device__ void inv3_cofactor(const double a[3][3], double r[3][3]) {
   r[2][0] = cof(0, 2) * invdet; r[2][1] = cof(1, 2) * invdet; r[2][2] = cof(2, 2) * invdet;
 }
 
-constexpr int kSortLimit = 64;  // leaves up to this size are summed in ascending point order
+constexpr int kSortLimit = 64;      // up to here: insertion sort
+constexpr int kSortGiveUp = 65536;  // beyond: left in arrival order (one thread would stall for too long)
+
+// in-place ascending sort of a small index segment by ONE thread
+__device__ __forceinline__ void sort_segment(int* seg, int cnt) {
+  if (cnt <= kSortLimit) {
+    for (int i = 1; i < cnt; i++) {
+      const int v = seg[i];
+      int j = i - 1;
+      while (j >= 0 && seg[j] > v) { seg[j + 1] = seg[j]; j--; }
+      seg[j + 1] = v;
+    }
+  } else if (cnt <= kSortGiveUp) {  // heap sort
+    auto sift = [&](int root, int end) {
+      for (;;) {
+        int child = 2 * root + 1;
+        if (child > end) break;
+        if (child + 1 <= end && seg[child] < seg[child + 1]) child++;
+        if (seg[root] < seg[child]) { const int t = seg[root]; seg[root] = seg[child]; seg[child] = t; root = child; }
+        else break;
+      }
+    };
+    for (int s0 = (cnt - 2) / 2; s0 >= 0; s0--) sift(s0, cnt - 1);
+    for (int end = cnt - 1; end > 0; end--) {
+      const int t = seg[0]; seg[0] = seg[end]; seg[end] = t;
+      sift(0, end - 1);
+    }
+  }
+}
+
+// Source ordering: after the counting sort by lattice cell, sort each cell's indices (stable,
+// hence deterministic) and gather the points, so that consecutive lanes of K2 touch the same or
+// adjacent target voxels (coalesced LUT probes and record gathers).
+__global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
+                                                        const int* __restrict__ leaf_count, int n_leaves,
+                                                        int* __restrict__ sorted_idx, float4* __restrict__ out) {
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n_leaves) return;
+  const unsigned start = leaf_start[o];
+  const int cnt = leaf_count[o];
+  int* seg = sorted_idx + start;
+  sort_segment(seg, cnt);
+  for (int i = 0; i < cnt; i++) out[start + i] = pts[seg[i]];
+}
 
 __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ pts, const int* __restrict__ leaf_cell,
                                                      const unsigned* __restrict__ leaf_start,
@@ -369,29 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
   // The scatter's atomic cursor leaves the segment in arrival order; restore
   // ascending point order so the f64 sums below round exactly like the
   // reference's sequential first pass (_impl.hpp:209-263).
-  if (cnt <= kSortLimit) {
-    for (int i = 1; i < cnt; i++) {
-      const int v = seg[i];
-      int j = i - 1;
-      while (j >= 0 && seg[j] > v) { seg[j + 1] = seg[j]; j--; }
-      seg[j + 1] = v;
-    }
-  } else {  // heap sort, in place
-    auto sift = [&](int root, int end) {
-      for (;;) {
-        int child = 2 * root + 1;
-        if (child > end) break;
-        if (child + 1 <= end && seg[child] < seg[child + 1]) child++;
-        if (seg[root] < seg[child]) { const int t = seg[root]; seg[root] = seg[child]; seg[child] = t; root = child; }
-        else break;
-      }
-    };
-    for (int s = (cnt - 2) / 2; s >= 0; s--) sift(s, cnt - 1);
-    for (int end = cnt - 1; end > 0; end--) {
-      const int t = seg[0]; seg[0] = seg[end]; seg[end] = t;
-      sift(0, end - 1);
-    }
-  }
+  sort_segment(seg, cnt);
 
   // first-pass sums: mean_ += pt ; cov_ += pt*pt^T with cov_ seeded Identity (.h:107)
   double sx = 0, sy = 0, sz = 0;
@@ -666,11 +770,41 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
   }
 }
 
-template <int NNB, bool WANT_H, bool BATCH>
+// DIRECT7, latency-oriented decomposition: one (point, neighbour) task per lane, 8 consecutive
+// lanes share a point (slot 7 idles).  Seven dependent gathers per point become seven parallel
+// lanes, so a 100k-point scan exposes 700k independent tasks instead of 100k serial chains.
+template <bool WANT_H, class P>
+__device__ __forceinline__ void derivatives_body_split7(const float4* __restrict__ src, int n, const GridView& gv,
+                                                        const P& prm, int first, int stride, double (&acc)[kNumAcc]) {
+  const int slot = threadIdx.x & 7;
+  if (slot == 7) return;
+  // order of getNeighborhoodAtPoint7 (_impl.hpp:423-430): centre, +x, -x, +y, -y, +z, -z
+  const int dx = (slot == 1) - (slot == 2), dy = (slot == 3) - (slot == 4), dz = (slot == 5) - (slot == 6);
+  const long long total = static_cast<long long>(n) * 8;
+  for (long long t = first; t < total; t += stride) {
+    const float4 pt = src[t >> 3];
+    float tx, ty, tz;
+    xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    int vi, vj, vk;
+    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    const int rix = probe(gv, vi, vj, vk, dx, dy, dz);
+    if (rix < 0) continue;
+    const RecRegs r = load_rec(gv.recs, rix);
+    PointDeriv d;
+    point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
+    const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
+    const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
+    const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
+    accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, r, prm.d1, prm.d2);
+  }
+}
+
+template <int NNB, bool WANT_H, bool BATCH, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                         const ScanDesc* __restrict__ descs, int kind,
                                                         double* __restrict__ partials) {
-  __shared__ double lds[(kBlock / kWave) * kNumAcc];
+  __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ EvalParams sP;
   double acc[kNumAcc];
 #pragma unroll
@@ -684,9 +818,11 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
     __syncthreads();
-    derivatives_body<NNB, WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    if (SPLIT) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    else derivatives_body<NNB, WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
   } else {
-    derivatives_body<NNB, WANT_H>(src, n, gv, P, first, stride, acc);
+    if (SPLIT) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
+    else derivatives_body<NNB, WANT_H>(src, n, gv, P, first, stride, acc);
   }
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
@@ -739,7 +875,7 @@ __device__ __forceinline__ void hessian64_neighbor(double (&acc)[kNumAcc], const
 template <int NNB, bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__ src, int n, GridView gv, Hess64Params P,
                                                       const ScanDesc* __restrict__ descs, double* __restrict__ partials) {
-  __shared__ double lds[(kBlock / kWave) * kNumAcc];
+  __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ Hess64Params sP;
   double acc[kNumAcc];
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
@@ -781,16 +917,27 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
 // ---------------------------------------------------------------------------
 // fixed-order reduction of the per-block partials
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ partials, int n_blocks,
-                                                   const ScanDesc* __restrict__ descs, double* __restrict__ out) {
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void k_reduce(const double* __restrict__ partials, int n_blocks,
+                                                           const ScanDesc* __restrict__ descs, double* __restrict__ out,
+                                                           unsigned long long seq) {
   const int scan = blockIdx.x;
   if (descs && descs[scan].kind == 3) return;  // EVAL_NONE: row left untouched
-  constexpr int kParts = kBlock / kEvalStride;  // 8
+  constexpr int kParts = kReduceThreads / kEvalStride;  // 32
   const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
   const double* base = partials + static_cast<size_t>(scan) * n_blocks * kEvalStride;
   double v = 0.0;
-  if (k < kNumAcc)
-    for (int b = part; b < n_blocks; b += kParts) v += base[static_cast<size_t>(b) * kEvalStride + k];
+  if (k < kNumAcc) {
+    int b = part;
+    for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {  // 4 independent loads in flight
+      const double a0 = base[static_cast<size_t>(b) * kEvalStride + k];
+      const double a1 = base[static_cast<size_t>(b + kParts) * kEvalStride + k];
+      const double a2 = base[static_cast<size_t>(b + 2 * kParts) * kEvalStride + k];
+      const double a3 = base[static_cast<size_t>(b + 3 * kParts) * kEvalStride + k];
+      v += a0; v += a1; v += a2; v += a3;
+    }
+    for (; b < n_blocks; b += kParts) v += base[static_cast<size_t>(b) * kEvalStride + k];
+  }
   __shared__ double s[kParts][kEvalStride];
   s[part][k] = v;
   __syncthreads();
@@ -798,7 +945,15 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
     double t = 0.0;
 #pragma unroll
     for (int p = 0; p < kParts; p++) t += s[p][threadIdx.x];
-    out[static_cast<size_t>(scan) * kEvalStride + threadIdx.x] = t;
+    // slot 31 is the completion word when the row is polled from the host (seq != 0)
+    if (seq == 0 || threadIdx.x != kEvalStride - 1) out[static_cast<size_t>(scan) * kEvalStride + threadIdx.x] = t;
+    if (seq != 0) {
+      // `out` is fine-grained pinned host memory: publish the row, then the sequence number
+      __threadfence_system();
+      if (threadIdx.x == kEvalStride - 1)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out) + static_cast<size_t>(scan) * kEvalStride + (kEvalStride - 1),
+                           seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -817,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__
 template <int NNB>
 __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict__ cloud, int n, GridView gv, double d1,
                                                        double d2, double d3, double* __restrict__ partials) {
-  __shared__ double lds[(kBlock / kWave) * 1];
+  __shared__ double lds[(kBlock / kWave) * 32];
   double acc[1] = {0.0};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 pt = cloud[i];
@@ -859,7 +1014,21 @@ inline int grid_for(size_t n, int max_blocks) {
 // ===========================================================================
 // launchers
 // ===========================================================================
-int derivative_blocks(int n) { return grid_for(static_cast<size_t>(n), 1024); }
+// Tunables (development aid): NDT_K2_SPLIT=0 selects the point-per-lane DIRECT7 kernel,
+// NDT_K2_MAX_BLOCKS caps the grid.
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+bool derivative_split7() {
+  static const bool on = env_int("NDT_K2_SPLIT", 0) != 0;
+  return on;
+}
+int derivative_blocks(int n, int search) {
+  static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
+  const size_t tasks = (search != 1 && search != 3 && derivative_split7()) ? static_cast<size_t>(n) * 8 : static_cast<size_t>(n);
+  return grid_for(tasks, cap);
+}
 
 hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream) {
   if (n == 0) return hipSuccess;
@@ -916,17 +1085,30 @@ hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsi
   return hipGetLastError();
 }
 
+hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_selftest_reduce, dim3(n_blocks), dim3(kBlock), 0, stream, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
+                              int* sorted_idx, float4* out, hipStream_t stream) {
+  if (n_leaves == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sort_gather, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
+                     leaf_count, n_leaves, sorted_idx, out);
+  return hipGetLastError();
+}
+
 int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile - 1) / kScanTile); }
 
-template <int NNB, bool WANT_H>
+template <int NNB, bool WANT_H, bool SPLIT>
 static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
                            int n_scans, int kind, int n_blocks, double* partials, hipStream_t stream) {
   if (descs)
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src, n, gv,
-                       P, descs, kind, partials);
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, SPLIT>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src,
+                       n, gv, P, descs, kind, partials);
   else
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n, gv, P,
-                       descs, kind, partials);
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false, SPLIT>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
+                       gv, P, descs, kind, partials);
 }
 
 hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
@@ -934,14 +1116,17 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
                               double* partials, hipStream_t stream) {
   // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
   if (search == 1) {
-    if (want_hessian) launch_deriv_t<26, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<26, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<26, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<26, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   } else if (search == 3) {
-    if (want_hessian) launch_deriv_t<1, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<1, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<1, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<1, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  } else if (derivative_split7()) {
+    if (want_hessian) launch_deriv_t<7, true, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   } else {
-    if (want_hessian) launch_deriv_t<7, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<7, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   }
   return hipGetLastError();
 }
@@ -966,8 +1151,8 @@ hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const 
 }
 
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
-                         hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce, dim3(n_scans), dim3(kBlock), 0, stream, partials, n_blocks, descs, out);
+                         hipStream_t stream, unsigned long long seq) {
+  hipLaunchKernelGGL(k_reduce, dim3(n_scans), dim3(kReduceThreads), 0, stream, partials, n_blocks, descs, out, seq);
   return hipGetLastError();
 }
 

@@ -107,14 +107,19 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
                               double* partials, hipStream_t stream);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
-// Sums the per-block partials in a fixed order: out[scan][kEvalStride].
+// Sums the per-block partials in a fixed order: out[scan][kEvalStride].  seq != 0: `out` is pinned
+// host memory polled by the host; slot kEvalStride-1 of each row then receives `seq` (u64) last.
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
-                         hipStream_t stream);
+                         hipStream_t stream, unsigned long long seq = 0);
 hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream);
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
                              int search, int n_blocks, double* partials, hipStream_t stream);
 
-int derivative_blocks(int n);  // grid size used for n source points
+hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
+                              int* sorted_idx, float4* out, hipStream_t stream);
+hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream);
+int derivative_blocks(int n, int search);  // grid size used for n source points
+bool derivative_split7();
 int scan_tiles(long long n_cells);  // number of 2048-cell tiles of the cell scan
 
 }  // namespace ndt

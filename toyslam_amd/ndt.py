@@ -210,6 +210,11 @@ class NormalDistributionsTransform:
         self._keep = [cb]
         check(self._L.ndt_set_allreduce(self._h, cb, None, int(on_device)))
 
+    def selftest_reduce(self, n_blocks=3):
+        out = np.zeros((n_blocks, _lib.EVAL_STRIDE))
+        check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
+        return out
+
     def profile(self, on):
         check(self._L.ndt_profile_enable(self._h, int(on)))
 
