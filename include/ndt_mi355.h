@@ -163,6 +163,12 @@ ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, doubl
  * of known per-thread values; block_sums receives n_blocks x NDT_EVAL_STRIDE doubles (slots 0..28). */
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums);
 
+/* Diagnostic (development aid): one DIRECT7 evaluation at pose p by the s_memtime-stamped build of
+ * the derivative kernel.  stamps receives n_waves x 8 u64 (shader cycles at: entry, point
+ * arrived, LUT arrived, first record arrived, neighbour math done, wave fold done, block done);
+ * *n_waves in: capacity, out: waves written. */
+ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* stamps, size_t* n_waves);
+
 /* Host-side scalar pieces of the driver (no GPU needed), exported so that the
  * CPU test-suite can check them against the oracle. */
 void ndt_host_solve6(const double* H /*36 row-major*/, const double* b /*6*/, double* x /*6*/); /* JacobiSVD.solve, :127-129 */

@@ -36,6 +36,15 @@ def main():
     for _ in range(50):
         g.hessian_f64(p)
     print("hessian_f64 %.1f us" % ((time.time() - t0) / 50 * 1e6))
+    g.diag_stamps(p)
+    st = g.diag_stamps(p).astype(np.int64)
+    t0 = st[:, 0].min()
+    names = ["entry", "point", "lut", "rec0", "math", "fold", "done"]
+    print("stamps (shader cycles, over %d waves): kernel span %d" % (len(st), st[:, 6].max() - t0))
+    for k in range(7):
+        col = st[:, k] - t0
+        d = (st[:, k] - st[:, k - 1]) if k else col
+        print("  %-6s abs median %7d max %7d | delta median %6d p90 %6d max %6d" % (names[k], np.median(col), col.max(), np.median(d), np.percentile(d, 90), d.max()))
     g.profile(True); g.profile_read(0); g.profile_read(1)
     g.align()
     n0, ms0 = g.profile_read(0); n1, ms1 = g.profile_read(1)

@@ -7,7 +7,7 @@ for split in 1 0; do
   for blocks in 256 512 1024 2048 4096; do
     for spin in 1; do
       echo "=== SPLIT=$split MAX_BLOCKS=$blocks SPIN=$spin" >> $out
-      NDT_K2_SPLIT=$split NDT_K2_MAX_BLOCKS=$blocks NDT_SPIN_WAIT=$spin timeout -k 5 120 python tools/gpu_probe.py ${1:-U} 2>&1 | grep -E "eval\(|event-timed|align median" >> $out
+      NDT_K2_VARIANT=$split NDT_K2_MAX_BLOCKS=$blocks NDT_SPIN_WAIT=$spin timeout -k 5 120 python tools/gpu_probe.py ${1:-U} 2>&1 | grep -E "eval\(|event-timed|align median" >> $out
     done
   done
 done

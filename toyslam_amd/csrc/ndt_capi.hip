@@ -926,6 +926,31 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
   return NDT_OK;
 }
 
+ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* stamps, size_t* n_waves) {
+  if (!h || !p || !stamps || !n_waves) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  const int n = h->source->k2_n();
+  if (n == 0 || h->grid->empty) { *n_waves = 0; return NDT_OK; }
+  const int nblk = ndt::derivative_blocks(n, NDT_DIRECT1);
+  const size_t waves = static_cast<size_t>(nblk) * 4;
+  if (*n_waves < waves) return fail(NDT_ERR_INVALID, "stamp buffer too small");
+  ndt::EvalRequest rq;
+  rq.kind = ndt::EVAL_WITH_HESSIAN;
+  std::memcpy(rq.p, p, sizeof(rq.p));
+  ndt::pose_to_matrix(p, rq.T);
+  ndt::EvalParams P;
+  fill_eval_params(rq, ndt::gauss_constants(h->resolution, h->outlier_ratio), P);
+  DevBuf<unsigned long long> d;
+  HIP_TRY(d.reserve(waves * 8));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(ndt::launch_derivatives_stamped(h->source->k2_pts(), n, h->grid->view(), P, nblk, h->partials.p, d.p, h->stream));
+  HIP_TRY(hipMemcpyAsync(stamps, d.p, waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_waves = waves;
+  return NDT_OK;
+}
+
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums) {
   if (!h || n_blocks <= 0 || !block_sums) return fail(NDT_ERR_INVALID, "bad arguments");
   ndt_status s = ensure_device(h);

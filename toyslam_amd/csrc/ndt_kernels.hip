@@ -735,11 +735,116 @@ __device__ __forceinline__ void accumulate_neighbor(double (&acc)[kNumAcc], cons
   }
 }
 
-template <int NNB, bool WANT_H, class P>
+// ---------------------------------------------------------------------------
+// Factored form of updateDerivatives.  With xc = C x' (C symmetric) the reference's per-neighbour
+// quantities are
+//   gradient_k     += e * (xc . J_k)
+//   hessian(i,j)   += e * ( -d2 (xc . J_i)(xc . J_j) + xc . HE_ij + J_j^T C J_i )
+// and J_k, HE_ij depend on the POINT only.  Everything is therefore linear in two small
+// per-neighbour objects,
+//   xe = sum_n e_n xc_n                      (3)
+//   A  = sum_n e_n (C_n - d2 xc_n xc_n^T)    (3x3 symmetric, 6)
+// which are accumulated over the <= 7 neighbours of a point (f32), after which
+//   gradient = J^T xe ,  hessian = J^T A J + [xe . HE_ij]   are formed ONCE per point and added to
+// the f64 accumulators.  ~60 instead of ~350 VALU instructions per neighbour; the f32 rounding of
+// the per-point sums differs from the reference's per-neighbour rounding by O(1e-7) relative per
+// point (same order as its own f32 noise), far inside the parity tolerance.
+// ---------------------------------------------------------------------------
+struct PointAcc {
+  float xe0, xe1, xe2;
+  float a00, a01, a02, a11, a12, a22;
+};
+
+template <bool WANT_H>
+__device__ __forceinline__ void accumulate_neighbor_factored(double& score, double& nn, PointAcc& pa, float x0, float x1,
+                                                             float x2, const RecRegs& r, double d1, float d2) {
+  const float xc0 = (x0 * r.c00 + x1 * r.c01) + x2 * r.c02;
+  const float xc1 = (x0 * r.c01 + x1 * r.c11) + x2 * r.c12;
+  const float xc2 = (x0 * r.c02 + x1 * r.c12) + x2 * r.c22;
+  const float q = (x0 * xc0 + x1 * xc1) + x2 * xc2;
+  float e = expf(-d2 * q * 0.5f);                                            // :499
+  const float score_inc = static_cast<float>(-d1 * static_cast<double>(e));  // :501
+  e = d2 * e;                                                                // :503
+  if (e > 1.0f || e < 0.0f || e != e) return;                                // :506-507
+  e = static_cast<float>(static_cast<double>(e) * d1);                       // :510
+  score += static_cast<double>(score_inc);
+  nn += 1.0;
+  pa.xe0 += e * xc0;
+  pa.xe1 += e * xc1;
+  pa.xe2 += e * xc2;
+  if (WANT_H) {
+    const float t0 = (-d2 * e) * xc0, t1 = (-d2 * e) * xc1, t2 = (-d2 * e) * xc2;
+    pa.a00 += e * r.c00 + t0 * xc0;
+    pa.a01 += e * r.c01 + t0 * xc1;
+    pa.a02 += e * r.c02 + t0 * xc2;
+    pa.a11 += e * r.c11 + t1 * xc1;
+    pa.a12 += e * r.c12 + t1 * xc2;
+    pa.a22 += e * r.c22 + t2 * xc2;
+  }
+}
+
+// J_E = [ I3 | B ],  B columns: (0, j0, j1), (j2, j3, j4), (j5, j6, j7)   (ndt_omp_impl.hpp:407-414)
+template <bool WANT_H>
+__device__ __forceinline__ void finish_point(double (&acc)[kNumAcc], const PointAcc& pa, const PointDeriv& d) {
+  const float* j = d.j;
+  const float B[3][3] = {{0.0f, j[2], j[5]}, {j[0], j[3], j[6]}, {j[1], j[4], j[7]}};
+  acc[1] += static_cast<double>(pa.xe0);
+  acc[2] += static_cast<double>(pa.xe1);
+  acc[3] += static_cast<double>(pa.xe2);
+  acc[4] += static_cast<double>(pa.xe1 * B[1][0] + pa.xe2 * B[2][0]);
+  acc[5] += static_cast<double>((pa.xe0 * B[0][1] + pa.xe1 * B[1][1]) + pa.xe2 * B[2][1]);
+  acc[6] += static_cast<double>((pa.xe0 * B[0][2] + pa.xe1 * B[1][2]) + pa.xe2 * B[2][2]);
+  if (WANT_H) {
+    const float A[3][3] = {{pa.a00, pa.a01, pa.a02}, {pa.a01, pa.a11, pa.a12}, {pa.a02, pa.a12, pa.a22}};
+    float AB[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      AB[r][0] = A[r][1] * B[1][0] + A[r][2] * B[2][0];
+#pragma unroll
+      for (int c = 1; c < 3; c++) AB[r][c] = (A[r][0] * B[0][c] + A[r][1] * B[1][c]) + A[r][2] * B[2][c];
+    }
+    // x-block of H_E: a b c / b d e / c e f  with a=(0,h0,h1) b=(0,h2,h3) c=(0,h4,h5) d=(h6,h7,h8) ...
+    const float* h = d.h;
+    const float xa = pa.xe1 * h[0] + pa.xe2 * h[1];
+    const float xb = pa.xe1 * h[2] + pa.xe2 * h[3];
+    const float xcc = pa.xe1 * h[4] + pa.xe2 * h[5];
+    const float xd = (pa.xe0 * h[6] + pa.xe1 * h[7]) + pa.xe2 * h[8];
+    const float xe = (pa.xe0 * h[9] + pa.xe1 * h[10]) + pa.xe2 * h[11];
+    const float xf = (pa.xe0 * h[12] + pa.xe1 * h[13]) + pa.xe2 * h[14];
+    const float X[3][3] = {{xa, xb, xcc}, {xb, xd, xe}, {xcc, xe, xf}};
+    // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+    int idx = 7;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int c = i; c < 3; c++) acc[idx++] += static_cast<double>(A[i][c]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) acc[idx++] += static_cast<double>(AB[i][c]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = a; b < 3; b++) {
+        float v = (a == 0) ? (B[1][0] * AB[1][b] + B[2][0] * AB[2][b])
+                           : ((B[0][a] * AB[0][b] + B[1][a] * AB[1][b]) + B[2][a] * AB[2][b]);
+        acc[idx++] += static_cast<double>(v + X[a][b]);
+      }
+  }
+}
+
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+template <int NNB, bool WANT_H, class P, bool STAMP = false, bool FACTORED = true>
 __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
-                                                 int first, int stride, double (&acc)[kNumAcc]) {
+                                                 int first, int stride, double (&acc)[kNumAcc],
+                                                 unsigned long long* st = nullptr) {
   for (int i = first; i < n; i += stride) {
     const float4 pt = src[i];
+    if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[1] = stamp(); }
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
     int vi, vj, vk;
@@ -754,19 +859,63 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
       rec[k] = probe(gv, vi, vj, vk, dx, dy, dz);
       any |= (rec[k] >= 0);
     }
+    if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[2] = stamp(); }
     if (!any) continue;
     PointDeriv d;
     point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
+    // Software pipeline over the neighbours: the record of neighbour k+1 is requested (index
+    // clamped, so the load is unconditional and hoistable) before neighbour k's math runs; one
+    // record gather latency is exposed per point instead of one per neighbour.
+    RecRegs cur = load_rec(gv.recs, rec[0] < 0 ? 0 : rec[0]);
+    if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = stamp(); }
+    PointAcc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NNB; k++) {
-      if (rec[k] < 0) continue;
-      const RecRegs r = load_rec(gv.recs, rec[k]);
-      // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
-      const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
-      const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
-      const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
-      accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, r, prm.d1, prm.d2);
+      RecRegs nxt = cur;
+      if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
+      if (rec[k] >= 0) {
+        // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
+        const float x0 = static_cast<float>(static_cast<double>(tx) - cur.mx);
+        const float x1 = static_cast<float>(static_cast<double>(ty) - cur.my);
+        const float x2 = static_cast<float>(static_cast<double>(tz) - cur.mz);
+        if (FACTORED) accumulate_neighbor_factored<WANT_H>(acc[0], acc[28], pa, x0, x1, x2, cur, prm.d1, prm.d2);
+        else accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, cur, prm.d1, prm.d2);
+      }
+      cur = nxt;
     }
+    if (FACTORED) finish_point<WANT_H>(acc, pa, d);
+    if (STAMP) st[4] = stamp();
+  }
+}
+
+// Diagnostic build of the DIRECT7 derivative kernel with s_memtime stamps (never used by the
+// product path): per wave, cycles at entry / point arrived / LUT arrived / first record arrived /
+// neighbour math done / wave fold done / block done.
+__global__ __launch_bounds__(kBlock) void k_derivatives_stamped(const float4* __restrict__ src, int n, GridView gv,
+                                                                EvalParams P, double* __restrict__ partials,
+                                                                unsigned long long* __restrict__ stamps) {
+  __shared__ double lds[(kBlock / kWave) * 32];
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  st[0] = stamp();
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  derivatives_body<7, true, EvalParams, true>(src, n, gv, P, first, stride, acc, st);
+  const double tot = wave_fold<kNumAcc>(acc);
+  st[5] = stamp();
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+  __syncthreads();
+  if (threadIdx.x < kNumAcc) {
+    double v = lds[threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v += lds[w * 32 + threadIdx.x];
+    partials[static_cast<size_t>(blockIdx.x) * kEvalStride + threadIdx.x] = v;
+  }
+  st[6] = stamp();
+  if (lane == 0) {
+    unsigned long long* o = stamps + (static_cast<size_t>(blockIdx.x) * (kBlock / kWave) + wave) * 8;
+    for (int k = 0; k < 8; k++) o[k] = st[k];
   }
 }
 
@@ -800,7 +949,7 @@ __device__ __forceinline__ void derivatives_body_split7(const float4* __restrict
   }
 }
 
-template <int NNB, bool WANT_H, bool BATCH, bool SPLIT>
+template <int NNB, bool WANT_H, bool BATCH, int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                         const ScanDesc* __restrict__ descs, int kind,
                                                         double* __restrict__ partials) {
@@ -818,11 +967,11 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
     __syncthreads();
-    if (SPLIT) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
-    else derivatives_body<NNB, WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    if (VARIANT == 1) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
   } else {
-    if (SPLIT) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
-    else derivatives_body<NNB, WANT_H>(src, n, gv, P, first, stride, acc);
+    if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
+    else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, P, first, stride, acc);
   }
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
@@ -1020,10 +1169,13 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-bool derivative_split7() {
-  static const bool on = env_int("NDT_K2_SPLIT", 0) != 0;
-  return on;
+// DIRECT7 kernel variant: 0 = factored, point per lane (default); 1 = one (point, neighbour)
+// task per lane; 2 = per-neighbour math in the reference's operation order (validation).
+int derivative_variant() {
+  static const int v = env_int("NDT_K2_VARIANT", 0);
+  return v;
 }
+bool derivative_split7() { return derivative_variant() == 1; }
 int derivative_blocks(int n, int search) {
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
   const size_t tasks = (search != 1 && search != 3 && derivative_split7()) ? static_cast<size_t>(n) * 8 : static_cast<size_t>(n);
@@ -1098,16 +1250,22 @@ hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, con
   return hipGetLastError();
 }
 
+hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,
+                                      double* partials, unsigned long long* stamps, hipStream_t stream) {
+  hipLaunchKernelGGL(k_derivatives_stamped, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, gv, P, partials, stamps);
+  return hipGetLastError();
+}
+
 int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile - 1) / kScanTile); }
 
-template <int NNB, bool WANT_H, bool SPLIT>
+template <int NNB, bool WANT_H, int VARIANT>
 static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
                            int n_scans, int kind, int n_blocks, double* partials, hipStream_t stream) {
   if (descs)
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, SPLIT>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src,
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, VARIANT>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src,
                        n, gv, P, descs, kind, partials);
   else
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false, SPLIT>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false, VARIANT>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
                        gv, P, descs, kind, partials);
 }
 
@@ -1115,18 +1273,22 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
                               bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
                               double* partials, hipStream_t stream) {
   // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
+  const int variant = derivative_variant();
   if (search == 1) {
-    if (want_hessian) launch_deriv_t<26, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<26, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<26, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<26, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   } else if (search == 3) {
-    if (want_hessian) launch_deriv_t<1, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<1, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-  } else if (derivative_split7()) {
-    if (want_hessian) launch_deriv_t<7, true, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false, true>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<1, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<1, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  } else if (variant == 1) {
+    if (want_hessian) launch_deriv_t<7, true, 1>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false, 1>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+  } else if (variant == 2) {
+    if (want_hessian) launch_deriv_t<7, true, 2>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false, 2>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   } else {
-    if (want_hessian) launch_deriv_t<7, true, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false, false>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) launch_deriv_t<7, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    else launch_deriv_t<7, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   }
   return hipGetLastError();
 }

@@ -117,9 +117,12 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
 
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream);
+hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,
+                                      double* partials, unsigned long long* stamps, hipStream_t stream);
 hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream);
 int derivative_blocks(int n, int search);  // grid size used for n source points
 bool derivative_split7();
+int derivative_variant();
 int scan_tiles(long long n_cells);  // number of 2048-cell tiles of the cell scan
 
 }  // namespace ndt

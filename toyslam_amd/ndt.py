@@ -210,6 +210,13 @@ class NormalDistributionsTransform:
         self._keep = [cb]
         check(self._L.ndt_set_allreduce(self._h, cb, None, int(on_device)))
 
+    def diag_stamps(self, p, max_waves=1 << 16):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        st = np.zeros((max_waves, 8), dtype=np.uint64)
+        n = C.c_size_t(max_waves)
+        check(self._L.ndt_diag_stamps(self._h, _d(p), st.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(n)))
+        return st[:n.value]
+
     def selftest_reduce(self, n_blocks=3):
         out = np.zeros((n_blocks, _lib.EVAL_STRIDE))
         check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
