@@ -1,0 +1,79 @@
+// TEST-ONLY: a caller shaped like ndt_omp/apps/align.cpp:14-33 and
+// lidar_subscriber/src/ndt_omp_mapping_node.cpp:151-169, compiled against include/pclomp/ndt_omp.h
+// (with the PCL stand-ins of tests/pcl_stub) and linked to libndt_mi355.so.
+//   adapter_harness target.f32 n_target source.f32 n_source   (xyz float32 triples)
+#include <pclomp/ndt_omp.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+typedef pcl::PointXYZ PointT;
+typedef pclomp::NormalDistributionsTransform<PointT, PointT> NDT;
+
+static pcl::PointCloud<PointT>::Ptr load(const char* path, size_t n) {
+  pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>());
+  std::vector<float> raw(n * 3);
+  FILE* f = std::fopen(path, "rb");
+  if (!f || std::fread(raw.data(), sizeof(float), raw.size(), f) != raw.size()) {
+    std::fprintf(stderr, "cannot read %s\n", path);
+    std::exit(2);
+  }
+  std::fclose(f);
+  c->points.resize(n);
+  for (size_t i = 0; i < n; i++) c->points[i] = PointT{raw[3 * i], raw[3 * i + 1], raw[3 * i + 2], 1.0f};
+  c->width = static_cast<unsigned>(n);
+  return c;
+}
+
+// ndt_omp_mapping_node.cpp:151-169: configures a member, aligns, returns the object BY VALUE
+static NDT align_consecutive(NDT& ndt, const pcl::PointCloud<PointT>::Ptr& target, const pcl::PointCloud<PointT>::Ptr& source) {
+  ndt.setInputTarget(target);
+  ndt.setInputSource(source);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  ndt.align(*aligned);
+  return ndt;
+}
+
+static void print(const char* tag, const Eigen::Matrix4f& m, bool conv, int iters) {
+  std::printf("%s converged=%d iterations=%d T=", tag, conv ? 1 : 0, iters);
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) std::printf("%.9g ", m(r, c));
+  std::printf("\n");
+}
+
+int main(int argc, char** argv) {
+  if (argc != 5) return 2;
+  auto target = load(argv[1], std::strtoul(argv[2], nullptr, 10));
+  auto source = load(argv[3], std::strtoul(argv[4], nullptr, 10));
+
+  // apps/align.cpp:95-103 -- through the pcl::Registration base pointer
+  NDT::Ptr ndt_omp(new NDT());
+  ndt_omp->setResolution(1.0);
+  ndt_omp->setNumThreads(8);
+  ndt_omp->setNeighborhoodSearchMethod(pclomp::DIRECT7);
+  pcl::Registration<PointT, PointT>::Ptr registration = ndt_omp;
+  registration->setInputTarget(target);
+  registration->setInputSource(source);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  registration->align(*aligned);
+  print("align_app", registration->getFinalTransformation(), registration->hasConverged(), ndt_omp->getFinalNumIteration());
+  std::printf("aligned0 %.9g %.9g %.9g %.9g\n", aligned->points[0].x, aligned->points[0].y, aligned->points[0].z, aligned->points[0].pad);
+
+  // ndt_omp_mapping_node.cpp:55-62 parameters, object returned by value
+  NDT member;
+  member.setResolution(1.0);
+  member.setStepSize(0.1);
+  member.setTransformationEpsilon(0.01);
+  member.setMaximumIterations(64);
+  member.setNumThreads(40);
+  member.setNeighborhoodSearchMethod(pclomp::DIRECT7);
+  NDT copy = align_consecutive(member, target, source);
+  print("mapping_node", copy.getFinalTransformation(), copy.hasConverged(), copy.getFinalNumIteration());
+
+  // ndt_rosbag_mapping_node.cpp:124-141: previous result as the initial guess
+  pcl::PointCloud<PointT>::Ptr aligned2(new pcl::PointCloud<PointT>());
+  copy.align(*aligned2, copy.getFinalTransformation());
+  print("rosbag_node", copy.getFinalTransformation(), copy.hasConverged(), copy.getFinalNumIteration());
+  std::printf("trans_probability %.12g\n", copy.getTransformationProbability());
+  return 0;
+}

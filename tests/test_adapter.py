@@ -1,0 +1,72 @@
+"""The header-only pclomp/ndt_omp.h adapter: compiles against test-only PCL/Eigen stand-ins (CPU),
+and a caller shaped like apps/align.cpp + ndt_omp_mapping_node.cpp runs through it on the GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rot_err, trans_err
+
+INC = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "pcl_stub")]
+SRC = os.path.join(ROOT, "tests", "adapter_harness.cpp")
+
+
+def test_adapter_header_compiles():
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + INC + [SRC])
+
+
+def test_adapter_declares_reference_surface():
+    """Every public method the reference class declares (ndt_omp.h:110-238) and its callers use."""
+    hdr = open(os.path.join(ROOT, "include", "pclomp", "ndt_omp.h")).read()
+    for name in ["setNumThreads", "setInputTarget", "setResolution", "getResolution", "getStepSize", "setStepSize",
+                 "getOutlierRatio", "setOutlierRatio", "setNeighborhoodSearchMethod", "getTransformationProbability",
+                 "getFinalNumIteration", "convertTransform", "calculateScore", "computeTransformation", "search_method",
+                 "EIGEN_MAKE_ALIGNED_OPERATOR_NEW", "enum NeighborSearchMethod { KDTREE, DIRECT26, DIRECT7, DIRECT1 }",
+                 "public pcl::Registration<PointSource, PointTarget>"]:
+        assert name in hdr, name
+
+
+@pytest.mark.gpu
+def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
+    from oracle import pyoracle as po
+    t, s = pair
+    exe = str(tmp_path / "adapter_harness")
+    libdir = os.path.join(ROOT, "toyslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + INC + [SRC, "-o", exe, "-L" + libdir, "-lndt_mi355",
+                                                               "-Wl,-rpath," + libdir])
+    tf, sf = str(tmp_path / "t.f32"), str(tmp_path / "s.f32")
+    t.astype("<f4").tofile(tf)
+    s.astype("<f4").tofile(sf)
+    out = subprocess.check_output([exe, tf, str(len(t)), sf, str(len(s))], text=True)
+    rows = {}
+    for line in out.splitlines():
+        tag, _, rest = line.partition(" ")
+        rows[tag] = rest
+    def parse(tag):
+        f = rows[tag].split()
+        conv = int(f[0].split("=")[1])
+        iters = int(f[1].split("=")[1])
+        T = np.array([float(x) for x in [f[2].split("=")[1]] + f[3:18]]).reshape(4, 4)
+        return conv, iters, T
+
+    o = po.OracleNDT(resolution=1.0, num_threads=8)
+    o.set_target(t)
+    o.set_source(s)
+    r = o.align()
+    conv, iters, T = parse("align_app")
+    assert conv == 1 and iters == r["iterations"]
+    assert rot_err(T, r["T"]) < 1e-4 and trans_err(T, r["T"]) < 1e-3
+    a0 = np.array([float(x) for x in rows["aligned0"].split()])
+    assert a0[3] == 1.0 and np.allclose(a0[:3], po.transform_cloud(np.c_[s[:1], [[1.0]]].astype(np.float32), r["T"])[0, :3], atol=1e-3)
+
+    o.set(trans_eps=0.01, max_iter=64)
+    r2 = o.align()
+    conv, iters, T2 = parse("mapping_node")   # the by-value COPY carries the result
+    assert conv == 1 and iters == r2["iterations"]
+    assert rot_err(T2, r2["T"]) < 1e-4 and trans_err(T2, r2["T"]) < 1e-3
+    r3 = o.align(r2["T"])
+    conv, iters, T3 = parse("rosbag_node")    # previous result as the guess
+    assert conv == 1 and iters == r3["iterations"]
+    assert rot_err(T3, r3["T"]) < 1e-4 and trans_err(T3, r3["T"]) < 1e-3
+    assert float(rows["trans_probability"]) == pytest.approx(r3["trans_probability"], rel=1e-5)
