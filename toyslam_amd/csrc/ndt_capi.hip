@@ -107,6 +107,7 @@ struct ndt_context {
   std::shared_ptr<DeviceGrid> grid;
   // scratch
   DevBuf<double> partials;
+  DevBuf<unsigned> ticket;  // zero between launches (reset by the last block of the fused kernel)
   DevBuf<double> batch_out;
   DevBuf<ndt::ScanDesc> descs;
   DevBuf<float4> out_cloud;
@@ -114,6 +115,7 @@ struct ndt_context {
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
   size_t host_result_rows = 0;
   unsigned long long eval_seq = 0;
+  double t_launch = 0, t_wait = 0, t_solver = 0, t_fill = 0;  // NDT_TIMING=1 accounting (seconds)
   // results
   float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int converged = 0, nr_iterations = 0;
@@ -458,9 +460,18 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     if (nn_total) *nn_total = 0;
     return NDT_OK;
   }
-  const int nblk = ndt::derivative_blocks(n, h->search);
+  static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
+  static const bool fuse = [] { const char* v = getenv("NDT_K2_FUSED"); return v ? atoi(v) != 0 : true; }();
+  const bool fused = fuse && spin_wait && rq.kind != ndt::EVAL_HESSIAN_F64 && ndt::derivative_variant() == 0 && !h->allreduce;
+  const int nblk = fused ? ndt::fused_blocks(n) : ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  if (!h->ticket.p) {
+    HIP_TRY(h->ticket.reserve(1));
+    HIP_TRY(hipMemsetAsync(h->ticket.p, 0, sizeof(unsigned), h->stream));
+  }
   const ndt::GridView gv = h->grid->view();
+  const auto tp0 = std::chrono::steady_clock::now();
+  unsigned long long seq = 0;
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   if (rq.kind == ndt::EVAL_HESSIAN_F64) {
     ndt::Hess64Params P;
@@ -469,16 +480,25 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   } else {
     ndt::EvalParams P;
     fill_eval_params(rq, gs, P);
-    HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1,
-                                    rq.kind, nblk, h->partials.p, h->stream));
+    if (fused) {
+      seq = ++h->eval_seq;
+      HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, h->partials.p,
+                                            h->ticket.p, h->host_result, seq, h->stream));
+    } else {
+      HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1, rq.kind, nblk,
+                                      h->partials.p, h->stream));
+    }
   }
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-  static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
   if (spin_wait && !h->profiling) {
-    // Latency path: the reduce kernel writes the row and then a sequence number straight into
-    // pinned host memory; poll it instead of paying a stream synchronisation per evaluation.
-    const unsigned long long seq = ++h->eval_seq;
-    HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream, seq));
+    // Latency path: the result row and then a sequence number are written straight into pinned
+    // host memory; poll it instead of paying a stream synchronisation per evaluation.
+    if (!fused) {
+      seq = ++h->eval_seq;
+      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream, seq));
+    }
+    const auto tp1 = std::chrono::steady_clock::now();
+    h->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
@@ -494,8 +514,9 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
           return fail(NDT_ERR_HIP, "timed out waiting for the evaluation result");
       }
     }
+    h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
   } else {
-    HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+    if (!fused) HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   if (h->profiling) {
@@ -652,7 +673,15 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
     s = evaluate_single(h, solver.request(), r, &nn_step);
     if (s) return s;
     if (counts_neighbors) nn = nn_step;
+    const auto ts0 = std::chrono::steady_clock::now();
     solver.feed(r);
+    h->t_solver += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+  }
+  static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
+  if (timing) {
+    std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus (per align)\n", solver.n_evals + solver.n_hess,
+                 h->t_launch * 1e6, h->t_wait * 1e6, h->t_solver * 1e6);
+    h->t_launch = h->t_wait = h->t_solver = 0;
   }
   std::memcpy(h->final_T, solver.final_T, sizeof(h->final_T));
   h->converged = solver.converged ? 1 : 0;

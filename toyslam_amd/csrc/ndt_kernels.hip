@@ -69,6 +69,17 @@ __device__ __forceinline__ float wave_max(float v) {
 // additions is fixed by the lane ids, so the result is deterministic.
 // Afterwards lane l holds the wave total of value fold_index(l).
 // ---------------------------------------------------------------------------
+// Publication of one packed result row into fine-grained pinned HOST memory by lanes 0..31 of one
+// wave: 31 system-scope write-through stores, drained, then the sequence word.  No cache-wide
+// write-back/invalidate (a __threadfence_system() here costs a buffer_wbl2 + buffer_inv, several us).
+__device__ __forceinline__ void publish_row(double* __restrict__ row, double value, unsigned long long seq) {
+  if (threadIdx.x < kEvalStride - 1) __hip_atomic_store(row + threadIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == kEvalStride - 1)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(row) + (kEvalStride - 1), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 typedef unsigned fold_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double mk_f64(int lo, int hi) { return __hiloint2double(hi, lo); }
 
@@ -977,6 +988,85 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// Single-scan latency path: derivatives + final reduction + publication in ONE launch.
+//
+// Every block stores its 32-f64 partial row write-through (sc1), drains it (s_waitcnt vmcnt(0))
+// and takes a ticket with one relaxed agent-scope fetch_add; the block whose ticket is the last
+// re-reads ALL rows with sc1 loads (L1 is bypassed; every row was written through before its
+// block's ticket), sums them in a fixed order and writes the packed row plus the sequence word
+// straight into pinned host memory.  This is the ticket form of the hand-off of
+// cdna_hip_programming.md Guideline 16 (sc1 stores / sc1 loads / drained before the counter add /
+// last arriver told by the value its add returned; other waves of the last block load only after
+// the workgroup barrier that the ticket wave joins).  Saves the second launch and the
+// inter-kernel gap of the two-kernel path (~5 us per evaluation at 100k points).
+// The counter is reset by the last block, so it is 0 again at the next launch.
+// ---------------------------------------------------------------------------
+template <int NNB, bool WANT_H, int TPB>
+__global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
+                                                           double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                           double* __restrict__ out_row, unsigned long long seq) {
+  constexpr int kWaves = TPB / kWave, kParts = TPB / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ double lds2[kParts * kEvalStride];
+  __shared__ int s_last;
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  derivatives_body<NNB, WANT_H, EvalParams, false, true>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double tot = wave_fold<kNumAcc>(acc);
+  if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+  __syncthreads();
+  if (wave == 0) {
+    if (lane < kEvalStride) {
+      double v = 0.0;
+      if (lane < kNumAcc) {
+        v = lds[lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+      }
+      // write-through store of the whole 256-B row by one wave instruction
+      __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // last arriver: fixed-order sum of all rows, every load sc1
+  const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
+  const int n_blocks = gridDim.x;
+  double v = 0.0;
+  {
+    int b = part;
+    for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {
+      const double a0 = __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double a1 = __hip_atomic_load(partials + static_cast<size_t>(b + kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double a2 = __hip_atomic_load(partials + static_cast<size_t>(b + 2 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double a3 = __hip_atomic_load(partials + static_cast<size_t>(b + 3 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v += a0; v += a1; v += a2; v += a3;
+    }
+    for (; b < n_blocks; b += kParts)
+      v += __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  lds2[part * kEvalStride + k] = v;
+  __syncthreads();
+  if (threadIdx.x < kEvalStride) {
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
+    publish_row(out_row, t, seq);
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // computeHessian / updateHessian, all f64 (ndt_omp_impl.hpp:540-645, 443-481)
 // acc layout identical to k_derivatives (only [7..27] are written).
 // ---------------------------------------------------------------------------
@@ -1095,14 +1185,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const double* __restr
 #pragma unroll
     for (int p = 0; p < kParts; p++) t += s[p][threadIdx.x];
     // slot 31 is the completion word when the row is polled from the host (seq != 0)
-    if (seq == 0 || threadIdx.x != kEvalStride - 1) out[static_cast<size_t>(scan) * kEvalStride + threadIdx.x] = t;
-    if (seq != 0) {
-      // `out` is fine-grained pinned host memory: publish the row, then the sequence number
-      __threadfence_system();
-      if (threadIdx.x == kEvalStride - 1)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out) + static_cast<size_t>(scan) * kEvalStride + (kEvalStride - 1),
-                           seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (seq == 0) out[static_cast<size_t>(scan) * kEvalStride + threadIdx.x] = t;
+    else publish_row(out + static_cast<size_t>(scan) * kEvalStride, t, seq);
   }
 }
 
@@ -1290,6 +1374,32 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
     if (want_hessian) launch_deriv_t<7, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
     else launch_deriv_t<7, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
   }
+  return hipGetLastError();
+}
+
+constexpr int kFusedTPB = 512;
+int fused_blocks(int n) {
+  static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
+  size_t b = (static_cast<size_t>(n) + kFusedTPB - 1) / kFusedTPB;
+  if (b < 1) b = 1;
+  if (b > static_cast<size_t>(cap)) b = cap;
+  return static_cast<int>(b);
+}
+
+hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
+                                    bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                                    unsigned long long seq, hipStream_t stream) {
+#define NDT_LAUNCH_FUSED(NNB, H)                                                                                        \
+  hipLaunchKernelGGL((k_derivatives_fused<NNB, H, kFusedTPB>), dim3(n_blocks), dim3(kFusedTPB), 0, stream, src, n, gv, P, \
+                     partials, counter, out_row, seq)
+  if (search == 1) {
+    if (want_hessian) NDT_LAUNCH_FUSED(26, true); else NDT_LAUNCH_FUSED(26, false);
+  } else if (search == 3) {
+    if (want_hessian) NDT_LAUNCH_FUSED(1, true); else NDT_LAUNCH_FUSED(1, false);
+  } else {
+    if (want_hessian) NDT_LAUNCH_FUSED(7, true); else NDT_LAUNCH_FUSED(7, false);
+  }
+#undef NDT_LAUNCH_FUSED
   return hipGetLastError();
 }
 

@@ -105,6 +105,12 @@ hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsi
 hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
                               bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
                               double* partials, hipStream_t stream);
+// Single launch: derivatives + fixed-order final sum by the last-arriving block + publication of
+// the packed row and `seq` into pinned host memory (out_row).  counter: one zero-initialised u32.
+int fused_blocks(int n);
+hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
+                                    bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                                    unsigned long long seq, hipStream_t stream);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
 // Sums the per-block partials in a fixed order: out[scan][kEvalStride].  seq != 0: `out` is pinned
