@@ -169,6 +169,10 @@ ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums);
  * *n_waves in: capacity, out: waves written. */
 ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* stamps, size_t* n_waves);
 
+/* Diagnostic: round-trip latency of the persistent evaluation server, averaged over n_iter commands:
+ * us[0] = no-op round (protocol only), us[1] = derivatives without Hessian, us[2] = with Hessian. */
+ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, double* us);
+
 /* Host-side scalar pieces of the driver (no GPU needed), exported so that the
  * CPU test-suite can check them against the oracle. */
 void ndt_host_solve6(const double* H /*36 row-major*/, const double* b /*6*/, double* x /*6*/); /* JacobiSVD.solve, :127-129 */

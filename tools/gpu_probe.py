@@ -36,6 +36,7 @@ def main():
     for _ in range(50):
         g.hessian_f64(p)
     print("hessian_f64 %.1f us" % ((time.time() - t0) / 50 * 1e6))
+    print("server round trip:", g.diag_server_roundtrip(p))
     g.diag_stamps(p)
     st = g.diag_stamps(p).astype(np.int64)
     t0 = st[:, 0].min()

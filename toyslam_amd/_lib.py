@@ -77,6 +77,7 @@ SIGNATURES = {
     "ndt_grid_info": (C.c_int, [vp, ip, ip, ip]),
     "ndt_grid_dump": (C.c_int, [vp, C.POINTER(C.c_int64), ip, dp, dp, dp, dp]),
     "ndt_diag_stamps": (C.c_int, [vp, dp, C.POINTER(C.c_ulonglong), szp]),
+    "ndt_diag_server_roundtrip": (C.c_int, [vp, dp, C.c_int, dp]),
     "ndt_selftest_reduce": (C.c_int, [vp, C.c_int, dp]),
     "ndt_profile_enable": (C.c_int, [vp, C.c_int]),
     "ndt_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_longlong), dp, C.c_int]),

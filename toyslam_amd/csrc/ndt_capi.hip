@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -35,25 +37,101 @@ ndt_status fail(ndt_status s, const std::string& msg) {
       return fail(NDT_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(_e));          \
   } while (0)
 
-// grow-only device buffer
+// Caching device allocator: setInputTarget / setInputSource run once per scan in the nodes, and a
+// dozen hipMalloc/hipFree pairs per call (~100 us each) would dominate the GPU time of the grid
+// build.  Freed blocks go to a per-device free list keyed by a rounded size class and are reused;
+// the cache is trimmed when it exceeds kPoolTrimBytes.  All users synchronise their stream before
+// releasing a buffer.
+class DevPool {
+ public:
+  static DevPool& instance() {
+    static DevPool p;
+    return p;
+  }
+  static size_t size_class(size_t bytes) {
+    if (bytes < 512) return 512;
+    size_t p2 = 512;
+    while (p2 * 2 <= bytes) p2 *= 2;
+    const size_t step = p2 / 8;
+    return (bytes + step - 1) / step * step;
+  }
+  hipError_t alloc(size_t bytes, void** out, size_t* got) {
+    const size_t cls = size_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      auto it = free_.find(std::make_pair(dev, cls));
+      if (it != free_.end()) {
+        *out = it->second;
+        *got = cls;
+        cached_ -= cls;
+        free_.erase(it);
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {  // retry once with an empty cache
+      trim(0);
+      e = hipMalloc(out, cls);
+    }
+    *got = cls;
+    return e;
+  }
+  void release(void* p, size_t cls) {
+    if (!p) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      free_.insert(std::make_pair(std::make_pair(dev, cls), p));
+      cached_ += cls;
+    }
+    if (cached_ > kPoolTrimBytes) trim(kPoolTrimBytes / 2);
+  }
+  void trim(size_t keep) {
+    std::lock_guard<std::mutex> g(m_);
+    for (auto it = free_.begin(); it != free_.end() && cached_ > keep;) {
+      (void)hipFree(it->second);
+      cached_ -= it->first.second;
+      it = free_.erase(it);
+    }
+  }
+
+ private:
+  static constexpr size_t kPoolTrimBytes = size_t(16) << 30;
+  std::mutex m_;
+  std::multimap<std::pair<int, size_t>, void*> free_;
+  size_t cached_ = 0;
+};
+
+// grow-only device buffer on top of the pool
 template <class T>
 struct DevBuf {
   T* p = nullptr;
-  size_t cap = 0;
+  size_t cap = 0;        // elements the caller may use
+  size_t cls_bytes = 0;  // pool size class actually held
   ~DevBuf() { release(); }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) DevPool::instance().release(p, cls_bytes);
     p = nullptr;
     cap = 0;
+    cls_bytes = 0;
   }
   hipError_t reserve(size_t n) {
-    if (n <= cap) return hipSuccess;
+    if (n <= cap && p) return hipSuccess;
     release();
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
-    if (e == hipSuccess) cap = n;
+    void* q = nullptr;
+    size_t got = 0;
+    hipError_t e = DevPool::instance().alloc(std::max<size_t>(n, 1) * sizeof(T), &q, &got);
+    if (e == hipSuccess) {
+      p = static_cast<T*>(q);
+      cls_bytes = got;
+      cap = got / sizeof(T);
+    }
     return e;
   }
 };
@@ -123,6 +201,12 @@ struct ndt_context {
   int n_evals = 0, n_hess = 0;
   double mean_neighbors = 0;
   size_t out_n = 0;
+  // persistent evaluation server (single-scan align)
+  bool server_running = false;
+  void* server_host_mb = nullptr;  // pinned command mailbox
+  DevBuf<unsigned char> server_dev_mb;
+  DevBuf<unsigned> server_counter;
+  int cu_count = 0;
   // live kernel timing (HIP events on `stream`)
   bool profiling = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -135,6 +219,7 @@ struct ndt_context {
 
   ~ndt_context() {
     if (host_result) (void)hipHostFree(host_result);
+    if (server_host_mb) (void)hipHostFree(server_host_mb);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (stream) (void)hipStreamDestroy(stream);
@@ -163,6 +248,7 @@ ndt_status ensure_device(ndt_context* h) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(NDT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->cu_count = prop.multiProcessorCount;
   h->device_ready = true;
   return NDT_OK;
 }
@@ -533,6 +619,77 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   return NDT_OK;
 }
 
+// ---- persistent evaluation server (see ndt_kernels.hip) -----------------------------------------
+bool server_enabled() {
+  static const bool on = [] { const char* v = getenv("NDT_PERSISTENT"); return v ? atoi(v) != 0 : true; }();
+  return on;
+}
+
+ndt_status server_stop(ndt_context* h) {
+  if (!h->server_running) return NDT_OK;
+  ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdExit, nullptr);
+  h->server_running = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+
+ndt_status server_start(ndt_context* h) {
+  if (h->server_running) return NDT_OK;
+  const int n = h->source->k2_n();
+  if (!h->server_host_mb) {
+    HIP_TRY(hipHostMalloc(&h->server_host_mb, ndt::server_mailbox_bytes(), hipHostMallocDefault));
+    ndt::server_reset_mailbox(h->server_host_mb);
+  }
+  if (!h->server_dev_mb.p) {
+    HIP_TRY(h->server_dev_mb.reserve(ndt::server_mailbox_bytes()));
+    HIP_TRY(hipMemsetAsync(h->server_dev_mb.p, 0, ndt::server_mailbox_bytes(), h->stream));
+  }
+  HIP_TRY(h->server_counter.reserve(1));
+  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, sizeof(unsigned), h->stream));
+  // one 512-thread block per CU at most: every block must be resident for the round to complete
+  int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + 511) / 512));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
+  const unsigned long long idle_ticks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
+  HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, h->server_dev_mb.p,
+                                  nblk, h->partials.p, h->server_counter.p, h->host_result, h->eval_seq + 1, idle_ticks,
+                                  h->stream));
+  h->server_running = true;
+  return NDT_OK;
+}
+
+// one evaluation through the running server; *served = false means the server had given up
+// (idle time-out) and the caller must use the launch path
+ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::EvalResult& res,
+                           double* nn_total, bool* served) {
+  *served = false;
+  ndt::EvalParams P;
+  fill_eval_params(rq, gs, P);
+  const unsigned long long seq = ++h->eval_seq;
+  ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), &P);
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3FFF) == 0) {
+      if (ndt::server_dead_word(h->server_host_mb) != 0 || hipStreamQuery(h->stream) != hipErrorNotReady) {
+        // the server left (idle time-out or error): drain and let the caller relaunch
+        h->server_running = false;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        ndt::server_reset_mailbox(h->server_host_mb);
+        return NDT_OK;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        return fail(NDT_ERR_HIP, "timed out waiting for the evaluation server");
+    }
+  }
+  unpack_row(h->host_result, rq.kind != ndt::EVAL_NO_HESSIAN, res, nn_total);
+  *served = true;
+  return NDT_OK;
+}
+
 ndt::SolverParams solver_params(const ndt_context* h) {
   ndt::SolverParams sp;
   sp.resolution = h->resolution;
@@ -592,7 +749,10 @@ ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
 
 void ndt_destroy(ndt_handle h) {
   if (!h) return;
-  if (h->device_ready) (void)hipSetDevice(h->device);
+  if (h->device_ready) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);  // nothing of this handle may still be running when its buffers return to the pool
+  }
   delete h;
 }
 
@@ -666,17 +826,38 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   ndt::ScanSolver solver;
   solver.start(guess, h->source->n, solver_params(h));
   double nn = 0;
+  const ndt::Gauss gs_align = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  struct ServerGuard {  // whatever path leaves align, the server is told to exit
+    ndt_context* c;
+    ~ServerGuard() { if (c->server_running) (void)server_stop(c); }
+  } server_guard{h};
+  const bool use_server = server_enabled() && !h->profiling && !h->allreduce && ndt::derivative_variant() == 0 &&
+                          h->source->k2_n() > 0 && !h->grid->empty;
   while (!solver.done()) {
     ndt::EvalResult r;
     double nn_step = 0;
     const bool counts_neighbors = solver.request().kind != ndt::EVAL_HESSIAN_F64;
-    s = evaluate_single(h, solver.request(), r, &nn_step);
-    if (s) return s;
+    bool served = false;
+    if (use_server && counts_neighbors) {
+      s = server_start(h);
+      if (s) return s;
+      s = server_evaluate(h, solver.request(), gs_align, r, &nn_step, &served);
+      if (s) return s;
+    } else if (h->server_running) {
+      s = server_stop(h);  // the f64 Hessian runs as an ordinary launch
+      if (s) return s;
+    }
+    if (!served) {
+      s = evaluate_single(h, solver.request(), r, &nn_step);
+      if (s) return s;
+    }
     if (counts_neighbors) nn = nn_step;
     const auto ts0 = std::chrono::steady_clock::now();
     solver.feed(r);
     h->t_solver += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
   }
+  s = server_stop(h);
+  if (s) return s;
   static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   if (timing) {
     std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus (per align)\n", solver.n_evals + solver.n_hess,
@@ -978,6 +1159,36 @@ ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* st
   HIP_TRY(hipStreamSynchronize(h->stream));
   *n_waves = waves;
   return NDT_OK;
+}
+
+ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, double* us) {
+  if (!h || !p || !us || n_iter <= 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  if (h->source->k2_n() == 0 || h->grid->empty) return fail(NDT_ERR_INVALID, "empty inputs");
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  ndt::EvalRequest rq;
+  std::memcpy(rq.p, p, sizeof(rq.p));
+  ndt::pose_to_matrix(p, rq.T);
+  s = server_start(h);
+  if (s) return s;
+  const int kinds[3] = {3, 1, 0};
+  for (int v = 0; v < 3; v++) {
+    rq.kind = static_cast<ndt::EvalKind>(kinds[v]);
+    double total = 0;
+    for (int it = 0; it < n_iter + 5; it++) {
+      ndt::EvalResult r;
+      bool served = false;
+      const auto t0 = std::chrono::steady_clock::now();
+      s = server_evaluate(h, rq, gs, r, nullptr, &served);
+      const auto t1 = std::chrono::steady_clock::now();
+      if (s) { (void)server_stop(h); return s; }
+      if (!served) { (void)server_stop(h); return fail(NDT_ERR_HIP, "server stopped serving"); }
+      if (it >= 5) total += std::chrono::duration<double>(t1 - t0).count();
+    }
+    us[v] = total / n_iter * 1e6;
+  }
+  return server_stop(h);
 }
 
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums) {

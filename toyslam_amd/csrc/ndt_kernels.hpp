@@ -111,6 +111,15 @@ int fused_blocks(int n);
 hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
                                     bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
                                     unsigned long long seq, hipStream_t stream);
+// Persistent evaluation server (one launch per align): see ndt_kernels.hip.
+constexpr int kServerCmdExit = 0x7fffffff;
+size_t server_mailbox_bytes();
+void server_reset_mailbox(void* host_mailbox);
+void server_post(void* host_mailbox, unsigned long long seq, int kind, const EvalParams* P);
+unsigned long long server_dead_word(const void* host_mailbox);
+hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
+                              void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
 // Sums the per-block partials in a fixed order: out[scan][kEvalStride].  seq != 0: `out` is pinned

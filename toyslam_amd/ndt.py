@@ -217,6 +217,12 @@ class NormalDistributionsTransform:
         check(self._L.ndt_diag_stamps(self._h, _d(p), st.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(n)))
         return st[:n.value]
 
+    def diag_server_roundtrip(self, p, n_iter=200):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        us = np.zeros(3)
+        check(self._L.ndt_diag_server_roundtrip(self._h, _d(p), n_iter, _d(us)))
+        return dict(nop_us=us[0], no_hessian_us=us[1], with_hessian_us=us[2])
+
     def selftest_reduce(self, n_blocks=3):
         out = np.zeros((n_blocks, _lib.EVAL_STRIDE))
         check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
