@@ -206,6 +206,8 @@ struct ndt_context {
   void* server_host_mb = nullptr;  // pinned command mailbox
   DevBuf<unsigned char> server_dev_mb;
   DevBuf<unsigned> server_counter;
+  DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
+  bool server_want_dbg = false;
   int cu_count = 0;
   // live kernel timing (HIP events on `stream`)
   bool profiling = false;
@@ -644,8 +646,8 @@ ndt_status server_start(ndt_context* h) {
     HIP_TRY(h->server_dev_mb.reserve(ndt::server_mailbox_bytes()));
     HIP_TRY(hipMemsetAsync(h->server_dev_mb.p, 0, ndt::server_mailbox_bytes(), h->stream));
   }
-  HIP_TRY(h->server_counter.reserve(1));
-  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, sizeof(unsigned), h->stream));
+  HIP_TRY(h->server_counter.reserve(32 * 9));  // top counter + 8 shard counters, one per 128-B line
+  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * 9 * sizeof(unsigned), h->stream));
   // one 512-thread block per CU at most: every block must be resident for the round to complete
   int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + 511) / 512));
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
@@ -653,7 +655,7 @@ ndt_status server_start(ndt_context* h) {
   const unsigned long long idle_ticks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
   HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, h->server_dev_mb.p,
                                   nblk, h->partials.p, h->server_counter.p, h->host_result, h->eval_seq + 1, idle_ticks,
-                                  h->stream));
+                                  h->stream, h->server_want_dbg ? h->server_dbg.p : nullptr));
   h->server_running = true;
   return NDT_OK;
 }
@@ -1170,7 +1172,11 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   ndt::EvalRequest rq;
   std::memcpy(rq.p, p, sizeof(rq.p));
   ndt::pose_to_matrix(p, rq.T);
+  HIP_TRY(h->server_dbg.reserve(8 + 2 * 1024));
+  HIP_TRY(hipMemsetAsync(h->server_dbg.p, 0, (8 + 2 * 1024) * sizeof(unsigned long long), h->stream));
+  h->server_want_dbg = true;
   s = server_start(h);
+  h->server_want_dbg = false;
   if (s) return s;
   const int kinds[3] = {3, 1, 0};
   for (int v = 0; v < 3; v++) {
@@ -1188,7 +1194,22 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
     }
     us[v] = total / n_iter * 1e6;
   }
-  return server_stop(h);
+  s = server_stop(h);
+  if (s) return s;
+  {  // device-side stamps of the LAST round (with Hessian), s_memrealtime ticks of 10 ns
+    std::vector<unsigned long long> d(8 + 2 * 1024);
+    HIP_TRY(hipMemcpy(d.data(), h->server_dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (h->source->k2_n() + 511) / 512));
+    unsigned long long got_min = ~0ull, got_max = 0, tk_min = ~0ull, tk_max = 0;
+    for (int b = 0; b < nblk; b++) {
+      got_min = std::min(got_min, d[8 + 2 * b]); got_max = std::max(got_max, d[8 + 2 * b]);
+      tk_min = std::min(tk_min, d[9 + 2 * b]); tk_max = std::max(tk_max, d[9 + 2 * b]);
+    }
+    auto us_of = [&](unsigned long long t) { return (static_cast<double>(t) - static_cast<double>(d[0])) * 0.01; };
+    std::fprintf(stderr, "[server stamps, us after the relay saw the command] relayed %.2f | blocks have params %.2f..%.2f | tickets %.2f..%.2f | final sum starts %.2f | published %.2f  (%d blocks)\n",
+                 us_of(d[1]), us_of(got_min), us_of(got_max), us_of(tk_min), us_of(tk_max), us_of(d[2]), us_of(d[3]), nblk);
+  }
+  return NDT_OK;
 }
 
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums) {

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
                                                             ServerMailbox* host_mb, ServerMailbox* dev_mb,
                                                             double* __restrict__ partials, unsigned* __restrict__ counter,
                                                             double* __restrict__ out_row, unsigned long long first_seq,
-                                                            unsigned long long idle_ticks) {
+                                                            unsigned long long idle_ticks, unsigned long long* dbg) {
   constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
   __shared__ double lds[kWaves * 32];
   __shared__ double lds2[kParts * kEvalStride];
@@ -1128,6 +1128,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
         if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) break;
         __builtin_amdgcn_s_sleep(1);
       }
+      const unsigned long long dbg_seen = __builtin_amdgcn_s_memrealtime();
       unsigned w0 = 0, w1 = 0;
       if (got) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       if (lane == 0) __hip_atomic_store(&dev_mb->kind, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(&dev_mb->seq, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg && lane == 0 && kind != kCmdExit) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
     }
     // ---- every block: wait for the device mailbox ----
     if (wave == 0) {
@@ -1166,6 +1168,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
         if (lane == 0) kind = __hip_atomic_load(&dev_mb->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (lane == 0) s_kind = kind;
+      if (dbg && lane == 0 && kind != kCmdExit) dbg[8 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its parameters
     }
     __syncthreads();
     const int kind = s_kind;
@@ -1194,13 +1197,28 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Two-level fan-in: 8 shard counters (blocks b and b+8 usually share an XCD; only speed
+        // depends on that) and one top counter.  ~200 returning atomics on ONE word serialise at
+        // ~13 ns each (measured 2.5-3 us of arrival skew); sharded, the longest chain is ~25+8.
+        // Counters live 128 B apart and are never reset inside a launch.
         const unsigned round = static_cast<unsigned>(expect - first_seq);
-        s_last = (ticket == (round + 1u) * gridDim.x - 1u) ? 1 : 0;  // the counter is never reset inside a launch
+        const unsigned shard = blockIdx.x & 7u;
+        const unsigned in_shard = (gridDim.x + 7u - shard) / 8u;  // blocks with this residue
+        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (t1 == (round + 1u) * in_shard - 1u) {
+          const unsigned n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+          const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = (t2 == (round + 1u) * n_shards - 1u) ? 1 : 0;
+        }
+        s_last = last;
+        if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
       }
     }
     __syncthreads();
     if (s_last) {
+      if (dbg && threadIdx.x == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
+        __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
       const int n_blocks = gridDim.x;
       double v = 0.0;
@@ -1221,6 +1239,8 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
 #pragma unroll
         for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
         publish_row(out_row, t, expect);
+        if (dbg && threadIdx.x == 0)  // published
+          __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
@@ -1581,18 +1601,19 @@ void server_reset_mailbox(void* host_mailbox) { std::memset(host_mailbox, 0, siz
 
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
-                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream) {
+                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream,
+                              unsigned long long* dbg) {
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks);
+                       out_row, first_seq, idle_ticks, dbg);
   else if (search == 3)
     hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks);
+                       out_row, first_seq, idle_ticks, dbg);
   else
     hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks);
+                       out_row, first_seq, idle_ticks, dbg);
   return hipGetLastError();
 }
 

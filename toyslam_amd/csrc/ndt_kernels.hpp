@@ -119,7 +119,8 @@ void server_post(void* host_mailbox, unsigned long long seq, int kind, const Eva
 unsigned long long server_dead_word(const void* host_mailbox);
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
-                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream);
+                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream,
+                              unsigned long long* dbg = nullptr);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
 // Sums the per-block partials in a fixed order: out[scan][kEvalStride].  seq != 0: `out` is pinned
