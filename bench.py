@@ -163,12 +163,28 @@ def main():
             avg_s = ms * 1e-3 / max(n_launch, 1)
             bytes_per_launch = algorithmic_bytes_per_eval(N_SOURCE, hbar)
             achieved = bytes_per_launch / avg_s / 1e9
+            # HBM traffic of the same kernel from the committed PMC passes of this command
+            # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; unit KB; gfx950
+            # correction 2 x FETCH_SIZE, MI355X_MICROARCH.md "HBM") -- not collectable live here.
+            traffic, traffic_src = None, None
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_profile_summary.json")))
+                for name, c in prof["pmc"].items():
+                    if "k_derivatives_fused<7, true" in name:
+                        traffic = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
+                        traffic_src = "profiles/r01_profile_summary.json"
+            except Exception:
+                pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "k_derivatives<DIRECT7, hessian>", "avg_kernel_us": avg_s * 1e6,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "kernel": "k_derivatives_fused<DIRECT7, hessian> (derivatives + final reduce + publish)",
+                               "avg_kernel_us": avg_s * 1e6,
                                "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                                "mean_neighbors": hbar,
-                               "how": "hipEvent pairs on the library stream around each launch, separate pass"}
+                               "how": "hipEvent pairs on the library stream around each launch, in a second pass of the "
+                                      "same steps with one launch per evaluation; the timed region itself runs the "
+                                      "same device code inside one persistent launch per registration (k_eval_server)"}
+            out["us_per_evaluation_in_timed_region"] = dt / args.steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
             out["registration_algorithmic_GBs"] = st["n_evals"] * bytes_per_launch / (dt / args.steps) / 1e9
             # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
             if world == 1 and not args.no_cpu_baseline:

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <cfloat>
 #include <chrono>
 #include <cstdlib>
@@ -188,6 +191,7 @@ struct ndt_context {
   DevBuf<unsigned> ticket;  // zero between launches (reset by the last block of the fused kernel)
   DevBuf<double> batch_out;
   DevBuf<ndt::ScanDesc> descs;
+  DevBuf<int> batch_active;  // per kind: indices of the scans that want it this step
   DevBuf<float4> out_cloud;
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
@@ -564,7 +568,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   if (rq.kind == ndt::EVAL_HESSIAN_F64) {
     ndt::Hess64Params P;
     fill_h64_params(rq, gs, P);
-    HIP_TRY(ndt::launch_hessian64(src, n, gv, P, h->search, nullptr, 1, nblk, h->partials.p, h->stream));
+    HIP_TRY(ndt::launch_hessian64(src, n, gv, P, h->search, nullptr, nullptr, 1, nblk, nblk, h->partials.p, h->stream));
   } else {
     ndt::EvalParams P;
     fill_eval_params(rq, gs, P);
@@ -573,7 +577,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
       HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, h->partials.p,
                                             h->ticket.p, h->host_result, seq, h->stream));
     } else {
-      HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, 1, rq.kind, nblk,
+      HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, nullptr, 1, nblk, nblk,
                                       h->partials.p, h->stream));
     }
   }
@@ -701,6 +705,62 @@ ndt::SolverParams solver_params(const ndt_context* h) {
   sp.max_iter = h->max_iter;
   return sp;
 }
+
+}  // namespace
+
+namespace {
+// Small spinning worker pool for the per-step host work of a lock-step batch (one Newton /
+// More-Thuente state machine per scan: 6x6 SVD solves, pose -> matrix, angle tables).  Threads
+// live for one ndt_align_batch call.
+class StepPool {
+ public:
+  explicit StepPool(int n_threads) : n_(std::max(1, n_threads)) {
+    for (int t = 1; t < n_; t++) workers_.emplace_back([this, t] { loop(t); });
+  }
+  ~StepPool() {
+    stop_.store(true, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    for (auto& w : workers_) w.join();
+  }
+  // runs fn(i) for i in [0, count), statically partitioned; returns when all are done
+  template <class F>
+  void run(size_t count, const F& fn) {
+    if (n_ == 1 || count < 32) {
+      for (size_t i = 0; i < count; i++) fn(i);
+      return;
+    }
+    job_ = [&](int t) {
+      const size_t lo = count * t / n_, hi = count * (t + 1) / n_;
+      for (size_t i = lo; i < hi; i++) fn(i);
+    };
+    pending_.store(n_ - 1, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    job_(0);
+    while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+
+ private:
+  void loop(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      unsigned spins = 0;
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        __builtin_ia32_pause();
+        if (++spins > 20000) { std::this_thread::yield(); spins = 0; }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_.load(std::memory_order_acquire)) return;
+      job_(t);
+      pending_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  std::function<void(int)> job_;
+  std::atomic<unsigned long long> gen_{0};
+  std::atomic<int> pending_{0};
+  std::atomic<bool> stop_{false};
+};
 
 }  // namespace
 
@@ -973,37 +1033,55 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     descs[k].pad = 0;
     max_n = std::max(max_n, cnt);
   }
-  const int nblk = std::max(1, std::min(ndt::derivative_blocks(static_cast<int>(max_n), h->search),
-                                        std::max(8, 4096 / static_cast<int>(n_scans))));
-  HIP_TRY(h->partials.reserve(n_scans * nblk * ndt::kEvalStride));
+  // rows of partials reserved per scan; the blocks actually used per scan follow the number of
+  // scans that want the same kind of evaluation in a step (few active scans -> more blocks each)
+  const int max_blocks = ndt::derivative_blocks(static_cast<int>(max_n), h->search);
+  constexpr int kBlockBudget = 4096;
+  HIP_TRY(h->partials.reserve(n_scans * max_blocks * ndt::kEvalStride));
   HIP_TRY(h->batch_out.reserve(n_scans * ndt::kEvalStride));
   HIP_TRY(h->descs.reserve(n_scans));
+  HIP_TRY(h->batch_active.reserve(3 * n_scans));
   const ndt::GridView gv = h->grid->view();
   const bool degenerate = h->grid->empty;
+  std::vector<int> active(3 * n_scans);
+  static const int n_host_threads = [] {
+    const char* v = getenv("NDT_HOST_THREADS");
+    if (v) return std::max(1, atoi(v));
+    return static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
+  }();
+  StepPool pool(n_scans >= 32 ? n_host_threads : 1);
   for (;;) {
-    bool any[3] = {false, false, false};
-    size_t active = 0;
+    int n_act[3] = {0, 0, 0};
     for (size_t k = 0; k < n_scans; k++) {
+      if (solvers[k].done()) {
+        descs[k].kind = ndt::EVAL_NONE;
+        continue;
+      }
+      const int kind = solvers[k].request().kind;
+      descs[k].kind = kind;
+      active[kind * n_scans + n_act[kind]++] = static_cast<int>(k);
+    }
+    if (n_act[0] + n_act[1] + n_act[2] == 0) break;
+    int nblk_kind[3];
+    for (int c = 0; c < 3; c++) nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / std::max(1, n_act[c])));
+    pool.run(n_scans, [&](size_t k) {  // per-scan parameter tables (sin/cos, pose -> matrix)
+      if (descs[k].kind == ndt::EVAL_NONE) return;
       const ndt::EvalRequest& rq = solvers[k].request();
-      descs[k].kind = solvers[k].done() ? ndt::EVAL_NONE : rq.kind;
-      if (solvers[k].done()) continue;
-      active++;
-      any[rq.kind] = true;
+      descs[k].pad = nblk_kind[descs[k].kind];
       if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, descs[k].P64);
       else fill_eval_params(rq, gs, descs[k].P);
-    }
-    if (!active) break;
+    });
     if (degenerate) {
       std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
     } else {
       HIP_TRY(hipMemcpyAsync(h->descs.p, descs.data(), n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->batch_active.p, active.data(), 3 * n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
-      if (any[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, static_cast<int>(n_scans), 0, nblk, h->partials.p, h->stream));
-      if (any[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, static_cast<int>(n_scans), 1, nblk, h->partials.p, h->stream));
-      if (any[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, static_cast<int>(n_scans), nblk, h->partials.p, h->stream));
-      HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, n_scans * ndt::kEvalStride * sizeof(double), h->stream));
-      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
+      if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, h->batch_active.p, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));
+      if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, h->batch_active.p + n_scans, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
+      if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, h->batch_active.p + 2 * n_scans, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
+      HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
       if (h->allreduce && h->allreduce_on_device) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->allreduce(h->batch_out.p, n_scans * ndt::kEvalStride, 1, h->allreduce_user))
@@ -1016,12 +1094,12 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
           return fail(NDT_ERR_COMM, "allreduce callback failed");
       }
     }
-    for (size_t k = 0; k < n_scans; k++) {
-      if (descs[k].kind == ndt::EVAL_NONE) continue;
+    pool.run(n_scans, [&](size_t k) {  // Newton / More-Thuente step of every live scan
+      if (descs[k].kind == ndt::EVAL_NONE) return;
       ndt::EvalResult r;
       unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, nullptr);
       solvers[k].feed(r);
-    }
+    });
   }
   for (size_t k = 0; k < n_scans; k++) {
     if (final_T) std::memcpy(final_T + 16 * k, solvers[k].final_T, 16 * sizeof(float));

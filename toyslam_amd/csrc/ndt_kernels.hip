@@ -963,29 +963,30 @@ __device__ __forceinline__ void derivatives_body_split7(const float4* __restrict
 
 template <int NNB, bool WANT_H, bool BATCH, int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
-                                                        const ScanDesc* __restrict__ descs, int kind,
-                                                        double* __restrict__ partials) {
+                                                        const ScanDesc* __restrict__ descs, const int* __restrict__ active,
+                                                        int max_blocks, double* __restrict__ partials) {
   __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ EvalParams sP;
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
   const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-  double* out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * kEvalStride;
   if (BATCH) {
-    const ScanDesc* dsc = descs + blockIdx.y;
-    if (dsc->kind != kind) return;  // block-uniform
+    // grid.y walks the scans that asked for THIS kind of evaluation in this step
+    const int scan = active[blockIdx.y];
+    const ScanDesc* dsc = descs + scan;
     const int* sp = reinterpret_cast<const int*>(&dsc->P);
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
     __syncthreads();
     if (VARIANT == 1) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
     else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
   } else {
     if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
     else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, P, first, stride, acc);
+    block_reduce_store<kNumAcc>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
   }
-  block_reduce_store<kNumAcc>(acc, out, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1252,59 +1253,64 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
 // computeHessian / updateHessian, all f64 (ndt_omp_impl.hpp:540-645, 443-481)
 // acc layout identical to k_derivatives (only [7..27] are written).
 // ---------------------------------------------------------------------------
+// Factored like the f32 path (see accumulate_neighbor_factored), everything in f64:
+//   per neighbour  xe += e xc ,  A += e (C - d2 xc xc^T)      with xc = C x'
+//   per point      H  = J^T A J + [xe . HE_ij]                 (f64 angle vectors, -sy in d1)
+struct PointAcc64 {
+  double xe0, xe1, xe2;
+  double a00, a01, a02, a11, a12, a22;
+};
+
 template <class P>
-__device__ __forceinline__ void hessian64_neighbor(double (&acc)[kNumAcc], const P& prm, double px, double py, double pz,
-                                                   double x0, double x1, double x2, const double C[3][3]) {
+__device__ __forceinline__ void finish_point64(double (&acc)[kNumAcc], const PointAcc64& pa, const P& prm, double px,
+                                               double py, double pz) {
   auto dot = [](const double a[3], double b0, double b1, double b2) { return (a[0] * b0 + a[1] * b1) + a[2] * b2; };
-  double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
-  J[1][3] = dot(prm.jd[0], px, py, pz); J[2][3] = dot(prm.jd[1], px, py, pz);
-  J[0][4] = dot(prm.jd[2], px, py, pz); J[1][4] = dot(prm.jd[3], px, py, pz); J[2][4] = dot(prm.jd[4], px, py, pz);
-  J[0][5] = dot(prm.jd[5], px, py, pz); J[1][5] = dot(prm.jd[6], px, py, pz); J[2][5] = dot(prm.jd[7], px, py, pz);
-  double xh[15];
+  double j[8], h[15];
 #pragma unroll
-  for (int r = 0; r < 15; r++) xh[r] = dot(prm.hd[r], px, py, pz);
-  const double xt[3] = {x0, x1, x2};
-  double Cx[3];
-  for (int i = 0; i < 3; i++) Cx[i] = (C[i][0] * x0 + C[i][1] * x1) + C[i][2] * x2;
-  double e = prm.d2 * exp(-prm.d2 * ((x0 * Cx[0] + x1 * Cx[1]) + x2 * Cx[2]) / 2);  // :622
-  if (e > 1 || e < 0 || e != e) return;                                             // :625-626
-  e *= prm.d1;
-  // H_E vectors a..f (blocks (3,3)=a (3,4)=b (3,5)=c (4,4)=d (4,5)=e (5,5)=f)
-  const double hv[6][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]},
-                           {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
-  const int hsel[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-  double CJ[3][6], xCJ[6];
-  for (int k = 0; k < 6; k++) {
-    for (int i = 0; i < 3; i++) CJ[i][k] = (C[i][0] * J[0][k] + C[i][1] * J[1][k]) + C[i][2] * J[2][k];
-    xCJ[k] = (xt[0] * CJ[0][k] + xt[1] * CJ[1][k]) + xt[2] * CJ[2][k];
-  }
+  for (int r = 0; r < 8; r++) j[r] = dot(prm.jd[r], px, py, pz);
+#pragma unroll
+  for (int r = 0; r < 15; r++) h[r] = dot(prm.hd[r], px, py, pz);
+  const double B[3][3] = {{0.0, j[2], j[5]}, {j[0], j[3], j[6]}, {j[1], j[4], j[7]}};
+  const double A[3][3] = {{pa.a00, pa.a01, pa.a02}, {pa.a01, pa.a11, pa.a12}, {pa.a02, pa.a12, pa.a22}};
+  double AB[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) AB[r][c] = (A[r][0] * B[0][c] + A[r][1] * B[1][c]) + A[r][2] * B[2][c];
+  const double xa = pa.xe1 * h[0] + pa.xe2 * h[1];
+  const double xb = pa.xe1 * h[2] + pa.xe2 * h[3];
+  const double xcc = pa.xe1 * h[4] + pa.xe2 * h[5];
+  const double xd = (pa.xe0 * h[6] + pa.xe1 * h[7]) + pa.xe2 * h[8];
+  const double xe = (pa.xe0 * h[9] + pa.xe1 * h[10]) + pa.xe2 * h[11];
+  const double xf = (pa.xe0 * h[12] + pa.xe1 * h[13]) + pa.xe2 * h[14];
+  const double X[3][3] = {{xa, xb, xcc}, {xb, xd, xe}, {xcc, xe, xf}};
   int idx = 7;
-  for (int i = 0; i < 6; i++)
-    for (int jj = i; jj < 6; jj++) {
-      double xCH = 0.0;
-      if (i >= 3) {
-        const double* hb = hv[hsel[i - 3][jj - 3]];
-        double Ch[3];
-        for (int r = 0; r < 3; r++) Ch[r] = (C[r][0] * hb[0] + C[r][1] * hb[1]) + C[r][2] * hb[2];
-        xCH = (xt[0] * Ch[0] + xt[1] * Ch[1]) + xt[2] * Ch[2];
-      }
-      const double jcj = (J[0][jj] * CJ[0][i] + J[1][jj] * CJ[1][i]) + J[2][jj] * CJ[2][i];
-      acc[idx++] += e * (-prm.d2 * xCJ[i] * xCJ[jj] + xCH + jcj);  // :639-641
-    }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int c = i; c < 3; c++) acc[idx++] += A[i][c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) acc[idx++] += AB[i][c];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++) acc[idx++] += ((B[0][a] * AB[0][b] + B[1][a] * AB[1][b]) + B[2][a] * AB[2][b]) + X[a][b];
 }
 
 template <int NNB, bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__ src, int n, GridView gv, Hess64Params P,
-                                                      const ScanDesc* __restrict__ descs, double* __restrict__ partials) {
+                                                      const ScanDesc* __restrict__ descs, const int* __restrict__ active,
+                                                      int max_blocks, double* __restrict__ partials) {
   __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ Hess64Params sP;
   double acc[kNumAcc];
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  double* out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * kEvalStride;
   const Hess64Params* prm = &P;
+  int scan = 0;
   if (BATCH) {
-    const ScanDesc* dsc = descs + blockIdx.y;
-    if (dsc->kind != 2) return;
+    scan = active[blockIdx.y];
+    const ScanDesc* dsc = descs + scan;
     const int* sp = reinterpret_cast<const int*>(&dsc->P64);
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(Hess64Params) / 4); t += kBlock) dp[t] = sp[t];
@@ -1313,6 +1319,7 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     n = dsc->count;
     prm = &sP;
   }
+  double* out = partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 pt = src[i];
     float tx, ty, tz;
@@ -1320,17 +1327,30 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
+    PointAcc64 pa = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
       const int rix = probe(gv, vi, vj, vk, dx, dy, dz);
       if (rix < 0) continue;
       const RecRegs r = load_rec(gv.recs, rix);
-      // f64 path reads the f64 icov; the record keeps its f32 rounding
-      const double C[3][3] = {{r.c00, r.c01, r.c02}, {r.c01, r.c11, r.c12}, {r.c02, r.c12, r.c22}};
-      hessian64_neighbor(acc, *prm, pt.x, pt.y, pt.z, static_cast<double>(tx) - r.mx, static_cast<double>(ty) - r.my,
-                         static_cast<double>(tz) - r.mz, C);
+      // the record keeps icov in its f32 rounding
+      const double c00 = r.c00, c01 = r.c01, c02 = r.c02, c11 = r.c11, c12 = r.c12, c22 = r.c22;
+      const double x0 = static_cast<double>(tx) - r.mx, x1 = static_cast<double>(ty) - r.my, x2 = static_cast<double>(tz) - r.mz;
+      const double xc0 = (c00 * x0 + c01 * x1) + c02 * x2;
+      const double xc1 = (c01 * x0 + c11 * x1) + c12 * x2;
+      const double xc2 = (c02 * x0 + c12 * x1) + c22 * x2;
+      double e = prm->d2 * exp(-prm->d2 * ((x0 * xc0 + x1 * xc1) + x2 * xc2) / 2);  // :622
+      if (e > 1 || e < 0 || e != e) continue;                                        // :625-626
+      e *= prm->d1;
+      any = true;
+      pa.xe0 += e * xc0; pa.xe1 += e * xc1; pa.xe2 += e * xc2;
+      const double t0 = (-prm->d2 * e) * xc0, t1 = (-prm->d2 * e) * xc1, t2 = (-prm->d2 * e) * xc2;
+      pa.a00 += e * c00 + t0 * xc0; pa.a01 += e * c01 + t0 * xc1; pa.a02 += e * c02 + t0 * xc2;
+      pa.a11 += e * c11 + t1 * xc1; pa.a12 += e * c12 + t1 * xc2; pa.a22 += e * c22 + t2 * xc2;
     }
+    if (any) finish_point64(acc, pa, *prm, pt.x, pt.y, pt.z);
   }
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
@@ -1339,25 +1359,31 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
 // fixed-order reduction of the per-block partials
 // ---------------------------------------------------------------------------
 constexpr int kReduceThreads = 1024;
+// n_blocks: rows per scan (single scan) or row stride per scan (batch, where descs[scan].pad holds
+// the number of rows actually written this step)
 __global__ __launch_bounds__(kReduceThreads) void k_reduce(const double* __restrict__ partials, int n_blocks,
                                                            const ScanDesc* __restrict__ descs, double* __restrict__ out,
                                                            unsigned long long seq) {
   const int scan = blockIdx.x;
-  if (descs && descs[scan].kind == 3) return;  // EVAL_NONE: row left untouched
+  int rows = n_blocks;
+  if (descs) {
+    if (descs[scan].kind == 3) return;  // EVAL_NONE: row left untouched
+    rows = descs[scan].pad;
+  }
   constexpr int kParts = kReduceThreads / kEvalStride;  // 32
   const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
   const double* base = partials + static_cast<size_t>(scan) * n_blocks * kEvalStride;
   double v = 0.0;
   if (k < kNumAcc) {
     int b = part;
-    for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {  // 4 independent loads in flight
+    for (; b + 3 * kParts < rows; b += 4 * kParts) {  // 4 independent loads in flight
       const double a0 = base[static_cast<size_t>(b) * kEvalStride + k];
       const double a1 = base[static_cast<size_t>(b + kParts) * kEvalStride + k];
       const double a2 = base[static_cast<size_t>(b + 2 * kParts) * kEvalStride + k];
       const double a3 = base[static_cast<size_t>(b + 3 * kParts) * kEvalStride + k];
       v += a0; v += a1; v += a2; v += a3;
     }
-    for (; b < n_blocks; b += kParts) v += base[static_cast<size_t>(b) * kEvalStride + k];
+    for (; b < rows; b += kParts) v += base[static_cast<size_t>(b) * kEvalStride + k];
   }
   __shared__ double s[kParts][kEvalStride];
   s[part][k] = v;
@@ -1526,36 +1552,34 @@ int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile
 
 template <int NNB, bool WANT_H, int VARIANT>
 static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
-                           int n_scans, int kind, int n_blocks, double* partials, hipStream_t stream) {
+                           const int* active, int n_active, int max_blocks, int n_blocks, double* partials,
+                           hipStream_t stream) {
   if (descs)
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, VARIANT>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src,
-                       n, gv, P, descs, kind, partials);
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, VARIANT>), dim3(n_blocks, n_active), dim3(kBlock), 0, stream, src,
+                       n, gv, P, descs, active, max_blocks, partials);
   else
     hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false, VARIANT>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
-                       gv, P, descs, kind, partials);
+                       gv, P, descs, active, max_blocks, partials);
 }
 
 hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
-                              bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
-                              double* partials, hipStream_t stream) {
+                              bool want_hessian, const ScanDesc* descs, const int* active, int n_active, int max_blocks,
+                              int n_blocks, double* partials, hipStream_t stream) {
   // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
   const int variant = derivative_variant();
+#define NDT_LAUNCH_DERIV(NNB, H, V) launch_deriv_t<NNB, H, V>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream)
   if (search == 1) {
-    if (want_hessian) launch_deriv_t<26, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<26, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) NDT_LAUNCH_DERIV(26, true, 0); else NDT_LAUNCH_DERIV(26, false, 0);
   } else if (search == 3) {
-    if (want_hessian) launch_deriv_t<1, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<1, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) NDT_LAUNCH_DERIV(1, true, 0); else NDT_LAUNCH_DERIV(1, false, 0);
   } else if (variant == 1) {
-    if (want_hessian) launch_deriv_t<7, true, 1>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false, 1>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 1); else NDT_LAUNCH_DERIV(7, false, 1);
   } else if (variant == 2) {
-    if (want_hessian) launch_deriv_t<7, true, 2>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false, 2>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 2); else NDT_LAUNCH_DERIV(7, false, 2);
   } else {
-    if (want_hessian) launch_deriv_t<7, true, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
-    else launch_deriv_t<7, false, 0>(src, n, gv, P, descs, n_scans, kind, n_blocks, partials, stream);
+    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 0); else NDT_LAUNCH_DERIV(7, false, 0);
   }
+#undef NDT_LAUNCH_DERIV
   return hipGetLastError();
 }
 
@@ -1619,20 +1643,22 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
 
 template <int NNB>
 static void launch_h64_t(const float4* src, int n, const GridView& gv, const Hess64Params& P, const ScanDesc* descs,
-                         int n_scans, int n_blocks, double* partials, hipStream_t stream) {
+                         const int* active, int n_active, int max_blocks, int n_blocks, double* partials,
+                         hipStream_t stream) {
   if (descs)
-    hipLaunchKernelGGL((k_hessian64<NNB, true>), dim3(n_blocks, n_scans), dim3(kBlock), 0, stream, src, n, gv, P, descs,
-                       partials);
+    hipLaunchKernelGGL((k_hessian64<NNB, true>), dim3(n_blocks, n_active), dim3(kBlock), 0, stream, src, n, gv, P, descs,
+                       active, max_blocks, partials);
   else
-    hipLaunchKernelGGL((k_hessian64<NNB, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n, gv, P, descs,
-                       partials);
+    hipLaunchKernelGGL((k_hessian64<NNB, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n, gv, P, descs, active,
+                       max_blocks, partials);
 }
 
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
-                            const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream) {
-  if (search == 1) launch_h64_t<26>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
-  else if (search == 3) launch_h64_t<1>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
-  else launch_h64_t<7>(src, n, gv, P, descs, n_scans, n_blocks, partials, stream);
+                            const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
+                            double* partials, hipStream_t stream) {
+  if (search == 1) launch_h64_t<26>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
+  else if (search == 3) launch_h64_t<1>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
+  else launch_h64_t<7>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
   return hipGetLastError();
 }
 

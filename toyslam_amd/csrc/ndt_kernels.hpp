@@ -61,7 +61,7 @@ struct ScanDesc {
   int offset;  // first point of the scan in the concatenated source
   int count;
   int kind;    // ndt::EvalKind of this step (EVAL_NONE = skip)
-  int pad;
+  int pad;     // batch: partial rows written for this scan in this step
   EvalParams P;
   Hess64Params P64;
 };
@@ -99,12 +99,13 @@ hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsi
                            int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
                            FinalizeDump dump, hipStream_t stream);
 
-// K2: derivatives.  search: NDT_DIRECT26/7/1.  Single scan (descs == nullptr,
-// params by value) or batch (grid.y = n_scans, blocks whose desc.kind !=
-// kind are skipped).  partials: [n_scans][n_blocks][kEvalStride].
+// K2: derivatives.  search: NDT_DIRECT26/7/1.  Single scan: descs == nullptr, params by value,
+// partials [n_blocks][kEvalStride].  Batch: grid.y walks active[0..n_active) -- the scans that want
+// THIS kind of evaluation in this step -- with n_blocks blocks each; partial rows of scan s live at
+// [s][max_blocks][kEvalStride] and descs[s].pad tells the reduce how many rows were written.
 hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
-                              bool want_hessian, const ScanDesc* descs, int n_scans, int kind, int n_blocks,
-                              double* partials, hipStream_t stream);
+                              bool want_hessian, const ScanDesc* descs, const int* active, int n_active, int max_blocks,
+                              int n_blocks, double* partials, hipStream_t stream);
 // Single launch: derivatives + fixed-order final sum by the last-arriving block + publication of
 // the packed row and `seq` into pinned host memory (out_row).  counter: one zero-initialised u32.
 int fused_blocks(int n);
@@ -122,7 +123,8 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream,
                               unsigned long long* dbg = nullptr);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
-                            const ScanDesc* descs, int n_scans, int n_blocks, double* partials, hipStream_t stream);
+                            const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
+                            double* partials, hipStream_t stream);
 // Sums the per-block partials in a fixed order: out[scan][kEvalStride].  seq != 0: `out` is pinned
 // host memory polled by the host; slot kEvalStride-1 of each row then receives `seq` (u64) last.
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
