@@ -335,12 +335,13 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   geo.mul[1] = geo.div_b[0];
   geo.mul[2] = geo.div_b[0] * geo.div_b[1];
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
-  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start;
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
   DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
   HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
-  HIP_TRY(ndt::launch_count(d_pts, ni, 0, geo, key.p, cell_count.p, st));
+  HIP_TRY(ndt::launch_count(d_pts, ni, 0, geo, key.p, rank.p, cell_count.p, st));
   const int n_tiles = ndt::scan_tiles(geo.n_cells);
   HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
   HIP_TRY(totals.reserve(4));
@@ -358,7 +359,7 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   HIP_TRY(sorted_idx.reserve(n));
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
-  HIP_TRY(ndt::launch_scatter(key.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
   HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
   HIP_TRY(hipStreamSynchronize(st));
   *n_out = tot[0];
@@ -446,12 +447,13 @@ ndt_status build_grid(ndt_context* h) {
     return fail(NDT_ERR_GRID_OVERFLOW, "voxel grid too large");
 
   // ---- count
-  DevBuf<unsigned> cell_count, block_sums, totals;
+  DevBuf<unsigned> cell_count, block_sums, totals, rank;
   DevBuf<int> key;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
   HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
-  HIP_TRY(ndt::launch_count(h->target->pts.p, n, h->target_dense, geo, key.p, cell_count.p, st));
+  HIP_TRY(ndt::launch_count(h->target->pts.p, n, h->target_dense, geo, key.p, rank.p, cell_count.p, st));
   // ---- scan
   const int n_tiles = ndt::scan_tiles(geo.n_cells);
   HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
@@ -473,7 +475,7 @@ ndt_status build_grid(ndt_context* h) {
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->lut.p, g->leaf_cell.p,
                                  g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
   // ---- scatter + finalize
-  HIP_TRY(ndt::launch_scatter(key.p, n, cell_count.p, g->sorted_idx.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
   HIP_TRY(hipMemsetAsync(totals.p, 0, sizeof(unsigned), st));
   ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,

@@ -222,7 +222,8 @@ __device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, f
 // K1.b  per-cell point count
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts, int n, int dense, GridGeom g,
-                                                  int* __restrict__ key, unsigned* __restrict__ cell_count) {
+                                                  int* __restrict__ key, unsigned* __restrict__ rank,
+                                                  unsigned* __restrict__ cell_count) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 p = pts[i];
     int c = -1;
@@ -232,7 +233,9 @@ __global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts
       if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;
     }
     key[i] = c;
-    if (c >= 0) atomicAdd(&cell_count[c], 1u);
+    // the returned count is the point's arrival rank inside its cell: the scatter needs no second
+    // round of atomics
+    if (c >= 0) rank[i] = atomicAdd(&cell_count[c], 1u);
   }
 }
 
@@ -362,11 +365,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* __restrict__ ce
 // ---------------------------------------------------------------------------
 // K1.d  counting-sort scatter of point indices into per-cell segments
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_scatter(const int* __restrict__ key, int n, unsigned* __restrict__ cursor,
-                                                    int* __restrict__ sorted_idx) {
+__global__ __launch_bounds__(kBlock) void k_scatter(const int* __restrict__ key, const unsigned* __restrict__ rank, int n,
+                                                    const unsigned* __restrict__ cell_start, int* __restrict__ sorted_idx) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const int c = key[i];
-    if (c >= 0) sorted_idx[atomicAdd(&cursor[c], 1u)] = i;
+    if (c >= 0) sorted_idx[cell_start[c] + rank[i]] = i;
   }
 }
 
@@ -504,21 +507,54 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
   const int cnt = leaf_count[o];
   int* seg = sorted_idx + start;
 
-  // The scatter's atomic cursor leaves the segment in arrival order; restore
-  // ascending point order so the f64 sums below round exactly like the
-  // reference's sequential first pass (_impl.hpp:209-263).
-  sort_segment(seg, cnt);
-
+  // The counting sort leaves the segment in arrival order; restore ascending point order so
+  // the f64 sums below round exactly like the reference's sequential first pass
+  // (_impl.hpp:209-263).
   // first-pass sums: mean_ += pt ; cov_ += pt*pt^T with cov_ seeded Identity (.h:107)
   double sx = 0, sy = 0, sz = 0;
   double cxx = 1, cxy = 0, cxz = 0, cyy = 1, cyz = 0, czz = 1;
   float fx = 0, fy = 0, fz = 0;  // centroid.head<4>() += pt  (f32, :240-244)
-  for (int i = 0; i < cnt; i++) {
-    const float4 p = pts[seg[i]];
+  auto add_point = [&](const float4& p) {
     const double x = p.x, y = p.y, z = p.z;
     sx += x; sy += y; sz += z;
     cxx += x * x; cxy += x * y; cxz += x * z; cyy += y * y; cyz += y * z; czz += z * z;
     fx += p.x; fy += p.y; fz += p.z;
+  };
+  constexpr int kReg = 16;
+  if (cnt <= kReg) {
+    // typical voxel: indices in registers (all loads in flight at once), odd-even transposition
+    // sort, then all point gathers in flight at once -- two memory latencies per voxel instead
+    // of two per point
+    int idx[kReg];
+#pragma unroll
+    for (int i = 0; i < kReg; i++) idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
+#pragma unroll
+    for (int pass = 0; pass < kReg; pass++) {
+#pragma unroll
+      for (int i = pass & 1; i + 1 < kReg; i += 2) {
+        const int a = idx[i], b = idx[i + 1];
+        idx[i] = min(a, b);
+        idx[i + 1] = max(a, b);
+      }
+    }
+    float4 pp[kReg];
+#pragma unroll
+    for (int i = 0; i < kReg; i++) pp[i] = pts[(i < cnt) ? idx[i] : idx[0]];
+#pragma unroll
+    for (int i = 0; i < kReg; i++) {
+      if (i < cnt) {
+        seg[i] = idx[i];  // keep the sorted order for the dump pass
+        add_point(pp[i]);
+      }
+    }
+  } else {
+    sort_segment(seg, cnt);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {  // four gathers in flight
+      const float4 p0 = pts[seg[i]], p1 = pts[seg[i + 1]], p2 = pts[seg[i + 2]], p3 = pts[seg[i + 3]];
+      add_point(p0); add_point(p1); add_point(p2); add_point(p3);
+    }
+    for (; i < cnt; i++) add_point(pts[seg[i]]);
   }
   const double n = cnt;
   const double ps[3] = {sx, sy, sz};
@@ -1486,9 +1522,9 @@ hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minma
   return hipGetLastError();
 }
 
-hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_cell_count,
-                        hipStream_t stream) {
-  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, pts, n, dense, g, d_key, d_cell_count);
+hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
+                        unsigned* d_cell_count, hipStream_t stream) {
+  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, pts, n, dense, g, d_key, d_rank, d_cell_count);
   return hipGetLastError();
 }
 
@@ -1513,8 +1549,9 @@ hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells
   return hipGetLastError();
 }
 
-hipError_t launch_scatter(const int* d_key, int n, unsigned* d_cursor, int* d_sorted_idx, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scatter, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, d_key, n, d_cursor, d_sorted_idx);
+hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const unsigned* d_cell_start, int* d_sorted_idx,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(k_scatter, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, d_key, d_rank, n, d_cell_start, d_sorted_idx);
   return hipGetLastError();
 }
 

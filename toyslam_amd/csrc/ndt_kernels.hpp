@@ -77,15 +77,16 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
 
 struct GridBuildScratch;  // opaque, owned by the grid
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
-hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_cell_count,
-                        hipStream_t stream);
+hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
+                        unsigned* d_cell_count, hipStream_t stream);
 hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
                               int n_tiles, hipStream_t stream);
 hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream);
 hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
                              const unsigned* d_block_sums, int n_tiles, int* d_lut, int* d_leaf_cell,
                              unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream);
-hipError_t launch_scatter(const int* d_key, int n, unsigned* d_cursor, int* d_sorted_idx, hipStream_t stream);
+hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const unsigned* d_cell_start, int* d_sorted_idx,
+                          hipStream_t stream);
 
 struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
   int* nr_points;
