@@ -46,7 +46,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--set", default="U", choices=["U", "S"], help="U = uniform box (headline), S = surface scene")
-    ap.add_argument("--workload", default="single", choices=["single", "batch"])
+    ap.add_argument("--workload", default="single", choices=["single", "batch", "large"],
+                    help="single = configs[1] (headline); batch = configs[3] shape per GPU; "
+                         "large = configs[2]: 2M-pt source vs 10M-pt target, 0.5 m voxels")
     ap.add_argument("--batch", type=int, default=64, help="scans per GPU for --workload batch (config 4 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -72,7 +74,13 @@ def main():
             dist.barrier()
 
     # ---- inputs (synthetic, seeded; resident in HBM before the timed region) ----
-    tgt = clouds.target_uniform(M_TARGET) if args.set == "U" else clouds.target_surfaces(M_TARGET)
+    global M_TARGET, N_SOURCE, RESOLUTION
+    if args.workload == "large":
+        M_TARGET, N_SOURCE, RESOLUTION = 10000000, 2000000, 0.5
+    if args.workload == "large":   # configs[2]: surface scene of 200 x 200 m (at 400 m a 10M-pt map is too sparse for 0.5 m voxels: most hold < 6 points)
+        tgt = clouds.target_surfaces(M_TARGET, extent=200.0, n_boxes=120)
+    else:
+        tgt = clouds.target_uniform(M_TARGET) if args.set == "U" else clouds.target_surfaces(M_TARGET)
     reg = ndt.NormalDistributionsTransform(device=local_rank)
     reg.setResolution(RESOLUTION)
     reg.setNeighborhoodSearchMethod(ndt.DIRECT7)
@@ -94,7 +102,7 @@ def main():
     torch.cuda.synchronize()
     t_build_dev = best_of(lambda: reg.setInputTargetDevice(tgt_dev.data_ptr(), len(tgt), 16))  # cloud already in HBM
 
-    if args.workload == "single":
+    if args.workload in ("single", "large"):
         src = clouds.source_from_target(tgt, N_SOURCE, seed=clouds.SEED + 1 + 7 * rank)
         reg.setInputSource(src)
         t_source = best_of(lambda: reg.setInputSource(src))           # H2D + spatial ordering of the scan
@@ -131,7 +139,7 @@ def main():
 
     out = None
     if rank == 0:
-        st = reg.stats() if args.workload == "single" else {}
+        st = reg.stats() if args.workload in ("single", "large") else {}
         value = world * args.steps * regs_per_step / dt
         out = {
             "metric": METRIC, "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
@@ -139,13 +147,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes "
                                     "(max_iterations 28, epsilon 0), set " + args.set) if args.workload == "single" else
+                       ("single 2M-pt source vs 10M-pt target (surface scene, 200 m), 0.5 m voxels, DIRECT7, 30 Newton passes")
+                       if args.workload == "large" else
                        ("map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set)),
                        "target_points": M_TARGET, "source_points": N_SOURCE, "resolution_m": RESOLUTION,
                        "search": "DIRECT7", "outer_passes": MAX_ITER + 2, "sharding": "one scan stream per GPU, target grid replicated"},
             "target_build_ms": t_build * 1e3, "target_build_device_resident_ms": t_build_dev * 1e3,
             "target_build_first_call_ms": t_build_first * 1e3,
         }
-        if args.workload == "single":
+        if args.workload in ("single", "large"):
             out["set_source_ms"] = t_source * 1e3
             out["registrations_per_s_incl_target_build_and_source_upload"] = 1.0 / (dt / args.steps + t_build + t_source)
             out["evaluations_per_registration"] = st["n_evals"]
@@ -170,7 +180,7 @@ def main():
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", "r01_profile_summary.json")))
                 for name, c in prof["pmc"].items():
-                    if "k_derivatives_fused<7, true" in name:
+                    if "k_derivatives_fused<7, true" in name and args.workload == "single":
                         traffic = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
                         traffic_src = "profiles/r01_profile_summary.json"
             except Exception:
@@ -187,7 +197,7 @@ def main():
             out["us_per_evaluation_in_timed_region"] = dt / args.steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
             out["registration_algorithmic_GBs"] = st["n_evals"] * bytes_per_launch / (dt / args.steps) / 1e9
             # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
-            if world == 1 and not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline and args.workload == "single":
                 from oracle import pyoracle as po
                 # the GPU box exposes every host core, but one GPU's share of it is 16 (and the port
                 # does not scale past that: its zero-fill/ordered-reduce/f64-Hessian parts are serial)

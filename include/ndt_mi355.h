@@ -67,7 +67,7 @@ ndt_status ndt_set_step_size(ndt_handle h, double step_size);        /* :165-169
 ndt_status ndt_set_outlier_ratio(ndt_handle h, double ratio);        /* :183-187 */
 ndt_status ndt_set_transformation_epsilon(ndt_handle h, double eps); /* pcl::Registration */
 ndt_status ndt_set_maximum_iterations(ndt_handle h, int n);          /* pcl::Registration */
-ndt_status ndt_set_neighborhood_search_method(ndt_handle h, int m);  /* :189-191; KDTREE is not implemented -> NDT_ERR_INVALID at align */
+ndt_status ndt_set_neighborhood_search_method(ndt_handle h, int m);  /* :189-191; unknown values act as DIRECT7 (the reference's `default:`) */
 ndt_status ndt_set_num_threads(ndt_handle h, int n);                 /* :115-117; stored, unused on the GPU */
 ndt_status ndt_set_min_points_per_voxel(ndt_handle h, int n);        /* voxel_grid_covariance_omp.h:227-239 (clamped to >= 3) */
 ndt_status ndt_set_cov_eig_value_inflation_ratio(ndt_handle h, double r); /* .h:253-257 */

@@ -50,7 +50,7 @@ def main():
     evals = {}
     poses = {"zero": [0, 0, 0, 0, 0, 0], "small": [0.4, 0.1, -0.02, 0.004, -0.001, -0.01],
              "large": [-0.7, 0.9, 0.15, 0.05, -0.08, 0.3]}
-    for method, mname in ((po.DIRECT7, "DIRECT7"), (po.DIRECT1, "DIRECT1"), (po.DIRECT26, "DIRECT26")):
+    for method, mname in ((po.DIRECT7, "DIRECT7"), (po.DIRECT1, "DIRECT1"), (po.DIRECT26, "DIRECT26"), (po.KDTREE, "KDTREE")):
         o.set(search_method=method)
         for pname, p in poses.items():
             score, grad, H, nn = o.eval(p, True)
@@ -70,7 +70,9 @@ def main():
              ("DIRECT7/guess", po.DIRECT7, guess, 0.01, 64, 0.1),                # ndt_rosbag_mapping_node.cpp:130
              ("DIRECT7/guess_neg_roll", po.DIRECT7, neg_roll, 0.01, 64, 0.1),    # eulerAngles [0,pi] branch
              ("DIRECT7/tight", po.DIRECT7, None, 1e-9, 28, 0.1),                 # line search iterates, f64 Hessian
-             ("DIRECT26/default", po.DIRECT26, None, 0.1, 35, 0.1)]
+             ("DIRECT26/default", po.DIRECT26, None, 0.1, 35, 0.1),
+             ("KDTREE/default", po.KDTREE, None, 0.1, 35, 0.1),                  # apps/align.cpp:88-93, README.md:18-21
+             ("KDTREE/node_params", po.KDTREE, None, 0.01, 64, 0.1)]
     for name, method, gs, eps, mi, step in cases:
         o.set(search_method=method, trans_eps=eps, max_iter=mi, step_size=step)
         r = o.align(gs)
@@ -79,7 +81,7 @@ def main():
                             trans_probability=r["trans_probability"], n_evals=r["n_evals"],
                             n_hessian_recomputes=r["n_hessian_recomputes"])
     gold["aligns"] = aligns
-    gold["readme_fitness"] = {"DIRECT7": 0.214205, "DIRECT1": 0.208511}  # ndt_omp/README.md:23-31,38-46
+    gold["readme_fitness"] = {"DIRECT7": 0.214205, "DIRECT1": 0.208511, "KDTREE": 0.213937}  # ndt_omp/README.md:13-46
 
     with open(os.path.join(OUT, "oracle_golden.json"), "w") as f:
         json.dump(gold, f, indent=1)

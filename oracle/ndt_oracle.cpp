@@ -319,6 +319,7 @@ void VoxelGrid::build(const std::vector<Pt>& cloud, bool is_dense) {
 
     centroids.push_back(Pt{leaf.centroid[0], leaf.centroid[1], leaf.centroid[2], 1.0f});
     centroid_leaf_idx.push_back(static_cast<int>(kv.first));
+    leaf.in_centroids = true;  // stays in the KD-tree even if rejected below (trap 7)
 
     // :329-330   cov_ started at Identity (trap 1)
     const double n = leaf.nr_points;
@@ -366,7 +367,44 @@ void VoxelGrid::build(const std::vector<Pt>& cloud, bool is_dense) {
 // getNeighborhoodAtPoint (:373-404) + wrappers (:407-442).
 // [PCL] getAllNeighborCellIndices(): 3x3x3 offsets with i outer, j, k inner over
 // {-1,0,1}, the centre (0,0,0) removed.
-int VoxelGrid::neighbors(const Pt& p, SearchMethod m, const Leaf** out) const {
+int VoxelGrid::neighbors(const Pt& p, SearchMethod m, const Leaf** out, float radius) const {
+  if (m == KDTREE) {
+    // radiusSearch (voxel_grid_covariance_omp.h:476-505): [PCL] KdTreeFLANN over voxel_centroids_
+    // (f32 x,y,z), [FLANN] L2_Simple distance accumulated in f32, RadiusResultSet keeps
+    // dist < radius^2 (strict), results sorted by distance.  A centroid lies inside its voxel, so
+    // every hit is in the 3x3x3 cells around the query; rejected leaves (nr_points == -1) are
+    // still in the centroid cloud and ARE returned (trap 7).
+    if (leaves.empty()) return 0;
+    const int ijk[3] = {static_cast<int>(std::floor(p.x / leaf_size[0])), static_cast<int>(std::floor(p.y / leaf_size[1])),
+                        static_cast<int>(std::floor(p.z / leaf_size[2]))};
+    const float r2 = static_cast<float>(static_cast<double>(radius) * static_cast<double>(radius));
+    struct Hit { float d; size_t key; const Leaf* leaf; };
+    Hit hits[27];
+    int n = 0;
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++) {
+          const int q[3] = {ijk[0] + a, ijk[1] + b, ijk[2] + c};
+          bool inside = true;
+          for (int k = 0; k < 3; k++)
+            if (q[k] < min_b[k] || q[k] > max_b[k]) inside = false;
+          if (!inside) continue;
+          size_t key = 0;
+          for (int k = 0; k < 3; k++) key += static_cast<size_t>(q[k] - min_b[k]) * divb_mul[k];
+          auto it = leaves.find(key);
+          if (it == leaves.end() || !it->second.in_centroids) continue;
+          const Leaf& lf = it->second;
+          const float dx = p.x - lf.centroid[0], dy = p.y - lf.centroid[1], dz = p.z - lf.centroid[2];
+          float d = 0.0f;
+          d += dx * dx;
+          d += dy * dy;
+          d += dz * dz;
+          if (d < r2) hits[n++] = Hit{d, key, &lf};
+        }
+    std::sort(hits, hits + n, [](const Hit& x, const Hit& y) { return x.d < y.d || (x.d == y.d && x.key < y.key); });
+    for (int i = 0; i < n; i++) out[i] = hits[i].leaf;
+    return n;
+  }
   static const int rel7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
   int rel26[26][3];
   const int (*rel)[3];
@@ -604,8 +642,8 @@ double NDT::compute_derivatives(double g[6], double H[36], const std::vector<Pt>
 #pragma omp parallel for num_threads(nthreads) schedule(guided, 8)
   for (size_t idx = 0; idx < N; idx++) {
     const Pt x_trans_pt = trans_cloud[idx];
-    const Leaf* nb[26];
-    int n_nb = grid.neighbors(x_trans_pt, search_method, nb);
+    const Leaf* nb[27];
+    int n_nb = grid.neighbors(x_trans_pt, search_method, nb, resolution);
     double score_pt = 0, g_pt[6] = {0, 0, 0, 0, 0, 0}, H_pt[36];
     for (int k = 0; k < 36; k++) H_pt[k] = 0;
     PointDerivF d;
@@ -643,8 +681,8 @@ void NDT::compute_hessian(double H[36], const std::vector<Pt>& trans_cloud) {
   const size_t N = source.size();
   for (size_t idx = 0; idx < N; idx++) {
     const Pt x_trans_pt = trans_cloud[idx];
-    const Leaf* nb[26];
-    int n_nb = grid.neighbors(x_trans_pt, search_method, nb);
+    const Leaf* nb[27];
+    int n_nb = grid.neighbors(x_trans_pt, search_method, nb, resolution);
     for (int ni = 0; ni < n_nb; ni++) {
       const Leaf* cell = nb[ni];
       const double x[3] = {source[idx].x, source[idx].y, source[idx].z};
@@ -701,8 +739,8 @@ double NDT::calculate_score(const std::vector<Pt>& trans_cloud) const {
   double score = 0;
   for (size_t idx = 0; idx < trans_cloud.size(); idx++) {
     const Pt x_trans_pt = trans_cloud[idx];
-    const Leaf* nb[26];
-    int n_nb = grid.neighbors(x_trans_pt, search_method, nb);
+    const Leaf* nb[27];
+    int n_nb = grid.neighbors(x_trans_pt, search_method, nb, resolution);
     for (int ni = 0; ni < n_nb; ni++) {
       const Leaf* cell = nb[ni];
       double xt[3] = {x_trans_pt.x, x_trans_pt.y, x_trans_pt.z};

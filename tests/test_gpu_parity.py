@@ -117,11 +117,11 @@ def test_grid_large_leaves_and_nonfinite(mods):
 
 # ------------------------------------------------------------------ K2: derivatives
 @pytest.mark.parametrize("key", ["DIRECT7/zero", "DIRECT7/small", "DIRECT7/large", "DIRECT1/zero", "DIRECT1/small",
-                                 "DIRECT26/small", "DIRECT26/large"])
+                                 "DIRECT26/small", "DIRECT26/large", "KDTREE/zero", "KDTREE/small", "KDTREE/large"])
 def test_eval_matches_oracle_and_golden(mods, pair, golden, key):
     ndt, po, _ = mods
     t, s = pair
-    method = {"DIRECT7": po.DIRECT7, "DIRECT1": po.DIRECT1, "DIRECT26": po.DIRECT26}[key.split("/")[0]]
+    method = {"DIRECT7": po.DIRECT7, "DIRECT1": po.DIRECT1, "DIRECT26": po.DIRECT26, "KDTREE": po.KDTREE}[key.split("/")[0]]
     g, o = make_pair(mods, t, s, search_method=method)
     e = golden["evals"][key]
     score, grad, H, nn = g.eval(e["p"], True)
@@ -188,7 +188,7 @@ def test_eval_linearity_in_points(mods, pair):
 
 # ------------------------------------------------------------------ full registration
 ALIGN_CASES = ["DIRECT7/default", "DIRECT1/default", "DIRECT7/node_params", "DIRECT7/guess", "DIRECT7/guess_neg_roll",
-               "DIRECT7/tight", "DIRECT26/default"]
+               "DIRECT7/tight", "DIRECT26/default", "KDTREE/default", "KDTREE/node_params"]
 
 
 @pytest.mark.parametrize("name", ALIGN_CASES)
@@ -223,7 +223,7 @@ def test_readme_fitness_on_gpu(mods, pair, golden):
     from scipy.spatial import cKDTree
     ndt, po, _ = mods
     t, s = pair
-    for name, method in (("DIRECT7", po.DIRECT7), ("DIRECT1", po.DIRECT1)):
+    for name, method in (("DIRECT7", po.DIRECT7), ("DIRECT1", po.DIRECT1), ("KDTREE", po.KDTREE)):
         g = ndt.NormalDistributionsTransform()
         g.setResolution(1.0)
         g.setNeighborhoodSearchMethod(method)
@@ -307,13 +307,33 @@ def test_edge_cases(mods, pair):
     o.set_target(t)
     o.set_source(np.delete(bad, 3, axis=0))
     assert g.eval(np.zeros(6))[0] == pytest.approx(o.eval(np.zeros(6))[0], rel=1e-6)
-    g.setNeighborhoodSearchMethod(ndt.KDTREE)
-    with pytest.raises(NdtError):
-        g.align()                                              # not implemented: fails loudly, no silent substitute
     g.setNeighborhoodSearchMethod(7)                           # unknown value: the reference's `default:` = DIRECT7
     g.setInputSource(s)
     o.set_source(s)
     assert g.eval(np.zeros(6))[0] == pytest.approx(o.eval(np.zeros(6))[0], rel=1e-6)
+
+
+def test_kdtree_degenerate_voxels(mods):
+    """KDTREE next to degenerate voxels.  Because cov_ is seeded with Identity (trap 1) a zero-spread
+    voxel is NOT rejected -- its covariance is (n-1)/n^2 * I -- so both searches use it; the
+    rejected-voxel branch of trap 7 needs catastrophic cancellation and is not reachable with sane
+    coordinates.  The GPU must agree with the oracle on such voxels in both modes."""
+    ndt, po, _ = mods
+    rng = np.random.default_rng(3)
+    good = (rng.random((400, 3)) * [3.0, 3.0, 1.0]).astype(np.float32)
+    same = np.tile(np.array([[5.5, 0.5, 0.5]], np.float32), (20, 1))       # zero spread
+    tgt = np.concatenate([good, same])
+    src = np.concatenate([good[::5], np.array([[5.4, 0.6, 0.4], [5.6, 0.4, 0.6]], np.float32)])
+    for method in (po.KDTREE, po.DIRECT7):
+        g, o = make_pair(mods, tgt, src, search_method=method)
+        og = o.grid()
+        k = int(np.nonzero(og["n"] == 20)[0][0])
+        assert np.allclose(og["cov"][k], np.eye(3) * 19.0 / 400.0, atol=1e-9)
+        p = [0.01, -0.02, 0.0, 0.0, 0.0, 0.003]
+        so, go, Ho, nno = o.eval(p, True)
+        sg, gg, Hg, nng = g.eval(p, True)
+        assert nng == nno
+        assert sg == pytest.approx(so, rel=1e-6) and close_sums(gg, go) and close_sums(Hg, Ho)
 
 
 def test_set_resolution_rebuild_rule(mods, pair):

@@ -8,7 +8,7 @@ from oracle import pyoracle as po
 
 from conftest import rot_err, trans_err
 
-METHODS = {"DIRECT7": po.DIRECT7, "DIRECT1": po.DIRECT1, "DIRECT26": po.DIRECT26}
+METHODS = {"DIRECT7": po.DIRECT7, "DIRECT1": po.DIRECT1, "DIRECT26": po.DIRECT26, "KDTREE": po.KDTREE}
 
 
 @pytest.fixture(scope="module")
@@ -27,9 +27,10 @@ def pcl_fitness(target, source, T):
     return float(np.mean((d.astype(np.float32) ** 2).astype(np.float64)))
 
 
-@pytest.mark.parametrize("name", ["DIRECT7", "DIRECT1"])
+@pytest.mark.parametrize("name", ["DIRECT7", "DIRECT1", "KDTREE"])
 def test_readme_fitness_known_answer(pair, golden, name):
-    """apps/align on the bundled pair: README prints fitness 0.214205 (DIRECT7) / 0.208511 (DIRECT1)."""
+    """apps/align on the bundled pair: README prints fitness 0.214205 (DIRECT7) / 0.208511 (DIRECT1) /
+    0.213937 (KDTREE, which the README says is also pcl::NDT's own result)."""
     t, s = pair
     o = po.OracleNDT(resolution=1.0, search_method=METHODS[name], num_threads=4)  # class defaults, align.cpp:95-103
     o.set_target(t)
@@ -77,7 +78,7 @@ def test_grid_covariance_quirks(pair, oracle):
     assert checked > 0
 
 
-@pytest.mark.parametrize("key", ["DIRECT7/zero", "DIRECT7/small", "DIRECT7/large", "DIRECT1/small", "DIRECT26/small"])
+@pytest.mark.parametrize("key", ["DIRECT7/zero", "DIRECT7/small", "DIRECT7/large", "DIRECT1/small", "DIRECT26/small", "KDTREE/small"])
 def test_eval_matches_golden(oracle, golden, key):
     e = golden["evals"][key]
     oracle.set(search_method=METHODS[key.split("/")[0]])
@@ -159,7 +160,8 @@ def test_f64_hessian_differs_only_by_sign_quirk(oracle):
 
 
 @pytest.mark.parametrize("name", ["DIRECT7/default", "DIRECT1/default", "DIRECT7/node_params", "DIRECT7/guess",
-                                  "DIRECT7/guess_neg_roll", "DIRECT7/tight", "DIRECT26/default"])
+                                  "DIRECT7/guess_neg_roll", "DIRECT7/tight", "DIRECT26/default", "KDTREE/default",
+                                  "KDTREE/node_params"])
 def test_align_matches_golden(pair, golden, name):
     t, s = pair
     a = golden["aligns"][name]

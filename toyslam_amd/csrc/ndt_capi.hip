@@ -495,7 +495,13 @@ void colmajor_to_T12(const float* m, float* T12) {
     for (int c = 0; c < 4; c++) T12[r * 4 + c] = m[c * 4 + r];
 }
 
-void fill_eval_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::EvalParams& P) {
+// squared KDTREE radius as [PCL]/[FLANN] see it: radius = resolution_ (f32 -> f64), squared, then f32
+float kd_radius2(float resolution) {
+  const double r = static_cast<double>(resolution);
+  return static_cast<float>(r * r);
+}
+
+void fill_eval_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, float kd_r2, ndt::EvalParams& P) {
   colmajor_to_T12(rq.T, P.T);
   ndt::AngleDerivs ad;
   ndt::angle_derivatives(rq.p, ad);
@@ -503,11 +509,10 @@ void fill_eval_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Eva
   std::memcpy(P.h, ad.h, sizeof(P.h));
   P.d1 = gs.d1;
   P.d2 = static_cast<float>(gs.d2);
-  static const int dbg = [] { const char* v = getenv("NDT_DBG_MODE"); return v ? atoi(v) : 0; }();
-  P.pad = dbg;  // diagnostic phase-skipping (0 in production)
+  std::memcpy(&P.pad, &kd_r2, sizeof(float));
 }
 
-void fill_h64_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Hess64Params& P) {
+void fill_h64_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, float kd_r2, ndt::Hess64Params& P) {
   colmajor_to_T12(rq.T, P.T);
   ndt::AngleDerivs ad;
   ndt::angle_derivatives(rq.p, ad);
@@ -515,6 +520,7 @@ void fill_h64_params(const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::Hess
   std::memcpy(P.hd, ad.hd, sizeof(P.hd));
   P.d1 = gs.d1;
   P.d2 = gs.d2;
+  P.r2 = kd_r2;
 }
 
 // packed row -> EvalResult
@@ -537,8 +543,6 @@ void unpack_row(const double* row, bool have_h, ndt::EvalResult& r, double* nn) 
 ndt_status check_ready(ndt_context* h) {
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target: call ndt_set_input_target first");
   if (!h->source) return fail(NDT_ERR_NO_INPUT, "no input source: call ndt_set_input_source first");
-  if (h->search == NDT_KDTREE)
-    return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented (DIRECT26/DIRECT7/DIRECT1 are)");
   return ensure_device(h);
 }
 
@@ -569,11 +573,11 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   if (rq.kind == ndt::EVAL_HESSIAN_F64) {
     ndt::Hess64Params P;
-    fill_h64_params(rq, gs, P);
+    fill_h64_params(rq, gs, kd_radius2(h->resolution), P);
     HIP_TRY(ndt::launch_hessian64(src, n, gv, P, h->search, nullptr, nullptr, 1, nblk, nblk, h->partials.p, h->stream));
   } else {
     ndt::EvalParams P;
-    fill_eval_params(rq, gs, P);
+    fill_eval_params(rq, gs, kd_radius2(h->resolution), P);
     if (fused) {
       seq = ++h->eval_seq;
       HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, h->partials.p,
@@ -672,7 +676,7 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
                            double* nn_total, bool* served) {
   *served = false;
   ndt::EvalParams P;
-  fill_eval_params(rq, gs, P);
+  fill_eval_params(rq, gs, kd_radius2(h->resolution), P);
   const unsigned long long seq = ++h->eval_seq;
   ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), &P);
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
@@ -979,7 +983,6 @@ ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hess, double* mean_n
 ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride, double* score) {
   if (!h || !score) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
-  if (h->search == NDT_KDTREE) return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented");
   std::shared_ptr<DeviceCloud> c;
   ndt_status s = upload_cloud(h, cloud, n, stride, false, c);
   if (s) return s;
@@ -993,7 +996,7 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
   const int nblk = ndt::derivative_blocks(static_cast<int>(n), NDT_DIRECT1);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   HIP_TRY(hipMemsetAsync(h->partials.p, 0, static_cast<size_t>(nblk) * ndt::kEvalStride * sizeof(double), h->stream));
-  HIP_TRY(ndt::launch_calc_score(c->pts.p, static_cast<int>(n), h->grid->view(), gs.d1, gs.d2, gs.d3, h->search, nblk,
+  HIP_TRY(ndt::launch_calc_score(c->pts.p, static_cast<int>(n), h->grid->view(), gs.d1, gs.d2, gs.d3, h->search, kd_radius2(h->resolution), nblk,
                                  h->partials.p, h->stream));
   HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1007,7 +1010,6 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
                                    double* tprob) {
   if (!h || !offsets) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
-  if (h->search == NDT_KDTREE) return fail(NDT_ERR_INVALID, "KDTREE neighbour search is not implemented");
   if (n_scans == 0) return NDT_OK;
   if (n_scans > 65535) return fail(NDT_ERR_INVALID, "at most 65535 scans per batch");
   for (size_t k = 0; k < n_scans; k++)
@@ -1070,8 +1072,8 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       if (descs[k].kind == ndt::EVAL_NONE) return;
       const ndt::EvalRequest& rq = solvers[k].request();
       descs[k].pad = nblk_kind[descs[k].kind];
-      if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, descs[k].P64);
-      else fill_eval_params(rq, gs, descs[k].P);
+      if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, kd_radius2(h->resolution), descs[k].P64);
+      else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[k].P);
     });
     if (degenerate) {
       std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
@@ -1232,7 +1234,7 @@ ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* st
   std::memcpy(rq.p, p, sizeof(rq.p));
   ndt::pose_to_matrix(p, rq.T);
   ndt::EvalParams P;
-  fill_eval_params(rq, ndt::gauss_constants(h->resolution, h->outlier_ratio), P);
+  fill_eval_params(rq, ndt::gauss_constants(h->resolution, h->outlier_ratio), kd_radius2(h->resolution), P);
   DevBuf<unsigned long long> d;
   HIP_TRY(d.reserve(waves * 8));
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));

@@ -449,6 +449,7 @@ __device__ void inv3_cofactor(const double a[3][3], double r[3][3]) {
   r[2][0] = cof(0, 2) * invdet; r[2][1] = cof(1, 2) * invdet; r[2][2] = cof(2, 2) * invdet;
 }
 
+constexpr int kLutRejected = 0x40000000;  // LUT flag: voxel has a record but nr_points == -1
 constexpr int kSortLimit = 64;      // up to here: insertion sort
 constexpr int kSortGiveUp = 65536;  // beyond: left in arrival order (one thread would stall for too long)
 
@@ -596,7 +597,12 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
         for (int j = 0; j < 3; j++) { mx = fmax(mx, icov[i][j]); mn = fmin(mn, icov[i][j]); }
       if (mx == static_cast<double>(INFINITY) || mn == -static_cast<double>(INFINITY)) nr_points = -1;  // :360-364
     }
-    if (nr_points >= min_pts) {
+    {
+      // Every voxel that reached min_points_per_voxel gets a record: the reference pushes its
+      // centroid to the KD-tree BEFORE the eigenvalue / inverse checks (_impl.hpp:302-326 vs
+      // :337-341,:360-364), so KDTREE search still returns a rejected voxel (trap 7), with the
+      // icov_ it was left with (zero, or the inf-bearing inverse).  DIRECT searches skip it
+      // (nr_points = -1): the LUT entry carries kLutRejected.
       const int r = leaf_rec[o];
       VoxelRec rec;
       rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
@@ -606,8 +612,12 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
       rec.centroid[0] = fx; rec.centroid[1] = fy; rec.centroid[2] = fz;
       rec.n = cnt;
       recs[r] = rec;
-      lut[leaf_cell[o]] = r;
-      atomicAdd(n_valid, 1u);
+      if (nr_points >= min_pts) {
+        lut[leaf_cell[o]] = r;
+        atomicAdd(n_valid, 1u);
+      } else {
+        lut[leaf_cell[o]] = r | kLutRejected;
+      }
     }
   }
   if (dump.nr_points) {
@@ -638,7 +648,8 @@ __device__ __constant__ signed char kOff26[26][3] = {
 
 template <int NNB>
 __device__ __forceinline__ void nb_offset(int k, int& dx, int& dy, int& dz) {
-  if (NNB == 26) { dx = kOff26[k][0]; dy = kOff26[k][1]; dz = kOff26[k][2]; }
+  if (NNB == 27) { dx = k / 9 - 1; dy = (k / 3) % 3 - 1; dz = k % 3 - 1; }  // KDTREE: the 3x3x3 block
+  else if (NNB == 26) { dx = kOff26[k][0]; dy = kOff26[k][1]; dz = kOff26[k][2]; }
   else { dx = kOff7[k][0]; dy = kOff7[k][1]; dz = kOff7[k][2]; }
 }
 
@@ -672,7 +683,33 @@ __device__ __forceinline__ int probe(const GridView& gv, int i, int j, int k, in
       ck > gv.g.max_b[2])
     return -1;
   const int cell = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
-  return gv.lut[cell];
+  const int e = gv.lut[cell];
+  return (e & kLutRejected) ? -1 : e;  // -1 has the bit set too
+}
+
+// KDTREE: record index of voxel (i+dx, ...) if it is in the centroid cloud (valid or rejected) and
+// its f32 centroid is closer than the radius -- radiusSearch, voxel_grid_covariance_omp.h:476-505,
+// [FLANN] L2_Simple accumulated in f32, RadiusResultSet keeps dist < r^2.  Else -1.
+__device__ __forceinline__ int probe_kd(const GridView& gv, int i, int j, int k, int dx, int dy, int dz, float x, float y,
+                                        float z, float r2) {
+  const int ci = i + dx, cj = j + dy, ck = k + dz;
+  if (ci < gv.g.min_b[0] || ci > gv.g.max_b[0] || cj < gv.g.min_b[1] || cj > gv.g.max_b[1] || ck < gv.g.min_b[2] ||
+      ck > gv.g.max_b[2])
+    return -1;
+  const int cell = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
+  const int e = gv.lut[cell];
+  if (e < 0) return -1;
+  const int rix = e & ~kLutRejected;
+  const float4 c = reinterpret_cast<const float4*>(gv.recs + rix)[3];  // centroid x,y,z, n
+  float d;
+  {
+#pragma clang fp contract(off)
+    const float ex = x - c.x, ey = y - c.y, ez = z - c.z;
+    d = ex * ex;
+    d = d + ey * ey;
+    d = d + ez * ez;
+  }
+  return (d < r2) ? rix : -1;
 }
 
 // coarse reject so that i+d cannot overflow and far-away points cost nothing
@@ -997,6 +1034,40 @@ __device__ __forceinline__ void derivatives_body_split7(const float4* __restrict
   }
 }
 
+// KDTREE search: 3x3x3 cells around the point, centroid-distance filter, same factored math.
+// (The reference visits the hits sorted by distance; only the f64 summation order differs.)
+template <bool WANT_H, class P>
+__device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
+                                                    int first, int stride, double (&acc)[kNumAcc]) {
+  const float r2 = __int_as_float(prm.pad);
+  for (int i = first; i < n; i += stride) {
+    const float4 pt = src[i];
+    float tx, ty, tz;
+    xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    int vi, vj, vk;
+    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    PointAcc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const double nn0 = acc[28];
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++) {
+          const int rix = probe_kd(gv, vi, vj, vk, a, b, c, tx, ty, tz, r2);
+          if (rix < 0) continue;
+          const RecRegs r = load_rec(gv.recs, rix);
+          const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
+          const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
+          const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
+          accumulate_neighbor_factored<WANT_H>(acc[0], acc[28], pa, x0, x1, x2, r, prm.d1, prm.d2);
+        }
+    if (acc[28] != nn0) {
+      PointDeriv d;
+      point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
+      finish_point<WANT_H>(acc, pa, d);
+    }
+  }
+}
+
 template <int NNB, bool WANT_H, bool BATCH, int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                         const ScanDesc* __restrict__ descs, const int* __restrict__ active,
@@ -1015,12 +1086,14 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
     __syncthreads();
-    if (VARIANT == 1) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
-    else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    if (NNB == 27) derivatives_body_kd<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
+    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
     block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
   } else {
-    if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
-    else derivatives_body<NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, P, first, stride, acc);
+    if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, P, first, stride, acc);
+    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
+    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, P, first, stride, acc);
     block_reduce_store<kNumAcc>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
   }
 }
@@ -1050,7 +1123,8 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  derivatives_body<NNB, WANT_H, EvalParams, false, true>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
@@ -1216,8 +1290,13 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
     const int first = blockIdx.x * kServerTPB + threadIdx.x, stride = gridDim.x * kServerTPB;
-    if (kind == 0) derivatives_body<NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
-    else if (kind == 1) derivatives_body<NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+    if (NNB == 27) {
+      if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);
+    } else {
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+    }
     const double tot = wave_fold<kNumAcc>(acc);
     if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
     __syncthreads();
@@ -1368,7 +1447,8 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      const int rix = probe(gv, vi, vj, vk, dx, dy, dz);
+      const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, tx, ty, tz, static_cast<float>(prm->r2))
+                                  : probe(gv, vi, vj, vk, dx, dy, dz);
       if (rix < 0) continue;
       const RecRegs r = load_rec(gv.recs, rix);
       // the record keeps icov in its f32 rounding
@@ -1448,7 +1528,7 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__
 // calculateScore (ndt_omp_impl.hpp:935-983): cloud used as given, f64 throughout
 template <int NNB>
 __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict__ cloud, int n, GridView gv, double d1,
-                                                       double d2, double d3, double* __restrict__ partials) {
+                                                       double d2, double d3, float r2, double* __restrict__ partials) {
   __shared__ double lds[(kBlock / kWave) * 32];
   double acc[1] = {0.0};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -1461,7 +1541,7 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      rec[k] = probe(gv, vi, vj, vk, dx, dy, dz);
+      rec[k] = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, pt.x, pt.y, pt.z, r2) : probe(gv, vi, vj, vk, dx, dy, dz);
       cnt += (rec[k] >= 0);
     }
     for (int k = 0; k < NNB; k++) {
@@ -1605,7 +1685,9 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
   // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
   const int variant = derivative_variant();
 #define NDT_LAUNCH_DERIV(NNB, H, V) launch_deriv_t<NNB, H, V>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream)
-  if (search == 1) {
+  if (search == 0) {
+    if (want_hessian) NDT_LAUNCH_DERIV(27, true, 0); else NDT_LAUNCH_DERIV(27, false, 0);
+  } else if (search == 1) {
     if (want_hessian) NDT_LAUNCH_DERIV(26, true, 0); else NDT_LAUNCH_DERIV(26, false, 0);
   } else if (search == 3) {
     if (want_hessian) NDT_LAUNCH_DERIV(1, true, 0); else NDT_LAUNCH_DERIV(1, false, 0);
@@ -1635,7 +1717,9 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
 #define NDT_LAUNCH_FUSED(NNB, H)                                                                                        \
   hipLaunchKernelGGL((k_derivatives_fused<NNB, H, kFusedTPB>), dim3(n_blocks), dim3(kFusedTPB), 0, stream, src, n, gv, P, \
                      partials, counter, out_row, seq)
-  if (search == 1) {
+  if (search == 0) {
+    if (want_hessian) NDT_LAUNCH_FUSED(27, true); else NDT_LAUNCH_FUSED(27, false);
+  } else if (search == 1) {
     if (want_hessian) NDT_LAUNCH_FUSED(26, true); else NDT_LAUNCH_FUSED(26, false);
   } else if (search == 3) {
     if (want_hessian) NDT_LAUNCH_FUSED(1, true); else NDT_LAUNCH_FUSED(1, false);
@@ -1666,7 +1750,10 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               unsigned long long* dbg) {
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
-  if (search == 1)
+  if (search == 0)
+    hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
+                       out_row, first_seq, idle_ticks, dbg);
+  else if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
                        out_row, first_seq, idle_ticks, dbg);
   else if (search == 3)
@@ -1693,7 +1780,8 @@ static void launch_h64_t(const float4* src, int n, const GridView& gv, const Hes
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
                             double* partials, hipStream_t stream) {
-  if (search == 1) launch_h64_t<26>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
+  if (search == 0) launch_h64_t<27>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
+  else if (search == 1) launch_h64_t<26>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
   else if (search == 3) launch_h64_t<1>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
   else launch_h64_t<7>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream);
   return hipGetLastError();
@@ -1714,13 +1802,15 @@ hipError_t launch_transform(const float4* src, int n, const float* T12, float4* 
 }
 
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3, int search,
-                             int n_blocks, double* partials, hipStream_t stream) {
-  if (search == 1)
-    hipLaunchKernelGGL(k_calc_score<26>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+                             float r2, int n_blocks, double* partials, hipStream_t stream) {
+  if (search == 0)
+    hipLaunchKernelGGL(k_calc_score<27>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
+  else if (search == 1)
+    hipLaunchKernelGGL(k_calc_score<26>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
   else if (search == 3)
-    hipLaunchKernelGGL(k_calc_score<1>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+    hipLaunchKernelGGL(k_calc_score<1>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
   else
-    hipLaunchKernelGGL(k_calc_score<7>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, partials);
+    hipLaunchKernelGGL(k_calc_score<7>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
   return hipGetLastError();
 }
 

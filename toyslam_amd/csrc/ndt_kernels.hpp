@@ -45,7 +45,7 @@ struct EvalParams {
   float h[15][3];   // h_ang  (:373-393), row 6 with +sy
   double d1;        // gauss_d1_ (used as double, :501,510)
   float d2;         // gauss_d2_ cast to float (:496)
-  int pad;
+  int pad;          // KDTREE: bits of the f32 squared search radius
 };
 
 // computeHessian's all-f64 constants (:540-645).
@@ -54,6 +54,7 @@ struct Hess64Params {
   double jd[8][3];
   double hd[15][3];
   double d1, d2;
+  double r2;   // KDTREE: squared search radius (f32 value)
 };
 
 // Batched launches: one descriptor per scan.
@@ -132,7 +133,7 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
                          hipStream_t stream, unsigned long long seq = 0);
 hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream);
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
-                             int search, int n_blocks, double* partials, hipStream_t stream);
+                             int search, float r2, int n_blocks, double* partials, hipStream_t stream);
 
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream);
