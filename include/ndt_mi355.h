@@ -107,6 +107,19 @@ ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hessian_recomputes, 
 /* calculateScore(cloud), ndt_omp_impl.hpp:935-983 (cloud is used as given). */
 ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride_bytes, double* score);
 
+/* ---- scan prefilter (row N1 of the scope table) -----------------------------
+ * pcl::VoxelGrid<PointT>::filter -- one centroid per occupied voxel, output in ascending
+ * voxel-index order -- as every caller runs it before NDT (ndt_omp/apps/align.cpp:60-69,
+ * ndt_omp_mapping_node.cpp:142-148,203-210; [PCL 1.10] filters/impl/voxel_grid.hpp).  xyz only.
+ * `out` must hold n records of out_stride_bytes (x,y,z,1.0f at offset 0); *n_out = voxels written.
+ * When the voxel index space would overflow int32 PCL warns and passes the input through: the
+ * input is then copied to `out`, *n_out = n and NDT_ERR_GRID_OVERFLOW is returned. */
+ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, int is_dense, float leaf_size,
+                                 void* out, size_t out_stride_bytes, size_t* n_out);
+/* Same with input and output (n x float4) resident in HBM. */
+ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense,
+                                        float leaf_size, void* d_out_float4, size_t* n_out);
+
 /* ---- batch (map-build mode: many sources against the one target) ----------
  * Registers n_scans sources in lock-step, one fused derivative launch per
  * line-search step for the whole batch.  Scan k is points

@@ -243,6 +243,59 @@ void transform_cloud(const std::vector<Pt>& in, std::vector<Pt>& out, const floa
   }
 }
 
+bool voxel_grid_filter(const std::vector<Pt>& in, bool is_dense, float leaf, std::vector<Pt>& out) {
+  out.clear();
+  if (in.empty()) return true;
+  const float inv = 1.0f / leaf;
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (const Pt& p : in) {
+    if (!is_dense && (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))) continue;
+    const float v[3] = {p.x, p.y, p.z};
+    for (int k = 0; k < 3; k++) {
+      min_p[k] = std::min(min_p[k], v[k]);
+      max_p[k] = std::max(max_p[k], v[k]);
+    }
+  }
+  if (!(min_p[0] <= max_p[0])) return true;
+  int64_t d[3];
+  for (int k = 0; k < 3; k++) d[k] = static_cast<int64_t>((max_p[k] - min_p[k]) * inv) + 1;
+  if (d[0] * d[1] * d[2] > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) {
+    out = in;  // "Leaf size is too small for the input dataset": output = *input_
+    return false;
+  }
+  int min_b[3], div_b[3];
+  for (int k = 0; k < 3; k++) {
+    min_b[k] = static_cast<int>(std::floor(min_p[k] * inv));
+    div_b[k] = static_cast<int>(std::floor(max_p[k] * inv)) - min_b[k] + 1;
+  }
+  const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+  std::vector<std::pair<unsigned, unsigned>> iv;  // (voxel idx, point index)
+  iv.reserve(in.size());
+  for (size_t i = 0; i < in.size(); i++) {
+    const Pt& p = in[i];
+    if (!is_dense && (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))) continue;
+    const int i0 = static_cast<int>(std::floor(p.x * inv) - static_cast<float>(min_b[0]));
+    const int i1 = static_cast<int>(std::floor(p.y * inv) - static_cast<float>(min_b[1]));
+    const int i2 = static_cast<int>(std::floor(p.z * inv) - static_cast<float>(min_b[2]));
+    iv.emplace_back(static_cast<unsigned>(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), static_cast<unsigned>(i));
+  }
+  std::sort(iv.begin(), iv.end());
+  for (size_t a = 0; a < iv.size();) {
+    size_t b = a;
+    float sx = 0, sy = 0, sz = 0;
+    while (b < iv.size() && iv[b].first == iv[a].first) {
+      sx += in[iv[b].second].x;
+      sy += in[iv[b].second].y;
+      sz += in[iv[b].second].z;
+      b++;
+    }
+    const float n = static_cast<float>(b - a);
+    out.push_back(Pt{sx / n, sy / n, sz / n, 1.0f});
+    a = b;
+  }
+  return true;
+}
+
 // ===========================================================================
 // VoxelGrid  (voxel_grid_covariance_omp_impl.hpp)
 // ===========================================================================

@@ -159,6 +159,17 @@ void oracle_gauss(void* h, double* d) {
   d[2] = nd->gauss_d3;
 }
 
+// [PCL] VoxelGrid centroid down-sample; out must hold n points (x,y,z,1); returns the voxel count,
+// *overflow = 1 when PCL would have copied the input through.
+size_t oracle_voxel_grid_filter(const float* pts, size_t n, size_t stride_floats, int is_dense, float leaf, float* out,
+                                int* overflow) {
+  std::vector<Pt> o;
+  const bool ok = voxel_grid_filter(to_pts(pts, n, stride_floats), is_dense != 0, leaf, o);
+  if (overflow) *overflow = ok ? 0 : 1;
+  std::memcpy(out, o.data(), o.size() * sizeof(Pt));
+  return o.size();
+}
+
 // ---- small restated-Eigen pieces, exported for unit tests -----------------
 void oracle_svd6_solve(const double* H, const double* b, double* x) { svd6_solve(H, b, x); }
 void oracle_eig3(const double* a /*row-major*/, double* evals, double* evecs) {

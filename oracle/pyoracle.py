@@ -54,6 +54,8 @@ def lib():
         L.oracle_pose_to_matrix.argtypes = [dp, fp]
         L.oracle_euler_from_matrix.argtypes = [fp, fp]
         L.oracle_transform_cloud.argtypes = [fp, C.c_size_t, fp, fp]
+        L.oracle_voxel_grid_filter.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, fp, ip]
+        L.oracle_voxel_grid_filter.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -218,3 +220,12 @@ def transform_cloud(pts4, T):
     out = np.zeros_like(a)
     lib().oracle_transform_cloud(_f(a), a.shape[0], _f(Tc), _f(out))
     return out
+
+
+def voxel_grid_filter(pts, leaf, is_dense=True):
+    """[PCL] pcl::VoxelGrid centroid down-sample -> ((V,3) float32, overflowed)."""
+    a = _xyz(pts)
+    out = np.zeros((max(a.shape[0], 1), 4), dtype=np.float32)
+    ov = C.c_int(0)
+    n = lib().oracle_voxel_grid_filter(_f(a), a.shape[0], a.shape[1], int(is_dense), float(leaf), _f(out), C.byref(ov))
+    return out[:n, :3].copy(), bool(ov.value)

@@ -409,3 +409,39 @@ def test_full_size_properties(mods):
     b = g.eval(p, True)
     assert full[0] == pytest.approx(a[0] + b[0], rel=1e-12)
     assert np.allclose(full[2], a[2] + b[2], rtol=1e-10, atol=1e-6)
+
+
+# ------------------------------------------------------------------ N1: scan prefilter (pcl::VoxelGrid)
+def test_voxel_grid_filter(mods, pair):
+    """Centroid down-sample on the GPU vs the oracle's restatement of pcl::VoxelGrid::applyFilter
+    (same f32 accumulation order -> identical), vs an f64 numpy mean, ordering and edge cases."""
+    ndt, po, clouds = mods
+    from toyslam_amd import NdtError, _lib
+    rng = np.random.default_rng(9)
+    g = ndt.NormalDistributionsTransform()
+    raw = (rng.standard_normal((200000, 3)) * [20, 20, 2]).astype(np.float32)
+    for leaf in (0.1, 0.5, 2.0):
+        got = g.voxelGridFilter(raw, leaf)
+        ref, ov = po.voxel_grid_filter(raw, leaf)
+        assert not ov and got.shape == ref.shape
+        assert np.array_equal(got, ref)
+        assert np.abs(got - clouds.voxel_downsample(raw, leaf)).max() < 2e-5
+    # XYZI-shaped input (32-byte records), non-finite points skipped when !is_dense
+    xyzi = np.zeros((len(raw), 8), np.float32)
+    xyzi[:, :3] = raw
+    xyzi[::1000, 0] = np.nan
+    got = g.voxelGridFilter(xyzi, 0.5, is_dense=False)
+    ref, _ = po.voxel_grid_filter(xyzi, 0.5, is_dense=False)
+    assert np.array_equal(got, ref) and np.isfinite(got).all()
+    # empty input; single point
+    assert g.voxelGridFilter(np.zeros((0, 3), np.float32), 0.5).shape == (0, 3)
+    assert np.array_equal(g.voxelGridFilter(np.array([[1.0, 2.0, 3.0]], np.float32), 0.5), [[1.0, 2.0, 3.0]])
+    # index-space overflow: PCL warns and passes the input through
+    far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
+    with pytest.raises(NdtError) as e:
+        g.voxelGridFilter(far, 0.01)
+    assert e.value.status == _lib.NDT_ERR_GRID_OVERFLOW
+    assert po.voxel_grid_filter(far, 0.01)[1]
+    # the filter feeds NDT exactly like apps/align.cpp: same registration as with the oracle's filter
+    t, s = pair
+    assert np.array_equal(g.voxelGridFilter(t, 0.5), po.voxel_grid_filter(t, 0.5)[0])

@@ -215,3 +215,22 @@ def test_edge_cases():
     pts[7] = np.nan
     o.set_target(pts, is_dense=False)
     assert int(o.grid()["n"].sum()) == 199
+
+
+def test_voxel_grid_filter_restatement():
+    """[PCL] VoxelGrid centroid filter: centroids, ascending voxel order, overflow pass-through."""
+    from toyslam_amd import clouds
+    rng = np.random.default_rng(2)
+    pts = (rng.random((5000, 3)) * [10, 10, 2]).astype(np.float32)
+    out, ov = po.voxel_grid_filter(pts, 0.5)
+    assert not ov
+    ref = clouds.voxel_downsample(pts, 0.5)
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-5
+    inv = np.float32(2.0)
+    ijk = np.floor(out * inv).astype(np.int64) - np.floor(pts.min(axis=0) * inv).astype(np.int64)
+    div = np.floor(pts.max(axis=0) * inv).astype(np.int64) - np.floor(pts.min(axis=0) * inv).astype(np.int64) + 1
+    key = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    assert np.all(np.diff(key) > 0)
+    far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
+    out, ov = po.voxel_grid_filter(far, 0.01)
+    assert ov and np.array_equal(out, far)

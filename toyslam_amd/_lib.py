@@ -67,6 +67,8 @@ SIGNATURES = {
     "ndt_get_output_device": (C.c_int, [vp, C.POINTER(vp), szp]),
     "ndt_get_stats": (C.c_int, [vp, ip, ip, dp]),
     "ndt_calculate_score": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, dp]),
+    "ndt_voxel_grid_filter": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, C.c_size_t, szp]),
+    "ndt_voxel_grid_filter_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, szp]),
     "ndt_align_batch": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_align_batch_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int]),

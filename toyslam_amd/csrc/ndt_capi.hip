@@ -1004,6 +1004,108 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
   return NDT_OK;
 }
 
+// ---- N1: voxel-grid centroid down-sample -----------------------------------
+static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf,
+                                    bool on_device, void* out, size_t out_stride, size_t* n_out) {
+  if (!h || !n_out || (n && !out) || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n_out = 0;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  if (n == 0) return NDT_OK;
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(n);
+  // bbox -> geometry, exactly as VoxelGrid::applyFilter
+  const int nb = std::min(1024, (ni + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(c->pts.p, ni, is_dense, d_mm.p, nb, st));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
+      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
+    }
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point: empty output
+  ndt::GridGeom geo{};
+  long long d[3];
+  for (int k = 0; k < 3; k++) {
+    geo.leaf[k] = leaf;
+    geo.inv_leaf[k] = 1.0f / leaf;
+    d[k] = static_cast<long long>((max_p[k] - min_p[k]) * geo.inv_leaf[k]) + 1;
+  }
+  DevBuf<float4> d_out_tmp;
+  float4* d_out = on_device ? static_cast<float4*>(out) : nullptr;
+  if (!on_device) {
+    HIP_TRY(d_out_tmp.reserve(n));
+    d_out = d_out_tmp.p;
+  }
+  size_t n_written = 0;
+  ndt_status result = NDT_OK;
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
+    HIP_TRY(hipMemcpyAsync(d_out, c->pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
+    n_written = n;
+    result = fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
+  } else {
+    for (int k = 0; k < 3; k++) {
+      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+    }
+    geo.mul[0] = 1;
+    geo.mul[1] = geo.div_b[0];
+    geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+    geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+    DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+    DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+    HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+    HIP_TRY(key.reserve(n));
+    HIP_TRY(rank.reserve(n));
+    HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+    HIP_TRY(ndt::launch_count(c->pts.p, ni, is_dense, geo, key.p, rank.p, cell_count.p, st));
+    const int n_tiles = ndt::scan_tiles(geo.n_cells);
+    HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+    HIP_TRY(totals.reserve(4));
+    HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
+    HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+    unsigned tot[3];
+    HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t n_leaves = tot[1];
+    HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
+    HIP_TRY(leaf_cell.reserve(n_leaves));
+    HIP_TRY(leaf_start.reserve(n_leaves));
+    HIP_TRY(leaf_count.reserve(n_leaves));
+    HIP_TRY(leaf_rec.reserve(n_leaves));
+    HIP_TRY(sorted_idx.reserve(n));
+    HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                   leaf_count.p, leaf_rec.p, st));
+    HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+    HIP_TRY(ndt::launch_voxel_centroids(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
+    n_written = n_leaves;
+  }
+  if (!on_device && n_written) {
+    if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_out, sizeof(float4), sizeof(float4), n_written, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  *n_out = n_written;
+  return result;
+}
+
+ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf, void* out,
+                                 size_t out_stride, size_t* n_out) {
+  return voxel_filter_impl(h, pts, n, stride, is_dense, leaf, false, out, out_stride, n_out);
+}
+ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t n, size_t stride, int is_dense, float leaf,
+                                        void* d_out, size_t* n_out) {
+  return voxel_filter_impl(h, d_pts, n, stride, is_dense, leaf, true, d_out, 16, n_out);
+}
+
 // ---- batch ---------------------------------------------------------------
 static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
                                    bool on_device, const float* guesses, float* final_T, int* conv, int* iters,

@@ -495,6 +495,39 @@ __global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict
   for (int i = 0; i < cnt; i++) out[start + i] = pts[seg[i]];
 }
 
+// ---------------------------------------------------------------------------
+// N1  centroid voxel down-sample -- [PCL] pcl::VoxelGrid<PointT>::applyFilter, the prefilter every
+// caller runs before NDT (ndt_omp/apps/align.cpp:60-69, ndt_omp_mapping_node.cpp:142-148,203-210).
+// Same count / scan / scatter machinery as K1; one thread per occupied voxel sums its points in
+// f32 (CentroidPoint / AccumulatorXYZ) in ascending point order and divides by the count.  Leaves
+// are enumerated in cell order, so the output is in ascending voxel-index order like PCL's.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_voxel_centroids(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
+                                                            const int* __restrict__ leaf_count, int n_leaves,
+                                                            int* __restrict__ sorted_idx, float4* __restrict__ out) {
+  const int o = blockIdx.x * kBlock + threadIdx.x;
+  if (o >= n_leaves) return;
+  const unsigned start = leaf_start[o];
+  const int cnt = leaf_count[o];
+  int* seg = sorted_idx + start;
+  sort_segment(seg, cnt);
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  int i = 0;
+  for (; i + 4 <= cnt; i += 4) {
+    const float4 p0 = pts[seg[i]], p1 = pts[seg[i + 1]], p2 = pts[seg[i + 2]], p3 = pts[seg[i + 3]];
+    sx += p0.x; sy += p0.y; sz += p0.z;
+    sx += p1.x; sy += p1.y; sz += p1.z;
+    sx += p2.x; sy += p2.y; sz += p2.z;
+    sx += p3.x; sy += p3.y; sz += p3.z;
+  }
+  for (; i < cnt; i++) {
+    const float4 p = pts[seg[i]];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  const float nf = static_cast<float>(cnt);
+  out[o] = make_float4(sx / nf, sy / nf, sz / nf, 1.0f);
+}
+
 __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ pts, const int* __restrict__ leaf_cell,
                                                      const unsigned* __restrict__ leaf_start,
                                                      const int* __restrict__ leaf_count,
@@ -1662,6 +1695,14 @@ hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, con
 hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,
                                       double* partials, unsigned long long* stamps, hipStream_t stream) {
   hipLaunchKernelGGL(k_derivatives_stamped, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, gv, P, partials, stamps);
+  return hipGetLastError();
+}
+
+hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
+                                  int* sorted_idx, float4* out, hipStream_t stream) {
+  if (n_leaves == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
+                     leaf_count, n_leaves, sorted_idx, out);
   return hipGetLastError();
 }
 

@@ -135,6 +135,8 @@ hipError_t launch_transform(const float4* src, int n, const float* T12, float4* 
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
                              int search, float r2, int n_blocks, double* partials, hipStream_t stream);
 
+hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
+                                  int* sorted_idx, float4* out, hipStream_t stream);
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream);
 hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,

@@ -165,6 +165,23 @@ class NormalDistributionsTransform:
         check(self._L.ndt_calculate_score(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, C.byref(s)))
         return s.value
 
+    # ---- scan prefilter (pcl::VoxelGrid) --------------------------------------------
+    def voxelGridFilter(self, cloud, leaf_size, is_dense=True):
+        """pcl::VoxelGrid::filter on the GPU: (V, 3) float32 centroids in ascending voxel-index order.
+        Raises NdtError(GRID_OVERFLOW) where PCL warns and passes the input through."""
+        a = _cloud(cloud)
+        out = np.zeros((max(a.shape[0], 1), 4), dtype=np.float32)
+        n = C.c_size_t(0)
+        check(self._L.ndt_voxel_grid_filter(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, int(is_dense),
+                                            float(leaf_size), out.ctypes.data, 16, C.byref(n)))
+        return out[:n.value, :3].copy()
+
+    def voxelGridFilterDevice(self, dev_ptr, n, stride_bytes, leaf_size, out_dev_ptr, is_dense=True):
+        m = C.c_size_t(0)
+        check(self._L.ndt_voxel_grid_filter_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense),
+                                                   float(leaf_size), C.c_void_p(out_dev_ptr), C.byref(m)))
+        return m.value
+
     # ---- batch (map-build) ---------------------------------------------------------
     def alignBatch(self, clouds=None, guesses=None, device_ptr=None, offsets=None, stride_bytes=16):
         """Register many sources against the one target in lock-step.
