@@ -144,7 +144,8 @@ struct DeviceCloud {
   DevBuf<float4> sorted;  // lattice-cell order, what the derivative kernels read
   size_t n = 0;
   size_t n_sorted = 0;    // finite points only
-  std::vector<size_t> scan_counts;  // batch uploads: finite points of each scan (sorted in place per scan)
+  std::vector<size_t> scan_counts;  // batch uploads: finite points of each scan ...
+  std::vector<size_t> scan_starts;  // ... and where its ordered segment starts in `sorted`
   const float4* k2_pts() const { return n_sorted ? sorted.p : pts.p; }
   int k2_n() const { return static_cast<int>(n_sorted ? n_sorted : n); }
 };
@@ -192,6 +193,8 @@ struct ndt_context {
   DevBuf<double> batch_out;
   DevBuf<ndt::ScanDesc> descs;
   DevBuf<int> batch_active;  // per kind: indices of the scans that want it this step
+  void* batch_pinned = nullptr;  // pinned staging: [n_scans] ScanDesc + [3 n_scans] int
+  size_t batch_pinned_bytes = 0;
   DevBuf<float4> out_cloud;
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
@@ -226,6 +229,7 @@ struct ndt_context {
   ~ndt_context() {
     if (host_result) (void)hipHostFree(host_result);
     if (server_host_mb) (void)hipHostFree(server_host_mb);
+    if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (stream) (void)hipStreamDestroy(stream);
@@ -366,6 +370,95 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   return NDT_OK;
 }
 
+// All scans of a batch in ONE count/scan/scatter pass: a common lattice over the batch's bounding
+// box, composite key scan * n_cells + cell.  The ordered points of scan k end up contiguous at
+// scan_starts[k] (non-finite points are dropped, so the segments are compacted).
+ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(c->n);
+  c->scan_counts.assign(n_scans, 0);
+  c->scan_starts.assign(n_scans + 1, 0);
+  const int nb = std::min(1024, (ni + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(c->pts.p, ni, 0, d_mm.p, nb, st));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
+      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
+    }
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;
+  ndt::GridGeom geo{};
+  for (float pitch = h->resolution;; pitch *= 2.0f) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      geo.leaf[k] = pitch;
+      geo.inv_leaf[k] = 1.0f / pitch;
+      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+      cells *= geo.div_b[k];
+    }
+    if (cells * static_cast<double>(n_scans) <= 32.0e6) break;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  const long long total_cells = geo.n_cells * static_cast<long long>(n_scans);
+  std::vector<int> off(n_scans + 1);
+  size_t max_scan = 0;
+  for (size_t k = 0; k <= n_scans; k++) off[k] = static_cast<int>(offsets[k] - offsets[0]);
+  for (size_t k = 0; k < n_scans; k++) max_scan = std::max(max_scan, offsets[k + 1] - offsets[k]);
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx, d_off;
+  HIP_TRY(d_off.reserve(n_scans + 1));
+  HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n_scans + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(total_cells) + 1));
+  HIP_TRY(key.reserve(c->n));
+  HIP_TRY(rank.reserve(c->n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, (static_cast<size_t>(total_cells) + 1) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count_batch(c->pts.p, d_off.p, static_cast<int>(n_scans), static_cast<int>(max_scan), geo, key.p, rank.p,
+                                  cell_count.p, st));
+  // one extra (always empty) cell at the end so that its start offset is the grand total
+  const long long scan_cells = total_cells + 1;
+  const int n_tiles = ndt::scan_tiles(scan_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const size_t n_leaves = tot[1];
+  HIP_TRY(lut.reserve(static_cast<size_t>(scan_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(c->n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  // start offset of every scan's first cell (+ the sentinel cell = grand total)
+  std::vector<unsigned> starts(n_scans + 1);
+  HIP_TRY(hipMemcpy2DAsync(starts.data(), sizeof(unsigned), cell_count.p, static_cast<size_t>(geo.n_cells) * sizeof(unsigned),
+                           sizeof(unsigned), n_scans + 1, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_sort_gather(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (size_t k = 0; k < n_scans; k++) {
+    c->scan_starts[k] = starts[k];
+    c->scan_counts[k] = starts[k + 1] - starts[k];
+  }
+  c->scan_starts[n_scans] = starts[n_scans];
+  c->n_sorted = tot[0];
+  return NDT_OK;
+}
+
 ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
   static const bool enabled = [] { const char* v = getenv("NDT_SORT_SOURCE"); return v ? atoi(v) != 0 : true; }();
   c->n_sorted = 0;
@@ -376,16 +469,9 @@ ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
     ndt_status s = order_range(h, c->pts.p, c->n, h->resolution, c->sorted.p, &got);
     if (s) return s;
     c->n_sorted = got;
-  } else {  // every scan of a batch is ordered on its own, in place of its segment
-    c->scan_counts.assign(n_scans, 0);
-    size_t total = 0;
-    for (size_t k = 0; k < n_scans; k++) {
-      const size_t off = offsets[k] - offsets[0], cnt = offsets[k + 1] - offsets[k];
-      ndt_status s = order_range(h, c->pts.p + off, cnt, h->resolution, c->sorted.p + off, &c->scan_counts[k]);
-      if (s) return s;
-      total += c->scan_counts[k];
-    }
-    c->n_sorted = total;
+  } else {
+    ndt_status s = order_batch(h, c, offsets, n_scans);
+    if (s) return s;
   }
   return NDT_OK;
 }
@@ -1129,12 +1215,22 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   if (s) return s;
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   std::vector<ndt::ScanSolver> solvers(n_scans);
-  std::vector<ndt::ScanDesc> descs(n_scans);
+  // per-step descriptors live in pinned host memory: the H2D copies are then truly asynchronous
+  const size_t pinned_need = n_scans * sizeof(ndt::ScanDesc) + 3 * n_scans * sizeof(int);
+  if (pinned_need > h->batch_pinned_bytes) {
+    if (h->batch_pinned) (void)hipHostFree(h->batch_pinned);
+    h->batch_pinned = nullptr;
+    h->batch_pinned_bytes = 0;
+    HIP_TRY(hipHostMalloc(&h->batch_pinned, pinned_need, hipHostMallocDefault));
+    h->batch_pinned_bytes = pinned_need;
+  }
+  ndt::ScanDesc* descs = static_cast<ndt::ScanDesc*>(h->batch_pinned);
+  int* active = reinterpret_cast<int*>(descs + n_scans);
   size_t max_n = 0;
   for (size_t k = 0; k < n_scans; k++) {
     const size_t cnt = offsets[k + 1] - offsets[k];
     solvers[k].start(guesses ? guesses + 16 * k : nullptr, cnt, solver_params(h));
-    descs[k].offset = static_cast<int>(offsets[k] - offsets[0]);
+    descs[k].offset = static_cast<int>(use_sorted ? cloud->scan_starts[k] : offsets[k] - offsets[0]);
     descs[k].count = static_cast<int>(use_sorted ? cloud->scan_counts[k] : cnt);
     descs[k].pad = 0;
     max_n = std::max(max_n, cnt);
@@ -1149,7 +1245,6 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   HIP_TRY(h->batch_active.reserve(3 * n_scans));
   const ndt::GridView gv = h->grid->view();
   const bool degenerate = h->grid->empty;
-  std::vector<int> active(3 * n_scans);
   static const int n_host_threads = [] {
     const char* v = getenv("NDT_HOST_THREADS");
     if (v) return std::max(1, atoi(v));
@@ -1180,8 +1275,8 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     if (degenerate) {
       std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
     } else {
-      HIP_TRY(hipMemcpyAsync(h->descs.p, descs.data(), n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipMemcpyAsync(h->batch_active.p, active.data(), 3 * n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->descs.p, descs, n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->batch_active.p, active, 3 * n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
       if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, h->batch_active.p, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));

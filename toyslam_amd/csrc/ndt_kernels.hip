@@ -239,6 +239,26 @@ __global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts
   }
 }
 
+// Batch variant for the source ordering of many scans at once: blockIdx.y = scan, composite key
+// scan * n_cells + cell, so one count/scan/scatter pass orders every scan inside its own segment.
+__global__ __launch_bounds__(kBlock) void k_count_batch(const float4* __restrict__ pts, const int* __restrict__ scan_off,
+                                                        GridGeom g, int* __restrict__ key, unsigned* __restrict__ rank,
+                                                        unsigned* __restrict__ cell_count) {
+  const int lo = scan_off[blockIdx.y], hi = scan_off[blockIdx.y + 1];
+  const long long base = static_cast<long long>(blockIdx.y) * g.n_cells;
+  for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    int c = -1;
+    if (finite3(p.x, p.y, p.z)) {
+      c = build_cell(g, p.x, p.y, p.z);
+      if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;
+      else c = static_cast<int>(base + c);
+    }
+    key[i] = c;
+    if (c >= 0) rank[i] = atomicAdd(&cell_count[c], 1u);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K1.c  exclusive scan over cells of {points, occupied, candidate} counters
 // ---------------------------------------------------------------------------
@@ -1703,6 +1723,13 @@ hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start,
   if (n_leaves == 0) return hipSuccess;
   hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
                      leaf_count, n_leaves, sorted_idx, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const GridGeom& g,
+                              int* d_key, unsigned* d_rank, unsigned* d_cell_count, hipStream_t stream) {
+  hipLaunchKernelGGL(k_count_batch, dim3(grid_for(max_scan_points, 256), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, g,
+                     d_key, d_rank, d_cell_count);
   return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ struct GridBuildScratch;  // opaque, owned by the grid
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
 hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
                         unsigned* d_cell_count, hipStream_t stream);
+hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const GridGeom& g,
+                              int* d_key, unsigned* d_rank, unsigned* d_cell_count, hipStream_t stream);
 hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
                               int n_tiles, hipStream_t stream);
 hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream);
