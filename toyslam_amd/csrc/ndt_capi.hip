@@ -210,7 +210,12 @@ struct ndt_context {
   size_t out_n = 0;
   // persistent evaluation server (single-scan align)
   bool server_running = false;
-  void* server_host_mb = nullptr;  // pinned command mailbox
+  // Two command mailboxes, used by alternate server instances: a server told to finish (transform +
+  // exit) is not waited for, and the next instance's first command must not overwrite the line the
+  // old one may still be reading.
+  void* server_host_mbs = nullptr;  // pinned, 2 mailboxes
+  void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
+  int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
   DevBuf<unsigned> server_counter;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
@@ -228,7 +233,7 @@ struct ndt_context {
 
   ~ndt_context() {
     if (host_result) (void)hipHostFree(host_result);
-    if (server_host_mb) (void)hipHostFree(server_host_mb);
+    if (server_host_mbs) (void)hipHostFree(server_host_mbs);
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -725,7 +730,7 @@ bool server_enabled() {
 
 ndt_status server_stop(ndt_context* h) {
   if (!h->server_running) return NDT_OK;
-  ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdExit, nullptr);
+  ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdExit, nullptr, nullptr);
   h->server_running = false;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
@@ -734,26 +739,47 @@ ndt_status server_stop(ndt_context* h) {
 ndt_status server_start(ndt_context* h) {
   if (h->server_running) return NDT_OK;
   const int n = h->source->k2_n();
-  if (!h->server_host_mb) {
-    HIP_TRY(hipHostMalloc(&h->server_host_mb, ndt::server_mailbox_bytes(), hipHostMallocDefault));
-    ndt::server_reset_mailbox(h->server_host_mb);
+  const size_t mb_bytes = ndt::server_mailbox_bytes();
+  if (!h->server_host_mbs) {
+    HIP_TRY(hipHostMalloc(&h->server_host_mbs, 2 * mb_bytes, hipHostMallocDefault));
+    std::memset(h->server_host_mbs, 0, 2 * mb_bytes);
   }
   if (!h->server_dev_mb.p) {
-    HIP_TRY(h->server_dev_mb.reserve(ndt::server_mailbox_bytes()));
-    HIP_TRY(hipMemsetAsync(h->server_dev_mb.p, 0, ndt::server_mailbox_bytes(), h->stream));
+    HIP_TRY(h->server_dev_mb.reserve(2 * mb_bytes));
+    HIP_TRY(hipMemsetAsync(h->server_dev_mb.p, 0, 2 * mb_bytes, h->stream));
   }
+  h->server_flip ^= 1;
+  h->server_host_mb = static_cast<unsigned char*>(h->server_host_mbs) + h->server_flip * mb_bytes;
+  ndt::server_reset_mailbox(h->server_host_mb);
+  void* dev_mb = h->server_dev_mb.p + h->server_flip * mb_bytes;
   HIP_TRY(h->server_counter.reserve(32 * 9));  // top counter + 8 shard counters, one per 128-B line
   HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * 9 * sizeof(unsigned), h->stream));
   // one 512-thread block per CU at most: every block must be resident for the round to complete
   int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + 511) / 512));
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
+  const int n_out = static_cast<int>(h->source->n);
+  HIP_TRY(h->out_cloud.reserve(n_out));
   const unsigned long long idle_ticks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
-  HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, h->server_dev_mb.p,
-                                  nblk, h->partials.p, h->server_counter.p, h->host_result, h->eval_seq + 1, idle_ticks,
-                                  h->stream, h->server_want_dbg ? h->server_dbg.p : nullptr));
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  const float r2 = kd_radius2(h->resolution);
+  int pad_bits;
+  std::memcpy(&pad_bits, &r2, sizeof(int));
+  HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
+                                  h->partials.p, h->server_counter.p, h->host_result, h->eval_seq + 1, idle_ticks, gs.d1,
+                                  gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
+                                  h->server_want_dbg ? h->server_dbg.p : nullptr));
   h->server_running = true;
   return NDT_OK;
+}
+
+// last command of a registration: the server writes the aligned cloud (source x T) and exits; the
+// caller does not wait (everything later on h->stream is ordered behind the server kernel)
+void server_finish(ndt_context* h, const float* T_colmajor) {
+  float T12[12];
+  colmajor_to_T12(T_colmajor, T12);
+  ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdTransformExit, T12, nullptr);
+  h->server_running = false;
 }
 
 // one evaluation through the running server; *served = false means the server had given up
@@ -761,10 +787,13 @@ ndt_status server_start(ndt_context* h) {
 ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::EvalResult& res,
                            double* nn_total, bool* served) {
   *served = false;
-  ndt::EvalParams P;
-  fill_eval_params(rq, gs, kd_radius2(h->resolution), P);
+  (void)gs;
+  float T12[12];
+  colmajor_to_T12(rq.T, T12);
+  double cs[6];
+  ndt::snapped_cos_sin(rq.p, cs);
   const unsigned long long seq = ++h->eval_seq;
-  ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), &P);
+  ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), T12, cs);
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
@@ -992,13 +1021,10 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
     double nn_step = 0;
     const bool counts_neighbors = solver.request().kind != ndt::EVAL_HESSIAN_F64;
     bool served = false;
-    if (use_server && counts_neighbors) {
+    if (use_server) {
       s = server_start(h);
       if (s) return s;
       s = server_evaluate(h, solver.request(), gs_align, r, &nn_step, &served);
-      if (s) return s;
-    } else if (h->server_running) {
-      s = server_stop(h);  // the f64 Hessian runs as an ordinary launch
       if (s) return s;
     }
     if (!served) {
@@ -1010,8 +1036,6 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
     solver.feed(r);
     h->t_solver += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
   }
-  s = server_stop(h);
-  if (s) return s;
   static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   if (timing) {
     std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus (per align)\n", solver.n_evals + solver.n_hess,
@@ -1027,17 +1051,23 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   h->mean_neighbors = h->source->n ? nn / static_cast<double>(h->source->n) : 0.0;
   // the aligned cloud = source transformed by the last trial's matrix (trans_cloud of :833/:878)
   const int n = static_cast<int>(h->source->n);
-  HIP_TRY(h->out_cloud.reserve(n));
-  float T12[12];
-  colmajor_to_T12(h->final_T, T12);
-  HIP_TRY(ndt::launch_transform(h->source->pts.p, n, T12, h->out_cloud.p, h->stream));
+  if (h->server_running) {
+    server_finish(h, h->final_T);  // the server writes it on its way out
+  } else {
+    HIP_TRY(h->out_cloud.reserve(n));
+    float T12[12];
+    colmajor_to_T12(h->final_T, T12);
+    HIP_TRY(ndt::launch_transform(h->source->pts.p, n, T12, h->out_cloud.p, h->stream));
+  }
   h->out_n = n;
   if (out_cloud && n) {
     if (out_stride_bytes < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
     HIP_TRY(hipMemcpy2DAsync(out_cloud, out_stride_bytes, h->out_cloud.p, sizeof(float4), sizeof(float4), n,
                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  // without a host copy nothing waits here: the cloud is complete in stream order (ndt_get_output_device
+  // synchronises before handing the pointer out)
   return ndt_get_result(h, final_transformation, has_converged, final_num_iteration, transformation_probability);
 }
 
@@ -1053,6 +1083,7 @@ ndt_status ndt_get_result(ndt_handle h, float* final_transformation, int* has_co
 
 ndt_status ndt_get_output_device(ndt_handle h, const void** d_cloud, size_t* n) {
   if (!h || !d_cloud || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->device_ready) HIP_TRY(hipStreamSynchronize(h->stream));  // ndt_align does not wait for the cloud
   *d_cloud = h->out_cloud.p;
   *n = h->out_n;
   return NDT_OK;
@@ -1451,8 +1482,8 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   ndt::EvalRequest rq;
   std::memcpy(rq.p, p, sizeof(rq.p));
   ndt::pose_to_matrix(p, rq.T);
-  HIP_TRY(h->server_dbg.reserve(8 + 2 * 1024));
-  HIP_TRY(hipMemsetAsync(h->server_dbg.p, 0, (8 + 2 * 1024) * sizeof(unsigned long long), h->stream));
+  HIP_TRY(h->server_dbg.reserve(8 + 10 * 1024));
+  HIP_TRY(hipMemsetAsync(h->server_dbg.p, 0, (8 + 10 * 1024) * sizeof(unsigned long long), h->stream));
   h->server_want_dbg = true;
   s = server_start(h);
   h->server_want_dbg = false;
@@ -1476,7 +1507,7 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   s = server_stop(h);
   if (s) return s;
   {  // device-side stamps of the LAST round (with Hessian), s_memrealtime ticks of 10 ns
-    std::vector<unsigned long long> d(8 + 2 * 1024);
+    std::vector<unsigned long long> d(8 + 10 * 1024);
     HIP_TRY(hipMemcpy(d.data(), h->server_dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (h->source->k2_n() + 511) / 512));
     unsigned long long got_min = ~0ull, got_max = 0, tk_min = ~0ull, tk_max = 0;
@@ -1485,6 +1516,12 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
       tk_min = std::min(tk_min, d[9 + 2 * b]); tk_max = std::max(tk_max, d[9 + 2 * b]);
     }
     auto us_of = [&](unsigned long long t) { return (static_cast<double>(t) - static_cast<double>(d[0])) * 0.01; };
+    if (const char* path = getenv("NDT_DIAG_DUMP")) {  // raw stamps for offline analysis
+      if (FILE* f = std::fopen(path, "wb")) {
+        std::fwrite(d.data(), sizeof(unsigned long long), d.size(), f);
+        std::fclose(f);
+      }
+    }
     std::fprintf(stderr, "[server stamps, us after the relay saw the command] relayed %.2f | blocks have params %.2f..%.2f | tickets %.2f..%.2f | final sum starts %.2f | published %.2f  (%d blocks)\n",
                  us_of(d[1]), us_of(got_min), us_of(got_max), us_of(tk_min), us_of(tk_max), us_of(d[2]), us_of(d[3]), nblk);
   }

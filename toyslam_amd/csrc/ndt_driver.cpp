@@ -206,6 +206,18 @@ void matrix_to_pose(const float T[16], double p[6]) {
 }
 
 // ---------------------------------------------------------------------------
+void snapped_cos_sin(const double p[6], double cs[6]) {
+  for (int k = 0; k < 3; k++) {
+    if (std::fabs(p[3 + k]) < 10e-5) {
+      cs[k] = 1.0;
+      cs[3 + k] = 0.0;
+    } else {
+      cs[k] = std::cos(p[3 + k]);
+      cs[3 + k] = std::sin(p[3 + k]);
+    }
+  }
+}
+
 void angle_derivatives(const double p[6], AngleDerivs& o) {
   // ndt_omp_impl.hpp:292-326: |angle| < 10e-5 snaps to cos = 1, sin = 0
   double c[3], s[3];

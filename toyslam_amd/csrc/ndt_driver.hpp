@@ -37,6 +37,8 @@ struct AngleDerivs {
   double hd[15][3];
 };
 void angle_derivatives(const double p[6], AngleDerivs& out);
+// cos / sin of roll, pitch, yaw with the reference's snap (|angle| < 10e-5 -> 1, 0): cx cy cz sx sy sz
+void snapped_cos_sin(const double p[6], double cs[6]);
 
 enum EvalKind { EVAL_WITH_HESSIAN = 0, EVAL_NO_HESSIAN = 1, EVAL_HESSIAN_F64 = 2, EVAL_NONE = 3 };
 

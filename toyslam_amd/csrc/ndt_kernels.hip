@@ -26,6 +26,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
 
 namespace ndt {
 
@@ -1245,178 +1246,6 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
 // worker that sees no command for 4x that budget leaves on its own.  The grid therefore always
 // drains, whatever the host does.  gridDim.x must not exceed the number of co-resident blocks.
 // ---------------------------------------------------------------------------
-constexpr int kServerTPB = 512;
-constexpr int kCmdExit = 0x7fffffff;
-constexpr int kParamWords = static_cast<int>(sizeof(EvalParams) / 4);
-
-// Command mailbox (same layout in pinned host memory and in device memory).  The host writes the
-// parameter image, then `kind`, then `seq` (x86 stores are ordered); only the line holding `seq`
-// is polled, by ONE lane, so the CPU's stores to the parameter lines never fight device snoops.
-// (Measured alternatives that were slower: sweeping the whole mailbox as tagged 8-byte granules on
-// every poll, by the relay +7 us and by all blocks +4 us per command; a single polled 128-byte
-// command line +8 us -- the CPU's burst of stores then contends with the polling reads.)
-struct ServerMailbox {
-  unsigned params[96];            // EvalParams image (kParamWords used)
-  int kind;                       // 0 = with Hessian, 1 = without, 3 = no-op round, kCmdExit
-  int pad0;
-  unsigned long long seq;         // written last
-  unsigned long long dead;        // host mailbox only: server gave up waiting
-};
-
-template <int NNB>
-__global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __restrict__ src, int n, GridView gv,
-                                                            ServerMailbox* host_mb, ServerMailbox* dev_mb,
-                                                            double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                            double* __restrict__ out_row, unsigned long long first_seq,
-                                                            unsigned long long idle_ticks, unsigned long long* dbg) {
-  constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
-  __shared__ double lds[kWaves * 32];
-  __shared__ double lds2[kParts * kEvalStride];
-  __shared__ EvalParams sP;
-  __shared__ int s_kind;
-  __shared__ int s_last;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  unsigned long long expect = first_seq;
-
-  for (;;) {
-    // ---- relay: host mailbox -> device mailbox (wave 0 of block 0) ----
-    if (blockIdx.x == 0 && wave == 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      int kind = kCmdExit;
-      bool got = false;
-      for (;;) {
-        unsigned long long sq = 0;
-        if (lane == 0) sq = __hip_atomic_load(&host_mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        sq = __shfl(sq, 0, kWave);
-        if (sq == expect) { got = true; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      const unsigned long long dbg_seen = __builtin_amdgcn_s_memrealtime();
-      unsigned w0 = 0, w1 = 0;
-      if (got) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        w0 = __hip_atomic_load(&host_mb->params[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane + 64 < 96) w1 = __hip_atomic_load(&host_mb->params[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane == 0) kind = __hip_atomic_load(&host_mb->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        kind = __shfl(kind, 0, kWave);
-      } else if (lane == 0) {
-        __hip_atomic_store(&host_mb->dead, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      __hip_atomic_store(&dev_mb->params[lane], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane + 64 < 96) __hip_atomic_store(&dev_mb->params[lane + 64], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0) __hip_atomic_store(&dev_mb->kind, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&dev_mb->seq, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dbg && lane == 0 && kind != kCmdExit) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
-    }
-    // ---- every block: wait for the device mailbox ----
-    if (wave == 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      int kind = kCmdExit;
-      bool got = false;
-      for (;;) {
-        unsigned long long sq = 0;
-        if (lane == 0) sq = __hip_atomic_load(&dev_mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sq = __shfl(sq, 0, kWave);
-        if (sq == expect) { got = true; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 4 * idle_ticks) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (got) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* dp = reinterpret_cast<unsigned*>(&sP);
-        const unsigned w0 = __hip_atomic_load(&dev_mb->params[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane < kParamWords) dp[lane] = w0;
-        if (lane + 64 < kParamWords) dp[lane + 64] = __hip_atomic_load(&dev_mb->params[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) kind = __hip_atomic_load(&dev_mb->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) s_kind = kind;
-      if (dbg && lane == 0 && kind != kCmdExit) dbg[8 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its parameters
-    }
-    __syncthreads();
-    const int kind = s_kind;
-    if (kind != 0 && kind != 1 && kind != 3) return;  // EXIT or time-out: the whole block leaves together (3 = no-op round)
-
-    // ---- evaluate ----
-    double acc[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    const int first = blockIdx.x * kServerTPB + threadIdx.x, stride = gridDim.x * kServerTPB;
-    if (NNB == 27) {
-      if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);
-    } else {
-      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
-    }
-    const double tot = wave_fold<kNumAcc>(acc);
-    if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
-    __syncthreads();
-    if (wave == 0) {
-      if (lane < kEvalStride) {
-        double v = 0.0;
-        if (lane < kNumAcc) {
-          v = lds[lane];
-#pragma unroll
-          for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
-        }
-        __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        // Two-level fan-in: 8 shard counters (blocks b and b+8 usually share an XCD; only speed
-        // depends on that) and one top counter.  ~200 returning atomics on ONE word serialise at
-        // ~13 ns each (measured 2.5-3 us of arrival skew); sharded, the longest chain is ~25+8.
-        // Counters live 128 B apart and are never reset inside a launch.
-        const unsigned round = static_cast<unsigned>(expect - first_seq);
-        const unsigned shard = blockIdx.x & 7u;
-        const unsigned in_shard = (gridDim.x + 7u - shard) / 8u;  // blocks with this residue
-        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = 0;
-        if (t1 == (round + 1u) * in_shard - 1u) {
-          const unsigned n_shards = gridDim.x < 8u ? gridDim.x : 8u;
-          const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = (t2 == (round + 1u) * n_shards - 1u) ? 1 : 0;
-        }
-        s_last = last;
-        if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
-      }
-    }
-    __syncthreads();
-    if (s_last) {
-      if (dbg && threadIdx.x == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
-        __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
-      const int n_blocks = gridDim.x;
-      double v = 0.0;
-      int b = part;
-      for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {
-        const double a0 = __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a1 = __hip_atomic_load(partials + static_cast<size_t>(b + kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a2 = __hip_atomic_load(partials + static_cast<size_t>(b + 2 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a3 = __hip_atomic_load(partials + static_cast<size_t>(b + 3 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v += a0; v += a1; v += a2; v += a3;
-      }
-      for (; b < n_blocks; b += kParts)
-        v += __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lds2[part * kEvalStride + k] = v;
-      __syncthreads();
-      if (threadIdx.x < kEvalStride) {
-        double t = 0.0;
-#pragma unroll
-        for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
-        publish_row(out_row, t, expect);
-        if (dbg && threadIdx.x == 0)  // published
-          __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
-    expect++;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // computeHessian / updateHessian, all f64 (ndt_omp_impl.hpp:540-645, 443-481)
 // acc layout identical to k_derivatives (only [7..27] are written).
@@ -1466,6 +1295,46 @@ __device__ __forceinline__ void finish_point64(double (&acc)[kNumAcc], const Poi
     for (int b = a; b < 3; b++) acc[idx++] += ((B[0][a] * AB[0][b] + B[1][a] * AB[1][b]) + B[2][a] * AB[2][b]) + X[a][b];
 }
 
+// all-f64 Hessian contributions (computeHessian / updateHessian, ndt_omp_impl.hpp:584-645) of the
+// points first, first + stride, ... into acc
+template <int NNB>
+__device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, int n, const GridView& gv,
+                                               const Hess64Params& prm, int first, int stride, double (&acc)[kNumAcc]) {
+  for (int i = first; i < n; i += stride) {
+    const float4 pt = src[i];
+    float tx, ty, tz;
+    xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    int vi, vj, vk;
+    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
+    if (!near_grid(gv.g, vi, vj, vk)) continue;
+    PointAcc64 pa = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
+    for (int k = 0; k < NNB; k++) {
+      int dx, dy, dz;
+      nb_offset<NNB>(k, dx, dy, dz);
+      const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
+                                  : probe(gv, vi, vj, vk, dx, dy, dz);
+      if (rix < 0) continue;
+      const RecRegs r = load_rec(gv.recs, rix);
+      // the record keeps icov in its f32 rounding (DESIGN.md)
+      const double c00 = r.c00, c01 = r.c01, c02 = r.c02, c11 = r.c11, c12 = r.c12, c22 = r.c22;
+      const double x0 = static_cast<double>(tx) - r.mx, x1 = static_cast<double>(ty) - r.my, x2 = static_cast<double>(tz) - r.mz;
+      const double xc0 = (c00 * x0 + c01 * x1) + c02 * x2;
+      const double xc1 = (c01 * x0 + c11 * x1) + c12 * x2;
+      const double xc2 = (c02 * x0 + c12 * x1) + c22 * x2;
+      double e = prm.d2 * exp(-prm.d2 * ((x0 * xc0 + x1 * xc1) + x2 * xc2) / 2);  // :622
+      if (e > 1 || e < 0 || e != e) continue;                                      // :625-626
+      e *= prm.d1;
+      any = true;
+      pa.xe0 += e * xc0; pa.xe1 += e * xc1; pa.xe2 += e * xc2;
+      const double t0 = (-prm.d2 * e) * xc0, t1 = (-prm.d2 * e) * xc1, t2 = (-prm.d2 * e) * xc2;
+      pa.a00 += e * c00 + t0 * xc0; pa.a01 += e * c01 + t0 * xc1; pa.a02 += e * c02 + t0 * xc2;
+      pa.a11 += e * c11 + t1 * xc1; pa.a12 += e * c12 + t1 * xc2; pa.a22 += e * c22 + t2 * xc2;
+    }
+    if (any) finish_point64(acc, pa, prm, pt.x, pt.y, pt.z);
+  }
+}
+
 template <int NNB, bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__ src, int n, GridView gv, Hess64Params P,
                                                       const ScanDesc* __restrict__ descs, const int* __restrict__ active,
@@ -1488,40 +1357,276 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     prm = &sP;
   }
   double* out = partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 pt = src[i];
-    float tx, ty, tz;
-    xform_point(prm->T, pt.x, pt.y, pt.z, tx, ty, tz);
-    int vi, vj, vk;
-    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
-    if (!near_grid(gv.g, vi, vj, vk)) continue;
-    PointAcc64 pa = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool any = false;
-    for (int k = 0; k < NNB; k++) {
-      int dx, dy, dz;
-      nb_offset<NNB>(k, dx, dy, dz);
-      const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, tx, ty, tz, static_cast<float>(prm->r2))
-                                  : probe(gv, vi, vj, vk, dx, dy, dz);
-      if (rix < 0) continue;
-      const RecRegs r = load_rec(gv.recs, rix);
-      // the record keeps icov in its f32 rounding (DESIGN.md)
-      const double c00 = r.c00, c01 = r.c01, c02 = r.c02, c11 = r.c11, c12 = r.c12, c22 = r.c22;
-      const double x0 = static_cast<double>(tx) - r.mx, x1 = static_cast<double>(ty) - r.my, x2 = static_cast<double>(tz) - r.mz;
-      const double xc0 = (c00 * x0 + c01 * x1) + c02 * x2;
-      const double xc1 = (c01 * x0 + c11 * x1) + c12 * x2;
-      const double xc2 = (c02 * x0 + c12 * x1) + c22 * x2;
-      double e = prm->d2 * exp(-prm->d2 * ((x0 * xc0 + x1 * xc1) + x2 * xc2) / 2);  // :622
-      if (e > 1 || e < 0 || e != e) continue;                                        // :625-626
-      e *= prm->d1;
-      any = true;
-      pa.xe0 += e * xc0; pa.xe1 += e * xc1; pa.xe2 += e * xc2;
-      const double t0 = (-prm->d2 * e) * xc0, t1 = (-prm->d2 * e) * xc1, t2 = (-prm->d2 * e) * xc2;
-      pa.a00 += e * c00 + t0 * xc0; pa.a01 += e * c01 + t0 * xc1; pa.a02 += e * c02 + t0 * xc2;
-      pa.a11 += e * c11 + t1 * xc1; pa.a12 += e * c12 + t1 * xc2; pa.a22 += e * c22 + t2 * xc2;
-    }
-    if (any) finish_point64(acc, pa, *prm, pt.x, pt.y, pt.z);
-  }
+  hessian64_body<NNB>(src, n, gv, *prm, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, acc);
   block_reduce_store<kNumAcc>(acc, out, lds);
+}
+
+constexpr int kServerTPB = 512;
+constexpr int kCmdExit = 0x7fffffff;
+constexpr int kCmdTransformExit = 4;  // transform the source by T into the output cloud, then exit
+
+// Command = ONE 128-byte block of pinned host memory, two 64-byte lines, each ending in the
+// command's sequence number:
+//   line A: T[12] (3x4 f32 transform, 48 B) | kind (4 B) | pad (4 B) | seq (8 B)
+//   line B: cos/sin of roll, pitch, yaw after the 1e-4 snap (6 f64, 48 B) | pad (8 B) | seq (8 B)
+// The host fills it with non-temporal stores (one full-line write per line: no read-for-ownership,
+// so the CPU never fights the device's polling reads for the line) and the sequence number is the
+// last 8 bytes of each line, so a line whose tag matches is complete.  The relay's poll (one
+// 16-lane load) IS the data read; it forwards the 128 bytes to the device mailbox in one store.
+// The 69 angle-derivative coefficients (computeAngleDerivatives, ndt_omp_impl.hpp:288-395) are a
+// function of those six values; every block recomputes them (bit-identical to the host's: same
+// f64 inputs, same operation order, contraction off) instead of fetching 344 B of tables.
+// (Measured alternatives that were slower: tagged-granule sweeps of a 700-B mailbox on every poll,
+// +4..7 us per command; a polled line written with ordinary stores, +8 us.)
+struct ServerMailbox {
+  unsigned long long cmd[16];
+  unsigned long long dead;  // host mailbox only: server gave up waiting (own line)
+  unsigned long long pad[15];
+};
+
+// 69 entries (j_ang 8x3 then h_ang 15x3): value = s1*f[a1]*f[b1]*f[c1] + s2*f[a2]*f[b2]*f[c2],
+// f = {1, sx, cx, sy, cy, sz, cz}; generated from the expressions of ndt_omp_impl.hpp:329-393
+__device__ __constant__ signed char kAngleTerms[69][8] = {
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 1, 6, 0, -1, 2, 3, 5}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 2, 5, 0, 1, 1, 3, 6}, {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 1, 4, 0, 0, 0, 0, 0},
+    {-1, 3, 6, 0, 0, 0, 0, 0}, {1, 3, 5, 0, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0, 0, 0},
+    {1, 1, 4, 6, 0, 0, 0, 0}, {-1, 1, 4, 5, 0, 0, 0, 0}, {1, 1, 3, 0, 0, 0, 0, 0},
+    {-1, 2, 4, 6, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0}, {-1, 2, 3, 0, 0, 0, 0, 0},
+    {-1, 4, 5, 0, 0, 0, 0, 0}, {-1, 4, 6, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 2, 5, 0, -1, 1, 3, 6}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 1, 6, 0, 1, 2, 3, 5}, {1, 2, 3, 6, -1, 1, 5, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 2, 5, 0, -1, 1, 3, 6}, {-1, 2, 6, 0, 1, 1, 3, 5}, {1, 1, 4, 0, 0, 0, 0, 0},
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 2, 3, 5, -1, 1, 6, 0}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 2, 4, 6, 0, 0, 0, 0}, {-1, 2, 4, 5, 0, 0, 0, 0}, {1, 2, 3, 0, 0, 0, 0, 0},
+    {1, 1, 4, 6, 0, 0, 0, 0}, {-1, 1, 4, 5, 0, 0, 0, 0}, {1, 1, 3, 0, 0, 0, 0, 0},
+    {-1, 1, 6, 0, -1, 2, 3, 5}, {1, 1, 5, 0, -1, 2, 3, 6}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 1, 3, 6, -1, 2, 5, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 4, 6, 0, 0, 0, 0, 0}, {1, 4, 5, 0, 0, 0, 0, 0}, {-1, 3, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 3, 6, 0, 0, 0, 0}, {1, 1, 3, 5, 0, 0, 0, 0}, {1, 1, 4, 0, 0, 0, 0, 0},
+    {1, 2, 3, 6, 0, 0, 0, 0}, {-1, 2, 3, 5, 0, 0, 0, 0}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 3, 5, 0, 0, 0, 0, 0}, {1, 3, 6, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 4, 5, 0, 0, 0, 0}, {-1, 1, 4, 6, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 4, 5, 0, 0, 0, 0}, {1, 2, 4, 6, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 4, 6, 0, 0, 0, 0, 0}, {1, 4, 5, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 2, 5, 0, -1, 1, 3, 6}, {-1, 2, 6, 0, 1, 1, 3, 5}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 2, 3, 5, -1, 1, 6, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+};
+
+// one coefficient of the f64 vectors j_ang_* (e < 24) / h_ang_* (e >= 24) from f = {1,sx,cx,sy,cy,sz,cz}
+__device__ __forceinline__ double angle_coefficient_f64(int e, const double* f) {
+#pragma clang fp contract(off)
+  const signed char* t = kAngleTerms[e];
+  const double t1 = ((static_cast<double>(t[0]) * f[t[1]]) * f[t[2]]) * f[t[3]];
+  const double t2 = ((static_cast<double>(t[4]) * f[t[5]]) * f[t[6]]) * f[t[7]];
+  return t1 + t2;
+}
+// the f32 matrices j_ang / h_ang hold the same values rounded, except h_ang row d1, z: +sy (:383)
+// where the f64 vector has -sy (:361)
+__device__ __forceinline__ float angle_coefficient(int e, const double* f) {
+  const double v = (e == 24 + 6 * 3 + 2) ? f[3] : angle_coefficient_f64(e, f);
+  return static_cast<float>(v);
+}
+
+template <int NNB>
+__global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __restrict__ src, int n, GridView gv,
+                                                            ServerMailbox* host_mb, ServerMailbox* dev_mb,
+                                                            double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                            double* __restrict__ out_row, unsigned long long first_seq,
+                                                            unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
+                                                            int param_pad, const float4* __restrict__ out_src,
+                                                            float4* __restrict__ out_dst, int out_n, unsigned long long* dbg) {
+  constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ double lds2[kParts * kEvalStride];
+  __shared__ EvalParams sP;
+  __shared__ Hess64Params sP64;
+  __shared__ double s_f[8];  // 1, sx, cx, sy, cy, sz, cz
+  __shared__ int s_kind;
+  __shared__ int s_last;
+  unsigned long long expect = first_seq;
+  if (threadIdx.x == 0) {
+    sP.d1 = gauss_d1;
+    sP.d2 = static_cast<float>(gauss_d2);
+    sP.pad = param_pad;
+    sP64.d1 = gauss_d1;
+    sP64.d2 = gauss_d2;
+    sP64.r2 = static_cast<double>(__int_as_float(param_pad));
+  }
+
+  for (;;) {
+    // Nothing but `expect` is meant to live across rounds: opaque copies keep the compiler from
+    // hoisting per-round address arithmetic out of the loop (it did, ran out of registers and
+    // spilled those values to scratch, whose reloads sat on the round's critical path).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    asm volatile("" : "+s"(host_mb), "+s"(dev_mb), "+s"(partials), "+s"(counter), "+s"(out_row), "+s"(dbg), "+s"(src));
+    // ---- relay: host mailbox -> device mailbox (wave 0 of block 0) ----
+    if (blockIdx.x == 0 && wave == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long w = 0;
+      bool got = false;
+      for (;;) {  // one 16-lane load = two 64-byte PCIe reads; the poll IS the data read
+        if (lane < 16) w = __hip_atomic_load(&host_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__shfl(w, 7, kWave) == expect && __shfl(w, 15, kWave) == expect) { got = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) break;
+      }
+      const unsigned long long dbg_seen = __builtin_amdgcn_s_memrealtime();
+      if (!got) {  // idle for too long: tell the host, send everybody home
+        if (lane == 0) __hip_atomic_store(&host_mb->dead, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w = (lane == 6) ? static_cast<unsigned long long>(static_cast<unsigned>(kCmdExit)) : ((lane == 7 || lane == 15) ? expect : 0ull);
+      }
+      if (lane < 16) __hip_atomic_store(&dev_mb->cmd[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg && got && static_cast<int>(static_cast<unsigned>(__shfl(w, 6, kWave))) != kCmdExit && lane == 0) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
+    }
+    // ---- every block: wait for the device command block ----
+    if (wave == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long w = 0;
+      bool got = false;
+      for (;;) {
+        if (lane < 16) w = __hip_atomic_load(&dev_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__shfl(w, 7, kWave) == expect && __shfl(w, 15, kWave) == expect) { got = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 4 * idle_ticks) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      int kind = kCmdExit;
+      if (got) {
+        kind = static_cast<int>(static_cast<unsigned>(__shfl(w, 6, kWave)));
+        if (lane < 6) {  // T[12]
+          const float t_lo = __int_as_float(static_cast<int>(static_cast<unsigned>(w)));
+          const float t_hi = __int_as_float(static_cast<int>(static_cast<unsigned>(w >> 32)));
+          sP.T[2 * lane] = t_lo;
+          sP.T[2 * lane + 1] = t_hi;
+          sP64.T[2 * lane] = t_lo;
+          sP64.T[2 * lane + 1] = t_hi;
+        }
+        if (lane >= 8 && lane < 14) {  // cx cy cz sx sy sz -> f = {1, sx, cx, sy, cy, sz, cz}
+          const double v = __longlong_as_double(static_cast<long long>(w));
+          const int a = lane - 8;  // 0..2 cos, 3..5 sin
+          s_f[(a < 3) ? 2 + 2 * a : 1 + 2 * (a - 3)] = v;
+        }
+        if (lane == 0) { s_f[0] = 1.0; s_f[7] = 0.0; }
+      }
+      if (lane == 0) {
+        s_kind = kind;
+        if (dbg && kind != kCmdExit) dbg[8 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its command
+      }
+    }
+    __syncthreads();
+    const int kind = s_kind;
+    if (kind == kCmdTransformExit) {  // last command of a registration: write the aligned cloud, then leave
+      for (int i = blockIdx.x * kServerTPB + tid; i < out_n; i += gridDim.x * kServerTPB) {
+        const float4 pt = out_src[i];
+        float tx, ty, tz;
+        xform_point(sP.T, pt.x, pt.y, pt.z, tx, ty, tz);
+        out_dst[i] = make_float4(tx, ty, tz, 1.0f);
+      }
+      return;
+    }
+    if (kind < 0 || kind > 3) return;  // EXIT or time-out: the whole block leaves together (3 = no-op round)
+    if (tid < 69) {
+      if (kind == 2) {  // f64 vectors of computeHessian (:329-361, -sy in row d1)
+        const double c = angle_coefficient_f64(tid, s_f);
+        if (tid < 24) sP64.jd[tid / 3][tid % 3] = c;
+        else sP64.hd[(tid - 24) / 3][(tid - 24) % 3] = c;
+      } else {
+        const float c = angle_coefficient(tid, s_f);
+        if (tid < 24) sP.j[tid / 3][tid % 3] = c;
+        else sP.h[(tid - 24) / 3][(tid - 24) % 3] = c;
+      }
+    }
+    __syncthreads();
+    unsigned long long* fine = dbg ? dbg + 8 + 2 * 1024 + 8 * blockIdx.x : nullptr;  // diagnostics: per-block phase stamps
+    if (fine && tid == 0) fine[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- evaluate ----
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int first = blockIdx.x * kServerTPB + tid, stride = gridDim.x * kServerTPB;
+    if (kind == 2) {
+      // rare round (at most one per Newton iteration): keep its loop invariants from being hoisted
+      // into registers the hot rounds need (the opaque copy of `first` pins them inside the branch)
+      int first64 = first;
+      asm volatile("" : "+v"(first64));
+      hessian64_body<NNB>(src, n, gv, sP64, first64, stride, acc);
+    } else if (NNB == 27) {
+      if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);
+    } else {
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+    }
+    if (fine && tid == 0) fine[1] = __builtin_amdgcn_s_memrealtime();
+    const double tot = wave_fold<kNumAcc>(acc);
+    if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+    if (fine && tid == 0) fine[2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (wave == 0) {
+      if (fine && lane == 0) fine[3] = __builtin_amdgcn_s_memrealtime();
+      if (lane < kEvalStride) {
+        double v = 0.0;
+        if (lane < kNumAcc) {
+          v = lds[lane];
+#pragma unroll
+          for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+        }
+        __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (fine && lane == 0) fine[4] = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) {
+        // Two-level fan-in: 8 shard counters (blocks b and b+8 usually share an XCD; only speed
+        // depends on that) and one top counter.  ~200 returning atomics on ONE word serialise at
+        // ~13 ns each (measured 2.5-3 us of arrival skew); sharded, the longest chain is ~25+8.
+        // Counters live 128 B apart and are never reset inside a launch.
+        const unsigned round = static_cast<unsigned>(expect - first_seq);
+        const unsigned shard = blockIdx.x & 7u;
+        const unsigned in_shard = (gridDim.x + 7u - shard) / 8u;  // blocks with this residue
+        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (t1 == (round + 1u) * in_shard - 1u) {
+          const unsigned n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+          const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = (t2 == (round + 1u) * n_shards - 1u) ? 1 : 0;
+        }
+        s_last = last;
+        if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
+      }
+    }
+    __syncthreads();
+    if (s_last) {
+      if (dbg && tid == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
+        __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int k = tid % kEvalStride, part = tid / kEvalStride;
+      const int n_blocks = gridDim.x;
+      double v = 0.0;
+      int b = part;
+      for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {
+        const double a0 = __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a1 = __hip_atomic_load(partials + static_cast<size_t>(b + kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a2 = __hip_atomic_load(partials + static_cast<size_t>(b + 2 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double a3 = __hip_atomic_load(partials + static_cast<size_t>(b + 3 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += a0; v += a1; v += a2; v += a3;
+      }
+      for (; b < n_blocks; b += kParts)
+        v += __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lds2[part * kEvalStride + k] = v;
+      __syncthreads();
+      if (tid < kEvalStride) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + tid];
+        publish_row(out_row, t, expect);
+        if (dbg && tid == 0)  // published
+          __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
+    expect++;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1800,12 +1905,21 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
 
 size_t server_mailbox_bytes() { return sizeof(ServerMailbox); }
 
-// host side of the mailbox protocol (pinned, coherent host memory)
-void server_post(void* host_mailbox, unsigned long long seq, int kind, const EvalParams* P) {
+// host side of the mailbox protocol (pinned, coherent host memory): the 128-byte command is built
+// locally and written with non-temporal 16-byte stores, one full-line write per 64-byte line
+void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6) {
   ServerMailbox* mb = static_cast<ServerMailbox*>(host_mailbox);
-  if (P) std::memcpy(mb->params, P, sizeof(EvalParams));
-  mb->kind = kind;
-  __atomic_store_n(&mb->seq, seq, __ATOMIC_RELEASE);
+  alignas(64) unsigned long long c[16];
+  std::memset(c, 0, sizeof(c));
+  if (T12) std::memcpy(&c[0], T12, 12 * sizeof(float));
+  const unsigned k = static_cast<unsigned>(kind);
+  c[6] = k;
+  c[7] = seq;
+  if (cos_sin6) std::memcpy(&c[8], cos_sin6, 6 * sizeof(double));
+  c[15] = seq;
+  for (int i = 0; i < 8; i++)
+    _mm_stream_si128(reinterpret_cast<__m128i*>(&mb->cmd[2 * i]), _mm_load_si128(reinterpret_cast<const __m128i*>(&c[2 * i])));
+  _mm_sfence();
 }
 unsigned long long server_dead_word(const void* host_mailbox) {
   return __atomic_load_n(&static_cast<const ServerMailbox*>(host_mailbox)->dead, __ATOMIC_ACQUIRE);
@@ -1814,22 +1928,23 @@ void server_reset_mailbox(void* host_mailbox) { std::memset(host_mailbox, 0, siz
 
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
-                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream,
+                              unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
+                              int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
                               unsigned long long* dbg) {
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 0)
     hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, dbg);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
   else if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, dbg);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
   else if (search == 3)
     hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, dbg);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
   else
     hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, dbg);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
   return hipGetLastError();
 }
 

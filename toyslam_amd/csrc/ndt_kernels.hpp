@@ -118,13 +118,15 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
                                     unsigned long long seq, hipStream_t stream);
 // Persistent evaluation server (one launch per align): see ndt_kernels.hip.
 constexpr int kServerCmdExit = 0x7fffffff;
+constexpr int kServerCmdTransformExit = 4;  // write the aligned cloud with the command's transform, then exit
 size_t server_mailbox_bytes();
 void server_reset_mailbox(void* host_mailbox);
-void server_post(void* host_mailbox, unsigned long long seq, int kind, const EvalParams* P);
+void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6);
 unsigned long long server_dead_word(const void* host_mailbox);
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
-                              unsigned long long first_seq, unsigned long long idle_ticks, hipStream_t stream,
+                              unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
+                              int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
                               unsigned long long* dbg = nullptr);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
