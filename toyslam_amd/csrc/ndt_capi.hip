@@ -198,6 +198,7 @@ struct ndt_context {
   DevBuf<float4> out_cloud;
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
+  double* host_pub = nullptr;     // pinned, tagged publication row of the single-scan paths (ndt_kernels.hip publish_row_tagged)
   size_t host_result_rows = 0;
   unsigned long long eval_seq = 0;
   double t_launch = 0, t_wait = 0, t_solver = 0, t_fill = 0;  // NDT_TIMING=1 accounting (seconds)
@@ -233,6 +234,7 @@ struct ndt_context {
 
   ~ndt_context() {
     if (host_result) (void)hipHostFree(host_result);
+    if (host_pub) (void)hipHostFree(host_pub);
     if (server_host_mbs) (void)hipHostFree(server_host_mbs);
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -275,6 +277,10 @@ ndt_status ensure_host_rows(ndt_context* h, size_t rows) {
   h->host_result_rows = 0;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_result), rows * ndt::kEvalStride * sizeof(double),
                         hipHostMallocDefault));
+  if (!h->host_pub) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_pub), ndt::kPublishSlots * sizeof(double), hipHostMallocDefault));
+    std::memset(h->host_pub, 0, ndt::kPublishSlots * sizeof(double));
+  }
   h->host_result_rows = rows;
   return NDT_OK;
 }
@@ -637,6 +643,18 @@ ndt_status check_ready(ndt_context* h) {
   return ensure_device(h);
 }
 
+// tagged publication row (5 chunks of 7 values + sequence number): complete when every chunk carries seq
+inline bool pub_ready(const double* pub, unsigned long long seq) {
+  const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(pub);
+  for (int c = ndt::kPublishSlots / 8 - 1; c >= 0; c--)
+    if (w[8 * c + 7] != seq) return false;
+  return true;
+}
+inline void pub_gather(const double* pub, double* row) {
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int k = 0; k < ndt::kEvalStride; k++) row[k] = pub[(k / 7) * 8 + k % 7];
+}
+
 // one evaluation of a single scan; blocks until the result is on the host
 ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::EvalResult& res, double* nn_total) {
   const int n = h->source->k2_n();
@@ -672,7 +690,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     if (fused) {
       seq = ++h->eval_seq;
       HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, h->partials.p,
-                                            h->ticket.p, h->host_result, seq, h->stream));
+                                            h->ticket.p, h->host_pub, seq, h->stream));
     } else {
       HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, nullptr, 1, nblk, nblk,
                                       h->partials.p, h->stream));
@@ -689,20 +707,22 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     const auto tp1 = std::chrono::steady_clock::now();
     h->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
+    auto arrived = [&] { return fused ? pub_ready(h->host_pub, seq) : __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq; };
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    while (!arrived()) {
       __builtin_ia32_pause();
       if ((++spins & 0xFFFF) == 0) {
         if (hipStreamQuery(h->stream) != hipErrorNotReady) {  // finished (or failed) without the flag
           HIP_TRY(hipStreamSynchronize(h->stream));
-          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+          if (arrived()) break;
           return fail(NDT_ERR_HIP, "evaluation finished without publishing its result");
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
           return fail(NDT_ERR_HIP, "timed out waiting for the evaluation result");
       }
     }
+    if (fused) pub_gather(h->host_pub, h->host_result);
     h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
   } else {
     if (!fused) HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
@@ -766,7 +786,7 @@ ndt_status server_start(ndt_context* h) {
   int pad_bits;
   std::memcpy(&pad_bits, &r2, sizeof(int));
   HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
-                                  h->partials.p, h->server_counter.p, h->host_result, h->eval_seq + 1, idle_ticks, gs.d1,
+                                  h->partials.p, h->server_counter.p, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
                                   h->server_want_dbg ? h->server_dbg.p : nullptr));
   h->server_running = true;
@@ -794,17 +814,16 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
   ndt::snapped_cos_sin(rq.p, cs);
   const unsigned long long seq = ++h->eval_seq;
   ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), T12, cs);
-  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result) + (ndt::kEvalStride - 1);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+  while (!pub_ready(h->host_pub, seq)) {
     __builtin_ia32_pause();
     if ((++spins & 0x3FFF) == 0) {
       if (ndt::server_dead_word(h->server_host_mb) != 0 || hipStreamQuery(h->stream) != hipErrorNotReady) {
         // the server left (idle time-out or error): drain and let the caller relaunch
         h->server_running = false;
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if (pub_ready(h->host_pub, seq)) break;
         ndt::server_reset_mailbox(h->server_host_mb);
         return NDT_OK;
       }
@@ -812,6 +831,7 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
         return fail(NDT_ERR_HIP, "timed out waiting for the evaluation server");
     }
   }
+  pub_gather(h->host_pub, h->host_result);
   unpack_row(h->host_result, rq.kind != ndt::EVAL_NO_HESSIAN, res, nn_total);
   *served = true;
   return NDT_OK;
@@ -1022,10 +1042,15 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
     const bool counts_neighbors = solver.request().kind != ndt::EVAL_HESSIAN_F64;
     bool served = false;
     if (use_server) {
+      const auto tl0 = std::chrono::steady_clock::now();
       s = server_start(h);
       if (s) return s;
+      const auto tl1 = std::chrono::steady_clock::now();
       s = server_evaluate(h, solver.request(), gs_align, r, &nn_step, &served);
       if (s) return s;
+      h->t_launch += std::chrono::duration<double>(tl1 - tl0).count();
+      h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl1).count();
+      if (h->t_fill == 0) h->t_fill = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();  // first evaluation, launch included
     }
     if (!served) {
       s = evaluate_single(h, solver.request(), r, &nn_step);
@@ -1038,9 +1063,9 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   }
   static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   if (timing) {
-    std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus (per align)\n", solver.n_evals + solver.n_hess,
-                 h->t_launch * 1e6, h->t_wait * 1e6, h->t_solver * 1e6);
-    h->t_launch = h->t_wait = h->t_solver = 0;
+    std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus first-eval=%.1fus (per align)\n",
+                 solver.n_evals + solver.n_hess, h->t_launch * 1e6, h->t_wait * 1e6, h->t_solver * 1e6, h->t_fill * 1e6);
+    h->t_launch = h->t_wait = h->t_solver = h->t_fill = 0;
   }
   std::memcpy(h->final_T, solver.final_T, sizeof(h->final_T));
   h->converged = solver.converged ? 1 : 0;

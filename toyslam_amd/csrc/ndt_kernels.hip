@@ -82,6 +82,44 @@ __device__ __forceinline__ void publish_row(double* __restrict__ row, double val
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Tagged publication (single-scan paths): the row goes out as 5 chunks of 64 bytes, each 7 values
+// + the sequence number in its last 8 bytes, by ONE store instruction of 40 lanes and with no drain
+// between data and flag: a 64-byte chunk reaches host memory as one full-line write, so a chunk
+// whose tag matches is complete.  (The drained form above costs a PCIe-visible round trip per
+// evaluation.)  Value k lives in slot (k / 7) * 8 + k % 7.  vals: kEvalStride doubles in LDS.
+constexpr int kPubChunks = 5, kPubSlots = kPubChunks * 8;
+__device__ __forceinline__ void publish_row_tagged(double* __restrict__ pub, const double* vals, int tid,
+                                                   unsigned long long seq) {
+  if (tid < kPubSlots) {
+    const int chunk = tid >> 3, pos = tid & 7, k = chunk * 7 + pos;
+    unsigned long long bits = seq;
+    if (pos < 7) bits = (k < kEvalStride) ? static_cast<unsigned long long>(__double_as_longlong(vals[k])) : 0ull;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pub) + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Fixed-order sum over the per-block partial rows by one workgroup of PARTS * kEvalStride threads:
+// thread (part, k) adds rows part, part + PARTS, ... of column k, 16 loads (sc1: the rows were
+// written through by other CUs) in flight at a time; the PARTS partial sums meet in lds2.
+template <int PARTS>
+__device__ __forceinline__ double sum_rows_fixed(const double* __restrict__ partials, int n_blocks, int tid) {
+  const int k = tid % kEvalStride, part = tid / kEvalStride;
+  double v = 0.0;
+  for (int base = part; base < n_blocks; base += 16 * PARTS) {
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int b = base + j * PARTS;
+      a[j] = (b < n_blocks) ? __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT)
+                            : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) v += a[j];
+  }
+  return v;
+}
+
 typedef unsigned fold_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double mk_f64(int lo, int hi) { return __hiloint2double(hi, lo); }
 
@@ -1207,29 +1245,17 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
 
   // last arriver: fixed-order sum of all rows, every load sc1
   const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
-  const int n_blocks = gridDim.x;
-  double v = 0.0;
-  {
-    int b = part;
-    for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {
-      const double a0 = __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double a1 = __hip_atomic_load(partials + static_cast<size_t>(b + kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double a2 = __hip_atomic_load(partials + static_cast<size_t>(b + 2 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double a3 = __hip_atomic_load(partials + static_cast<size_t>(b + 3 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v += a0; v += a1; v += a2; v += a3;
-    }
-    for (; b < n_blocks; b += kParts)
-      v += __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  lds2[part * kEvalStride + k] = v;
+  lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, threadIdx.x);
   __syncthreads();
   if (threadIdx.x < kEvalStride) {
     double t = 0.0;
 #pragma unroll
     for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
-    publish_row(out_row, t, seq);
+    lds[threadIdx.x] = t;
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
+  publish_row_tagged(out_row, lds, threadIdx.x, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1601,28 +1627,18 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       if (dbg && tid == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
         __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int k = tid % kEvalStride, part = tid / kEvalStride;
-      const int n_blocks = gridDim.x;
-      double v = 0.0;
-      int b = part;
-      for (; b + 3 * kParts < n_blocks; b += 4 * kParts) {
-        const double a0 = __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a1 = __hip_atomic_load(partials + static_cast<size_t>(b + kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a2 = __hip_atomic_load(partials + static_cast<size_t>(b + 2 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double a3 = __hip_atomic_load(partials + static_cast<size_t>(b + 3 * kParts) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v += a0; v += a1; v += a2; v += a3;
-      }
-      for (; b < n_blocks; b += kParts)
-        v += __hip_atomic_load(partials + static_cast<size_t>(b) * kEvalStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lds2[part * kEvalStride + k] = v;
+      lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, tid);
       __syncthreads();
       if (tid < kEvalStride) {
         double t = 0.0;
 #pragma unroll
         for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + tid];
-        publish_row(out_row, t, expect);
-        if (dbg && tid == 0)  // published
-          __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds[tid] = t;
       }
+      __syncthreads();
+      publish_row_tagged(out_row, lds, tid, expect);
+      if (dbg && tid == 0)  // published
+        __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
     expect++;
