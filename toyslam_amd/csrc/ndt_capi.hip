@@ -643,16 +643,22 @@ ndt_status check_ready(ndt_context* h) {
   return ensure_device(h);
 }
 
-// tagged publication row (5 chunks of 7 values + sequence number): complete when every chunk carries seq
+// tagged publication row (ndt_kernels.hip publish_row_tagged): 64 words, each (half of a value << 32) |
+// low 32 bits of the sequence number; complete when every word carries the tag
 inline bool pub_ready(const double* pub, unsigned long long seq) {
   const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(pub);
-  for (int c = ndt::kPublishSlots / 8 - 1; c >= 0; c--)
-    if (w[8 * c + 7] != seq) return false;
+  const unsigned tag = static_cast<unsigned>(seq);
+  for (int i = ndt::kPublishSlots - 1; i >= 0; i--)
+    if (static_cast<unsigned>(w[i]) != tag) return false;
   return true;
 }
 inline void pub_gather(const double* pub, double* row) {
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (int k = 0; k < ndt::kEvalStride; k++) row[k] = pub[(k / 7) * 8 + k % 7];
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(pub);
+  for (int k = 0; k < ndt::kEvalStride; k++) {
+    const unsigned long long bits = (w[2 * k] >> 32) | ((w[2 * k + 1] >> 32) << 32);
+    std::memcpy(&row[k], &bits, sizeof(double));
+  }
 }
 
 // one evaluation of a single scan; blocks until the result is on the host

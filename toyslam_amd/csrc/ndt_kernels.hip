@@ -82,19 +82,24 @@ __device__ __forceinline__ void publish_row(double* __restrict__ row, double val
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Tagged publication (single-scan paths): the row goes out as 5 chunks of 64 bytes, each 7 values
-// + the sequence number in its last 8 bytes, by ONE store instruction of 40 lanes and with no drain
-// between data and flag: a 64-byte chunk reaches host memory as one full-line write, so a chunk
-// whose tag matches is complete.  (The drained form above costs a PCIe-visible round trip per
-// evaluation.)  Value k lives in slot (k / 7) * 8 + k % 7.  vals: kEvalStride doubles in LDS.
-constexpr int kPubChunks = 5, kPubSlots = kPubChunks * 8;
+// Tagged publication (single-scan paths).  Every 8-byte word that crosses PCIe carries its own
+// validity tag: word = (32 payload bits << 32) | (low 32 bits of the sequence number); value k of the
+// row travels as words 2k (low half) and 2k + 1 (high half).  One store instruction of 64 lanes, no
+// drain between data and flag (the drained form above costs a PCIe-visible round trip per
+// evaluation), and no assumption about how the 512 bytes are split into bus transactions: a lane's
+// aligned 8-byte store is single-copy atomic, and the host accepts the row only when all 64 words
+// carry the expected tag.  vals: kEvalStride doubles in LDS.
+constexpr int kPubWords = 2 * kEvalStride;
+__device__ __forceinline__ unsigned long long tag_word(unsigned payload, unsigned long long seq) {
+  return (static_cast<unsigned long long>(payload) << 32) | (seq & 0xffffffffull);
+}
 __device__ __forceinline__ void publish_row_tagged(double* __restrict__ pub, const double* vals, int tid,
                                                    unsigned long long seq) {
-  if (tid < kPubSlots) {
-    const int chunk = tid >> 3, pos = tid & 7, k = chunk * 7 + pos;
-    unsigned long long bits = seq;
-    if (pos < 7) bits = (k < kEvalStride) ? static_cast<unsigned long long>(__double_as_longlong(vals[k])) : 0ull;
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pub) + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid < kPubWords) {
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(vals[tid >> 1]));
+    const unsigned payload = (tid & 1) ? static_cast<unsigned>(bits >> 32) : static_cast<unsigned>(bits);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pub) + tid, tag_word(payload, seq), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1391,21 +1396,25 @@ constexpr int kServerTPB = 512;
 constexpr int kCmdExit = 0x7fffffff;
 constexpr int kCmdTransformExit = 4;  // transform the source by T into the output cloud, then exit
 
-// Command = ONE 128-byte block of pinned host memory, two 64-byte lines, each ending in the
-// command's sequence number:
-//   line A: T[12] (3x4 f32 transform, 48 B) | kind (4 B) | pad (4 B) | seq (8 B)
-//   line B: cos/sin of roll, pitch, yaw after the 1e-4 snap (6 f64, 48 B) | pad (8 B) | seq (8 B)
-// The host fills it with non-temporal stores (one full-line write per line: no read-for-ownership,
-// so the CPU never fights the device's polling reads for the line) and the sequence number is the
-// last 8 bytes of each line, so a line whose tag matches is complete.  The relay's poll (one
-// 16-lane load) IS the data read; it forwards the 128 bytes to the device mailbox in one store.
+// Command = 32 self-validating 8-byte words in pinned host memory (same format in the device
+// mailbox): word = (32 payload bits << 32) | (low 32 bits of the command's sequence number).
+//   words  0..11  T[12]   (3x4 f32 transform)
+//   word   12     kind    (0 with Hessian, 1 without, 2 f64 Hessian, 3 no-op, 4 transform + exit, EXIT)
+//   words 13..24  cos/sin of roll, pitch, yaw after the 1e-4 snap: 6 f64 as (low, high) word pairs
+//   words 25..31  zero
+// A reader accepts the command when all 32 words carry the expected tag, so nothing depends on how
+// the CPU's stores or the relay's 32-lane store are split into bus transactions (an aligned 8-byte
+// word is single-copy atomic on both sides).  The host fills it with non-temporal stores (full-line
+// writes, no read-for-ownership, so the CPU never fights the device's polling reads for the lines);
+// the relay's poll (one 32-lane load) IS the data read, and it forwards the words with one store.
 // The 69 angle-derivative coefficients (computeAngleDerivatives, ndt_omp_impl.hpp:288-395) are a
-// function of those six values; every block recomputes them (bit-identical to the host's: same
+// function of the six cos/sin values; every block recomputes them (bit-identical to the host's: same
 // f64 inputs, same operation order, contraction off) instead of fetching 344 B of tables.
-// (Measured alternatives that were slower: tagged-granule sweeps of a 700-B mailbox on every poll,
-// +4..7 us per command; a polled line written with ordinary stores, +8 us.)
+// (Measured alternatives that were slower: parameter image + separate sequence word, two more
+// dependent round trips, +4 us per command; a polled line written with ordinary stores, +8 us.)
+constexpr int kCmdWords = 32;
 struct ServerMailbox {
-  unsigned long long cmd[16];
+  unsigned long long cmd[kCmdWords];
   unsigned long long dead;  // host mailbox only: server gave up waiting (own line)
   unsigned long long pad[15];
 };
@@ -1492,18 +1501,18 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       unsigned long long w = 0;
       bool got = false;
-      for (;;) {  // one 16-lane load = two 64-byte PCIe reads; the poll IS the data read
-        if (lane < 16) w = __hip_atomic_load(&host_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__shfl(w, 7, kWave) == expect && __shfl(w, 15, kWave) == expect) { got = true; break; }
+      for (;;) {  // the poll IS the data read
+        if (lane < kCmdWords) w = __hip_atomic_load(&host_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) break;
       }
       const unsigned long long dbg_seen = __builtin_amdgcn_s_memrealtime();
       if (!got) {  // idle for too long: tell the host, send everybody home
         if (lane == 0) __hip_atomic_store(&host_mb->dead, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        w = (lane == 6) ? static_cast<unsigned long long>(static_cast<unsigned>(kCmdExit)) : ((lane == 7 || lane == 15) ? expect : 0ull);
+        w = tag_word(lane == 12 ? static_cast<unsigned>(kCmdExit) : 0u, expect);
       }
-      if (lane < 16) __hip_atomic_store(&dev_mb->cmd[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dbg && got && static_cast<int>(static_cast<unsigned>(__shfl(w, 6, kWave))) != kCmdExit && lane == 0) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
+      if (lane < kCmdWords) __hip_atomic_store(&dev_mb->cmd[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg && got && static_cast<int>(__shfl(static_cast<unsigned>(w >> 32), 12, kWave)) != kCmdExit && lane == 0) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
     }
     // ---- every block: wait for the device command block ----
     if (wave == 0) {
@@ -1511,25 +1520,24 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       unsigned long long w = 0;
       bool got = false;
       for (;;) {
-        if (lane < 16) w = __hip_atomic_load(&dev_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__shfl(w, 7, kWave) == expect && __shfl(w, 15, kWave) == expect) { got = true; break; }
+        if (lane < kCmdWords) w = __hip_atomic_load(&dev_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > 4 * idle_ticks) break;
         __builtin_amdgcn_s_sleep(1);
       }
       int kind = kCmdExit;
       if (got) {
-        kind = static_cast<int>(static_cast<unsigned>(__shfl(w, 6, kWave)));
-        if (lane < 6) {  // T[12]
-          const float t_lo = __int_as_float(static_cast<int>(static_cast<unsigned>(w)));
-          const float t_hi = __int_as_float(static_cast<int>(static_cast<unsigned>(w >> 32)));
-          sP.T[2 * lane] = t_lo;
-          sP.T[2 * lane + 1] = t_hi;
-          sP64.T[2 * lane] = t_lo;
-          sP64.T[2 * lane + 1] = t_hi;
+        const unsigned payload = static_cast<unsigned>(w >> 32);
+        const unsigned next = __shfl_down(payload, 1, kWave);
+        kind = static_cast<int>(__shfl(payload, 12, kWave));
+        if (lane < 12) {  // T[12]
+          const float t = __int_as_float(static_cast<int>(payload));
+          sP.T[lane] = t;
+          sP64.T[lane] = t;
         }
-        if (lane >= 8 && lane < 14) {  // cx cy cz sx sy sz -> f = {1, sx, cx, sy, cy, sz, cz}
-          const double v = __longlong_as_double(static_cast<long long>(w));
-          const int a = lane - 8;  // 0..2 cos, 3..5 sin
+        if (lane >= 13 && lane < 25 && ((lane - 13) & 1) == 0) {  // cx cy cz sx sy sz -> f = {1, sx, cx, sy, cy, sz, cz}
+          const double v = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(next) << 32) | payload));
+          const int a = (lane - 13) >> 1;  // 0..2 cos, 3..5 sin
           s_f[(a < 3) ? 2 + 2 * a : 1 + 2 * (a - 3)] = v;
         }
         if (lane == 0) { s_f[0] = 1.0; s_f[7] = 0.0; }
@@ -1921,19 +1929,28 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
 
 size_t server_mailbox_bytes() { return sizeof(ServerMailbox); }
 
-// host side of the mailbox protocol (pinned, coherent host memory): the 128-byte command is built
-// locally and written with non-temporal 16-byte stores, one full-line write per 64-byte line
+// host side of the mailbox protocol (pinned, coherent host memory): the 32 tagged words are built
+// locally and written with non-temporal 16-byte stores, full 64-byte lines
 void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6) {
   ServerMailbox* mb = static_cast<ServerMailbox*>(host_mailbox);
-  alignas(64) unsigned long long c[16];
-  std::memset(c, 0, sizeof(c));
-  if (T12) std::memcpy(&c[0], T12, 12 * sizeof(float));
-  const unsigned k = static_cast<unsigned>(kind);
-  c[6] = k;
-  c[7] = seq;
-  if (cos_sin6) std::memcpy(&c[8], cos_sin6, 6 * sizeof(double));
-  c[15] = seq;
-  for (int i = 0; i < 8; i++)
+  alignas(64) unsigned long long c[kCmdWords];
+  const unsigned long long tag = seq & 0xffffffffull;
+  for (int i = 0; i < kCmdWords; i++) c[i] = tag;
+  if (T12)
+    for (int i = 0; i < 12; i++) {
+      unsigned bits;
+      std::memcpy(&bits, &T12[i], sizeof(bits));
+      c[i] |= static_cast<unsigned long long>(bits) << 32;
+    }
+  c[12] |= static_cast<unsigned long long>(static_cast<unsigned>(kind)) << 32;
+  if (cos_sin6)
+    for (int i = 0; i < 6; i++) {
+      unsigned long long bits;
+      std::memcpy(&bits, &cos_sin6[i], sizeof(bits));
+      c[13 + 2 * i] |= (bits & 0xffffffffull) << 32;
+      c[14 + 2 * i] |= (bits >> 32) << 32;
+    }
+  for (int i = 0; i < kCmdWords / 2; i++)
     _mm_stream_si128(reinterpret_cast<__m128i*>(&mb->cmd[2 * i]), _mm_load_si128(reinterpret_cast<const __m128i*>(&c[2 * i])));
   _mm_sfence();
 }

@@ -117,7 +117,7 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
                                     bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
                                     unsigned long long seq, hipStream_t stream);
 // Persistent evaluation server (one launch per align): see ndt_kernels.hip.
-constexpr int kPublishSlots = 40;  // tagged publication row: 5 x (7 values + sequence number)
+constexpr int kPublishSlots = 64;  // tagged publication row: value k as words 2k, 2k+1 = (half << 32) | seq32
 constexpr int kServerCmdExit = 0x7fffffff;
 constexpr int kServerCmdTransformExit = 4;  // write the aligned cloud with the command's transform, then exit
 size_t server_mailbox_bytes();
