@@ -1,0 +1,445 @@
+// ndt_latency.hip -- the single-scan latency path: one-launch evaluation (derivatives + final
+// reduction + publication) and the persistent evaluation server.  Built with -fno-slp-vectorize:
+// the SLP vectoriser packs the f32 neighbour math into v_pk_* pairs at the price of register
+// shuffling, which costs these latency-bound kernels ~5 % (measured A/B on one MI355X) while the
+// throughput kernels of ndt_kernels.hip gain from it.
+#include "ndt_device.hpp"
+
+#include <emmintrin.h>
+
+namespace ndt {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Single-scan latency path: derivatives + final reduction + publication in ONE launch.
+//
+// Every block stores its 32-f64 partial row write-through (sc1), drains it (s_waitcnt vmcnt(0))
+// and takes a ticket with one relaxed agent-scope fetch_add; the block whose ticket is the last
+// re-reads ALL rows with sc1 loads (L1 is bypassed; every row was written through before its
+// block's ticket), sums them in a fixed order and writes the packed row plus the sequence word
+// straight into pinned host memory.  This is the ticket form of the hand-off of
+// cdna_hip_programming.md Guideline 16 (sc1 stores / sc1 loads / drained before the counter add /
+// last arriver told by the value its add returned; other waves of the last block load only after
+// the workgroup barrier that the ticket wave joins).  Saves the second launch and the
+// inter-kernel gap of the two-kernel path (~5 us per evaluation at 100k points).
+// The counter is reset by the last block, so it is 0 again at the next launch.
+// ---------------------------------------------------------------------------
+template <int NNB, bool WANT_H, int TPB>
+__global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
+                                                           double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                           double* __restrict__ out_row, unsigned long long seq) {
+  constexpr int kWaves = TPB / kWave, kParts = TPB / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ double lds2[kParts * kEvalStride];
+  __shared__ int s_last;
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double tot = wave_fold<kNumAcc>(acc);
+  if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+  __syncthreads();
+  if (wave == 0) {
+    if (lane < kEvalStride) {
+      double v = 0.0;
+      if (lane < kNumAcc) {
+        v = lds[lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+      }
+      // write-through store of the whole 256-B row by one wave instruction
+      __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // last arriver: fixed-order sum of all rows, every load sc1
+  const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
+  lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x < kEvalStride) {
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
+    lds[threadIdx.x] = t;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  publish_row_tagged(out_row, lds, threadIdx.x, seq);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent evaluation server (single-scan latency path).
+//
+// One launch per align(): gridDim.x resident blocks loop { wait for a command; evaluate; publish }.
+// The host posts (sequence number, kind, EvalParams) into a pinned HOST mailbox; wave 0 of block 0
+// relays it into a DEVICE mailbox (write-through), all blocks poll that with L1-bypassing loads.
+// Per evaluation this removes the kernel launch, the dispatch latency and the kernel-boundary cache
+// invalidation (the read-only source / LUT / records stay L2-warm across evaluations).
+//
+// Liveness: every spin is bounded by a wall-clock budget (s_memrealtime, 100 MHz).  If no command
+// arrives within `idle_ticks` the relay broadcasts EXIT and raises the host-visible `dead` word; a
+// worker that sees no command for 4x that budget leaves on its own.  The grid therefore always
+// drains, whatever the host does.  gridDim.x must not exceed the number of co-resident blocks.
+// ---------------------------------------------------------------------------
+constexpr int kServerTPB = 512;
+constexpr int kCmdExit = 0x7fffffff;
+constexpr int kCmdTransformExit = 4;  // transform the source by T into the output cloud, then exit
+
+// Command = 32 self-validating 8-byte words in pinned host memory (same format in the device
+// mailbox): word = (32 payload bits << 32) | (low 32 bits of the command's sequence number).
+//   words  0..11  T[12]   (3x4 f32 transform)
+//   word   12     kind    (0 with Hessian, 1 without, 2 f64 Hessian, 3 no-op, 4 transform + exit, EXIT)
+//   words 13..24  cos/sin of roll, pitch, yaw after the 1e-4 snap: 6 f64 as (low, high) word pairs
+//   words 25..31  zero
+// A reader accepts the command when all 32 words carry the expected tag, so nothing depends on how
+// the CPU's stores or the relay's 32-lane store are split into bus transactions (an aligned 8-byte
+// word is single-copy atomic on both sides).  The host fills it with non-temporal stores (full-line
+// writes, no read-for-ownership, so the CPU never fights the device's polling reads for the lines);
+// the relay's poll (one 32-lane load) IS the data read, and it forwards the words with one store.
+// The 69 angle-derivative coefficients (computeAngleDerivatives, ndt_omp_impl.hpp:288-395) are a
+// function of the six cos/sin values; every block recomputes them (bit-identical to the host's: same
+// f64 inputs, same operation order, contraction off) instead of fetching 344 B of tables.
+// (Measured alternatives that were slower: parameter image + separate sequence word, two more
+// dependent round trips, +4 us per command; a polled line written with ordinary stores, +8 us.)
+constexpr int kCmdWords = 32;
+struct ServerMailbox {
+  unsigned long long cmd[kCmdWords];
+  unsigned long long dead;  // host mailbox only: server gave up waiting (own line)
+  unsigned long long pad[15];
+};
+
+// 69 entries (j_ang 8x3 then h_ang 15x3): value = s1*f[a1]*f[b1]*f[c1] + s2*f[a2]*f[b2]*f[c2],
+// f = {1, sx, cx, sy, cy, sz, cz}; generated from the expressions of ndt_omp_impl.hpp:329-393
+__device__ __constant__ signed char kAngleTerms[69][8] = {
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 1, 6, 0, -1, 2, 3, 5}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 2, 5, 0, 1, 1, 3, 6}, {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 1, 4, 0, 0, 0, 0, 0},
+    {-1, 3, 6, 0, 0, 0, 0, 0}, {1, 3, 5, 0, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0, 0, 0},
+    {1, 1, 4, 6, 0, 0, 0, 0}, {-1, 1, 4, 5, 0, 0, 0, 0}, {1, 1, 3, 0, 0, 0, 0, 0},
+    {-1, 2, 4, 6, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0}, {-1, 2, 3, 0, 0, 0, 0, 0},
+    {-1, 4, 5, 0, 0, 0, 0, 0}, {-1, 4, 6, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 2, 5, 0, -1, 1, 3, 6}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 1, 6, 0, 1, 2, 3, 5}, {1, 2, 3, 6, -1, 1, 5, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 2, 5, 0, -1, 1, 3, 6}, {-1, 2, 6, 0, 1, 1, 3, 5}, {1, 1, 4, 0, 0, 0, 0, 0},
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 2, 3, 5, -1, 1, 6, 0}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 2, 4, 6, 0, 0, 0, 0}, {-1, 2, 4, 5, 0, 0, 0, 0}, {1, 2, 3, 0, 0, 0, 0, 0},
+    {1, 1, 4, 6, 0, 0, 0, 0}, {-1, 1, 4, 5, 0, 0, 0, 0}, {1, 1, 3, 0, 0, 0, 0, 0},
+    {-1, 1, 6, 0, -1, 2, 3, 5}, {1, 1, 5, 0, -1, 2, 3, 6}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 6, 0, -1, 1, 3, 5}, {-1, 1, 3, 6, -1, 2, 5, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 4, 6, 0, 0, 0, 0, 0}, {1, 4, 5, 0, 0, 0, 0, 0}, {-1, 3, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 3, 6, 0, 0, 0, 0}, {1, 1, 3, 5, 0, 0, 0, 0}, {1, 1, 4, 0, 0, 0, 0, 0},
+    {1, 2, 3, 6, 0, 0, 0, 0}, {-1, 2, 3, 5, 0, 0, 0, 0}, {-1, 2, 4, 0, 0, 0, 0, 0},
+    {1, 3, 5, 0, 0, 0, 0, 0}, {1, 3, 6, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 4, 5, 0, 0, 0, 0}, {-1, 1, 4, 6, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 4, 5, 0, 0, 0, 0}, {1, 2, 4, 6, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 4, 6, 0, 0, 0, 0, 0}, {1, 4, 5, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 2, 5, 0, -1, 1, 3, 6}, {-1, 2, 6, 0, 1, 1, 3, 5}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {-1, 1, 5, 0, 1, 2, 3, 6}, {-1, 2, 3, 5, -1, 1, 6, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+};
+
+// one coefficient of the f64 vectors j_ang_* (e < 24) / h_ang_* (e >= 24) from f = {1,sx,cx,sy,cy,sz,cz}
+__device__ __forceinline__ double angle_coefficient_f64(int e, const double* f) {
+#pragma clang fp contract(off)
+  const signed char* t = kAngleTerms[e];
+  const double t1 = ((static_cast<double>(t[0]) * f[t[1]]) * f[t[2]]) * f[t[3]];
+  const double t2 = ((static_cast<double>(t[4]) * f[t[5]]) * f[t[6]]) * f[t[7]];
+  return t1 + t2;
+}
+// the f32 matrices j_ang / h_ang hold the same values rounded, except h_ang row d1, z: +sy (:383)
+// where the f64 vector has -sy (:361)
+__device__ __forceinline__ float angle_coefficient(int e, const double* f) {
+  const double v = (e == 24 + 6 * 3 + 2) ? f[3] : angle_coefficient_f64(e, f);
+  return static_cast<float>(v);
+}
+
+template <int NNB>
+__global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __restrict__ src, int n, GridView gv,
+                                                            ServerMailbox* host_mb, ServerMailbox* dev_mb,
+                                                            double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                            double* __restrict__ out_row, unsigned long long first_seq,
+                                                            unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
+                                                            int param_pad, const float4* __restrict__ out_src,
+                                                            float4* __restrict__ out_dst, int out_n, unsigned long long* dbg) {
+  constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ double lds2[kParts * kEvalStride];
+  __shared__ EvalParams sP;
+  __shared__ Hess64Params sP64;
+  __shared__ double s_f[8];  // 1, sx, cx, sy, cy, sz, cz
+  __shared__ int s_kind;
+  __shared__ int s_last;
+  unsigned long long expect = first_seq;
+  if (threadIdx.x == 0) {
+    sP.d1 = gauss_d1;
+    sP.d2 = static_cast<float>(gauss_d2);
+    sP.pad = param_pad;
+    sP64.d1 = gauss_d1;
+    sP64.d2 = gauss_d2;
+    sP64.r2 = static_cast<double>(__int_as_float(param_pad));
+  }
+
+  for (;;) {
+    // Nothing but `expect` is meant to live across rounds: opaque copies keep the compiler from
+    // hoisting per-round address arithmetic out of the loop (it did, ran out of registers and
+    // spilled those values to scratch, whose reloads sat on the round's critical path).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    asm volatile("" : "+s"(host_mb), "+s"(dev_mb), "+s"(partials), "+s"(counter), "+s"(out_row), "+s"(dbg), "+s"(src));
+    // ---- relay: host mailbox -> device mailbox (wave 0 of block 0) ----
+    if (blockIdx.x == 0 && wave == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long w = 0;
+      bool got = false;
+      for (;;) {  // the poll IS the data read
+        if (lane < kCmdWords) w = __hip_atomic_load(&host_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) break;
+      }
+      const unsigned long long dbg_seen = __builtin_amdgcn_s_memrealtime();
+      if (!got) {  // idle for too long: tell the host, send everybody home
+        if (lane == 0) __hip_atomic_store(&host_mb->dead, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w = tag_word(lane == 12 ? static_cast<unsigned>(kCmdExit) : 0u, expect);
+      }
+      if (lane < kCmdWords) __hip_atomic_store(&dev_mb->cmd[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg && got && static_cast<int>(__shfl(static_cast<unsigned>(w >> 32), 12, kWave)) != kCmdExit && lane == 0) { dbg[0] = dbg_seen; dbg[1] = __builtin_amdgcn_s_memrealtime(); }  // seen / relayed
+    }
+    // ---- every block: wait for the device command block ----
+    if (wave == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long w = 0;
+      bool got = false;
+      for (;;) {
+        if (lane < kCmdWords) w = __hip_atomic_load(&dev_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 4 * idle_ticks) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      int kind = kCmdExit;
+      if (got) {
+        const unsigned payload = static_cast<unsigned>(w >> 32);
+        const unsigned next = __shfl_down(payload, 1, kWave);
+        kind = static_cast<int>(__shfl(payload, 12, kWave));
+        if (lane < 12) {  // T[12]
+          const float t = __int_as_float(static_cast<int>(payload));
+          sP.T[lane] = t;
+          sP64.T[lane] = t;
+        }
+        if (lane >= 13 && lane < 25 && ((lane - 13) & 1) == 0) {  // cx cy cz sx sy sz -> f = {1, sx, cx, sy, cy, sz, cz}
+          const double v = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(next) << 32) | payload));
+          const int a = (lane - 13) >> 1;  // 0..2 cos, 3..5 sin
+          s_f[(a < 3) ? 2 + 2 * a : 1 + 2 * (a - 3)] = v;
+        }
+        if (lane == 0) { s_f[0] = 1.0; s_f[7] = 0.0; }
+      }
+      if (lane == 0) {
+        s_kind = kind;
+        if (dbg && kind != kCmdExit) dbg[8 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its command
+      }
+    }
+    __syncthreads();
+    const int kind = s_kind;
+    if (kind == kCmdTransformExit) {  // last command of a registration: write the aligned cloud, then leave
+      for (int i = blockIdx.x * kServerTPB + tid; i < out_n; i += gridDim.x * kServerTPB) {
+        const float4 pt = out_src[i];
+        float tx, ty, tz;
+        xform_point(sP.T, pt.x, pt.y, pt.z, tx, ty, tz);
+        out_dst[i] = make_float4(tx, ty, tz, 1.0f);
+      }
+      return;
+    }
+    if (kind < 0 || kind > 3) return;  // EXIT or time-out: the whole block leaves together (3 = no-op round)
+    if (tid < 69) {
+      if (kind == 2) {  // f64 vectors of computeHessian (:329-361, -sy in row d1)
+        const double c = angle_coefficient_f64(tid, s_f);
+        if (tid < 24) sP64.jd[tid / 3][tid % 3] = c;
+        else sP64.hd[(tid - 24) / 3][(tid - 24) % 3] = c;
+      } else {
+        const float c = angle_coefficient(tid, s_f);
+        if (tid < 24) sP.j[tid / 3][tid % 3] = c;
+        else sP.h[(tid - 24) / 3][(tid - 24) % 3] = c;
+      }
+    }
+    __syncthreads();
+    unsigned long long* fine = dbg ? dbg + 8 + 2 * 1024 + 8 * blockIdx.x : nullptr;  // diagnostics: per-block phase stamps
+    if (fine && tid == 0) fine[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- evaluate ----
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int first = blockIdx.x * kServerTPB + tid, stride = gridDim.x * kServerTPB;
+    if (kind == 2) {
+      // rare round (at most one per Newton iteration): keep its loop invariants from being hoisted
+      // into registers the hot rounds need (the opaque copy of `first` pins them inside the branch)
+      int first64 = first;
+      asm volatile("" : "+v"(first64));
+      hessian64_body<NNB>(src, n, gv, sP64, first64, stride, acc);
+    } else if (NNB == 27) {
+      if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);
+    } else {
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+    }
+    if (fine && tid == 0) fine[1] = __builtin_amdgcn_s_memrealtime();
+    const double tot = wave_fold<kNumAcc>(acc);
+    if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+    if (fine && tid == 0) fine[2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (wave == 0) {
+      if (fine && lane == 0) fine[3] = __builtin_amdgcn_s_memrealtime();
+      if (lane < kEvalStride) {
+        double v = 0.0;
+        if (lane < kNumAcc) {
+          v = lds[lane];
+#pragma unroll
+          for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+        }
+        __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (fine && lane == 0) fine[4] = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0) {
+        // Two-level fan-in: 8 shard counters (blocks b and b+8 usually share an XCD; only speed
+        // depends on that) and one top counter.  ~200 returning atomics on ONE word serialise at
+        // ~13 ns each (measured 2.5-3 us of arrival skew); sharded, the longest chain is ~25+8.
+        // Counters live 128 B apart and are never reset inside a launch.
+        const unsigned round = static_cast<unsigned>(expect - first_seq);
+        const unsigned shard = blockIdx.x & 7u;
+        const unsigned in_shard = (gridDim.x + 7u - shard) / 8u;  // blocks with this residue
+        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (t1 == (round + 1u) * in_shard - 1u) {
+          const unsigned n_shards = gridDim.x < 8u ? gridDim.x : 8u;
+          const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = (t2 == (round + 1u) * n_shards - 1u) ? 1 : 0;
+        }
+        s_last = last;
+        if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
+      }
+    }
+    __syncthreads();
+    if (s_last) {
+      if (dbg && tid == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
+        __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int k = tid % kEvalStride, part = tid / kEvalStride;
+      lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, tid);
+      __syncthreads();
+      if (tid < kEvalStride) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + tid];
+        lds[tid] = t;
+      }
+      __syncthreads();
+      publish_row_tagged(out_row, lds, tid, expect);
+      if (dbg && tid == 0)  // published
+        __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
+    expect++;
+  }
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+}  // namespace
+
+constexpr int kFusedTPB = 512;
+int fused_blocks(int n) {
+  static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
+  size_t b = (static_cast<size_t>(n) + kFusedTPB - 1) / kFusedTPB;
+  if (b < 1) b = 1;
+  if (b > static_cast<size_t>(cap)) b = cap;
+  return static_cast<int>(b);
+}
+
+hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
+                                    bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                                    unsigned long long seq, hipStream_t stream) {
+#define NDT_LAUNCH_FUSED(NNB, H)                                                                                        \
+  hipLaunchKernelGGL((k_derivatives_fused<NNB, H, kFusedTPB>), dim3(n_blocks), dim3(kFusedTPB), 0, stream, src, n, gv, P, \
+                     partials, counter, out_row, seq)
+  if (search == 0) {
+    if (want_hessian) NDT_LAUNCH_FUSED(27, true); else NDT_LAUNCH_FUSED(27, false);
+  } else if (search == 1) {
+    if (want_hessian) NDT_LAUNCH_FUSED(26, true); else NDT_LAUNCH_FUSED(26, false);
+  } else if (search == 3) {
+    if (want_hessian) NDT_LAUNCH_FUSED(1, true); else NDT_LAUNCH_FUSED(1, false);
+  } else {
+    if (want_hessian) NDT_LAUNCH_FUSED(7, true); else NDT_LAUNCH_FUSED(7, false);
+  }
+#undef NDT_LAUNCH_FUSED
+  return hipGetLastError();
+}
+
+size_t server_mailbox_bytes() { return sizeof(ServerMailbox); }
+
+// host side of the mailbox protocol (pinned, coherent host memory): the 32 tagged words are built
+// locally and written with non-temporal 16-byte stores, full 64-byte lines
+void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6) {
+  ServerMailbox* mb = static_cast<ServerMailbox*>(host_mailbox);
+  alignas(64) unsigned long long c[kCmdWords];
+  const unsigned long long tag = seq & 0xffffffffull;
+  for (int i = 0; i < kCmdWords; i++) c[i] = tag;
+  if (T12)
+    for (int i = 0; i < 12; i++) {
+      unsigned bits;
+      std::memcpy(&bits, &T12[i], sizeof(bits));
+      c[i] |= static_cast<unsigned long long>(bits) << 32;
+    }
+  c[12] |= static_cast<unsigned long long>(static_cast<unsigned>(kind)) << 32;
+  if (cos_sin6)
+    for (int i = 0; i < 6; i++) {
+      unsigned long long bits;
+      std::memcpy(&bits, &cos_sin6[i], sizeof(bits));
+      c[13 + 2 * i] |= (bits & 0xffffffffull) << 32;
+      c[14 + 2 * i] |= (bits >> 32) << 32;
+    }
+  for (int i = 0; i < kCmdWords / 2; i++)
+    _mm_stream_si128(reinterpret_cast<__m128i*>(&mb->cmd[2 * i]), _mm_load_si128(reinterpret_cast<const __m128i*>(&c[2 * i])));
+  _mm_sfence();
+}
+unsigned long long server_dead_word(const void* host_mailbox) {
+  return __atomic_load_n(&static_cast<const ServerMailbox*>(host_mailbox)->dead, __ATOMIC_ACQUIRE);
+}
+void server_reset_mailbox(void* host_mailbox) { std::memset(host_mailbox, 0, sizeof(ServerMailbox)); }
+
+hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
+                              void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                              unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
+                              int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
+                              unsigned long long* dbg) {
+  ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
+  ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
+  if (search == 0)
+    hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
+  else if (search == 1)
+    hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
+  else if (search == 3)
+    hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
+  else
+    hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg);
+  return hipGetLastError();
+}
+
+}  // namespace ndt
