@@ -170,6 +170,12 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
  * kernel), 1 = without, 2 = f64 Hessian.  Off by default (the event pairs cost
  * host time). */
 ndt_status ndt_profile_enable(ndt_handle h, int on);
+
+/* How ndt_align evaluates: 1 (default) = one persistent kernel per registration, fed one command
+ * per evaluation through a pinned mailbox; 0 = one kernel launch per evaluation.  Both run the same
+ * device code over the same thread partition and return bit-identical results (tests pin that);
+ * the setting only trades latency.  The NDT_PERSISTENT environment variable sets the default. */
+ndt_status ndt_set_evaluation_path(ndt_handle h, int persistent);
 ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset);
 
 /* Device self-test of the wave64 fold reduction used by every kernel epilogue: n_blocks blocks

@@ -251,6 +251,34 @@ def test_synthetic_align_vs_oracle(mods, kind):
         assert rot_err(T, clouds.T_GT_DEFAULT) < 2e-3 and trans_err(T, clouds.T_GT_DEFAULT) < 2e-2
 
 
+@pytest.mark.parametrize("method", ["KDTREE", "DIRECT26", "DIRECT7", "DIRECT1"])
+def test_persistent_server_equals_launch_per_evaluation(mods, pair, method):
+    """The persistent evaluation server (its angle tables are computed on the device from six cos/sin
+    values, its f64 Hessian and final transform run inside the same kernel) must return exactly what
+    the one-launch-per-evaluation path returns: same partition, same fold order, same tables."""
+    ndt, po, clouds = mods
+    t, s = pair
+    res = {}
+    for persistent in (True, False):
+        g = ndt.NormalDistributionsTransform()
+        g.setNeighborhoodSearchMethod(getattr(po, method))
+        g.setTransformationEpsilon(1e-9)  # the line search iterates near the optimum -> f64 Hessian recomputes
+        g.setMaximumIterations(12)
+        g.setEvaluationPath(persistent)
+        g.setInputTarget(t)
+        g.setInputSource(s)
+        out = g.align(n_out=len(s))
+        res[persistent] = (g.getFinalTransformation().copy(), g.getFinalNumIteration(), g.getTransformationProbability(),
+                           g.stats(), np.asarray(out).copy())
+    a, b = res[True], res[False]
+    assert np.array_equal(a[0], b[0])
+    assert a[1] == b[1] and a[2] == b[2]
+    assert a[3]["n_evals"] == b[3]["n_evals"] and a[3]["n_hessian_recomputes"] == b[3]["n_hessian_recomputes"]
+    if method == "DIRECT7":
+        assert a[3]["n_hessian_recomputes"] >= 1, "case does not reach the in-server f64 Hessian"
+    assert np.array_equal(a[4], b[4])
+
+
 def test_point_stride_32_and_clone(mods, pair):
     """PointXYZI/XYZRGB are 32-byte records; copies share the device grid (value semantics of the nodes)."""
     ndt, _, _ = mods

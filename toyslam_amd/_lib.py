@@ -82,6 +82,7 @@ SIGNATURES = {
     "ndt_diag_server_roundtrip": (C.c_int, [vp, dp, C.c_int, dp]),
     "ndt_selftest_reduce": (C.c_int, [vp, C.c_int, dp]),
     "ndt_profile_enable": (C.c_int, [vp, C.c_int]),
+    "ndt_set_evaluation_path": (C.c_int, [vp, C.c_int]),
     "ndt_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_longlong), dp, C.c_int]),
     "ndt_host_solve6": (None, [dp, dp, dp]),
     "ndt_host_pose_to_matrix": (None, [dp, fp]),

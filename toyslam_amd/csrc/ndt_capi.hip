@@ -211,6 +211,7 @@ struct ndt_context {
   size_t out_n = 0;
   // persistent evaluation server (single-scan align)
   bool server_running = false;
+  int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
   // Two command mailboxes, used by alternate server instances: a server told to finish (transform +
   // exit) is not waited for, and the next instance's first command must not overwrite the line the
   // old one may still be reading.
@@ -939,6 +940,7 @@ ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
   h->max_iter = src->max_iter;
   h->search = src->search;
   h->num_threads = src->num_threads;
+  h->persistent = src->persistent;
   h->min_pts = src->min_pts;
   h->eig_ratio = src->eig_ratio;
   h->target = src->target;
@@ -983,6 +985,7 @@ ndt_status ndt_set_neighborhood_search_method(ndt_handle h, int m) {
   h->search = m;  // unknown values behave like DIRECT7: the reference's `default:` label
   return NDT_OK;
 }
+ndt_status ndt_set_evaluation_path(ndt_handle h, int persistent) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->persistent = persistent ? 1 : 0; return NDT_OK; }
 ndt_status ndt_set_num_threads(ndt_handle h, int n) { if (!h) return fail(NDT_ERR_INVALID, "null"); h->num_threads = n; return NDT_OK; }
 ndt_status ndt_set_min_points_per_voxel(ndt_handle h, int n) {
   if (!h) return fail(NDT_ERR_INVALID, "null");
@@ -1040,7 +1043,7 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
     ndt_context* c;
     ~ServerGuard() { if (c->server_running) (void)server_stop(c); }
   } server_guard{h};
-  const bool use_server = server_enabled() && !h->profiling && !h->allreduce && ndt::derivative_variant() == 0 &&
+  const bool use_server = (h->persistent < 0 ? server_enabled() : h->persistent != 0) && !h->profiling && !h->allreduce && ndt::derivative_variant() == 0 &&
                           h->source->k2_n() > 0 && !h->grid->empty;
   while (!solver.done()) {
     ndt::EvalResult r;

@@ -245,6 +245,10 @@ class NormalDistributionsTransform:
         check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
         return out
 
+    def setEvaluationPath(self, persistent):
+        """True (default): one persistent kernel per registration; False: one launch per evaluation."""
+        check(self._L.ndt_set_evaluation_path(self._h, int(bool(persistent))))
+
     def profile(self, on):
         check(self._L.ndt_profile_enable(self._h, int(on)))
 
