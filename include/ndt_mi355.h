@@ -120,6 +120,35 @@ ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t
 ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense,
                                         float leaf_size, void* d_out_float4, size_t* n_out);
 
+/* ---- global map accumulation (row N2 of the scope table) ---------------------
+ * update_global_map of the mapping nodes (ndt_omp_mapping_node.cpp:195-211,
+ * ndt_rosbag_mapping_node.cpp:146-161): pcl::transformPointCloud(scan, pose) -> global_map += it ->
+ * global_map = VoxelGrid(leaf).filter(global_map).  The map lives in HBM with the handle; `pose` is a
+ * column-major 4x4 (NULL = identity).  *overflowed = 1 when the leaf is too small for the map's
+ * bounding box: PCL then keeps the unfiltered concatenation, and so does this.
+ * ndt_host_chain_pose is the nodes' `pose = pose * transform` (:88-99 / :62-68) in Eigen's f32 rounding. */
+ndt_status ndt_map_clear(ndt_handle h);
+ndt_status ndt_map_update(ndt_handle h, const void* scan, size_t n, size_t stride_bytes, int is_dense, const float* pose,
+                          float leaf_size, int* overflowed);
+ndt_status ndt_map_update_device(ndt_handle h, const void* d_scan, size_t n, size_t stride_bytes, int is_dense,
+                                 const float* pose, float leaf_size, int* overflowed);
+ndt_status ndt_map_size(ndt_handle h, size_t* n);
+ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride_bytes); /* x,y,z,1.0f per point */
+ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts_float4, size_t* n);
+void ndt_host_chain_pose(const float* pose /*16*/, const float* transform /*16*/, float* out /*16, may alias*/);
+
+/* ---- PCD files (row N3 of the scope table) -----------------------------------
+ * What pcl::io::loadPCDFile<pcl::PointXYZ> hands the callers (ndt_omp/apps/align.cpp:48-55,
+ * ndt_omp_mapping_node.cpp:140, ndt_omp_node.cpp:82) and what pcl::io::savePCDFileBinary writes
+ * (lidar_subscriber_node.cpp:46): PCD v0.7, DATA ascii | binary | binary_compressed; x, y, z are
+ * picked by field name, other fields (intensity, rgb, ...) are skipped.  Host only, no device needed.
+ * data_kind: 0 ascii, 1 binary, 2 binary_compressed.  Records written to `out` are x,y,z(,1.0f when
+ * stride_bytes >= 16); *is_dense = every point finite (PCDReader's rule). */
+ndt_status ndt_pcd_read_header(const char* path, size_t* n_points, int* n_fields, int* data_kind);
+ndt_status ndt_pcd_read_xyz(const char* path, void* out, size_t capacity_points, size_t stride_bytes, size_t* n_points,
+                            int* is_dense);
+ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t stride_bytes, int binary);
+
 /* ---- batch (map-build mode: many sources against the one target) ----------
  * Registers n_scans sources in lock-step, one fused derivative launch per
  * line-search step for the whole batch.  Scan k is points

@@ -473,3 +473,40 @@ def test_voxel_grid_filter(mods, pair):
     # the filter feeds NDT exactly like apps/align.cpp: same registration as with the oracle's filter
     t, s = pair
     assert np.array_equal(g.voxelGridFilter(t, 0.5), po.voxel_grid_filter(t, 0.5)[0])
+
+
+# ------------------------------------------------------------------ N2: global map accumulation
+def test_map_accumulation_matches_reference_loop(mods, pair):
+    """update_global_map (ndt_omp_mapping_node.cpp:195-211): transformPointCloud + '+=' + VoxelGrid,
+    three scans in a row, against the oracle's restatements of the same three PCL calls -- bit for bit."""
+    ndt, po, clouds = mods
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    rng = np.random.default_rng(21)
+    scans = [t, s, (s + rng.normal(0, 0.05, s.shape)).astype(np.float32)]
+    poses = [np.eye(4, dtype=np.float32),
+             clouds.make_T([0.30, -0.20, 0.10], np.deg2rad([0.5, -0.3, 1.0])).astype(np.float32),
+             clouds.make_T([0.70, -0.35, 0.12], np.deg2rad([0.9, -0.2, 2.1])).astype(np.float32)]
+    ref = np.zeros((0, 3), np.float32)
+    for leaf in (0.5, 0.2):
+        g.mapClear()
+        ref = np.zeros((0, 3), np.float32)
+        for scan, pose in zip(scans, poses):
+            n_map, ov = g.mapUpdate(scan, pose, leaf_size=leaf)
+            moved = po.transform_cloud(np.c_[scan[:, :3], np.ones(len(scan), np.float32)], pose)[:, :3]
+            ref, ov_ref = po.voxel_grid_filter(np.concatenate([ref, moved]), leaf)
+            assert not ov and not ov_ref and n_map == len(ref)
+            assert np.array_equal(g.mapGet(), ref)
+    # identity pose by default; clearing empties the map; an empty scan leaves the (re-filtered) map as it is
+    g.mapClear()
+    assert g.mapSize() == 0 and g.mapGet().shape == (0, 3)
+    g.mapUpdate(t, None, 0.5)
+    assert np.array_equal(g.mapGet(), po.voxel_grid_filter(t, 0.5)[0])
+    before = g.mapGet()
+    g.mapUpdate(np.zeros((0, 3), np.float32), None, 0.5)
+    assert np.array_equal(g.mapGet(), po.voxel_grid_filter(before, 0.5)[0])
+    # overflow: PCL keeps the unfiltered concatenation
+    g.mapClear()
+    far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
+    n_map, ov = g.mapUpdate(far, None, 0.01)
+    assert ov and n_map == 2 and np.array_equal(g.mapGet(), far)

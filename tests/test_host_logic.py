@@ -69,6 +69,24 @@ def test_solve6(ndt):
     assert np.isnan(ndt.host_solve6(Hn, b)).any()
 
 
+def test_chain_pose_is_eigen_f32_product(ndt):
+    """pose * transform of the mapping nodes: [Eigen] fixed-size Matrix4f product, no FMA, terms added
+    left to right."""
+    rng = np.random.default_rng(5)
+    f = np.float32
+    for _ in range(50):
+        a = po.pose_to_matrix(np.r_[rng.uniform(-50, 50, 3), rng.uniform(-3, 3, 3)])
+        b = po.pose_to_matrix(np.r_[rng.uniform(-1, 1, 3), rng.uniform(-0.2, 0.2, 3)])
+        ref = np.zeros((4, 4), f)
+        for i in range(4):
+            for j in range(4):
+                ref[i, j] = f(f(f(f(a[i, 0] * b[0, j]) + f(a[i, 1] * b[1, j])) + f(a[i, 2] * b[2, j])) + f(a[i, 3] * b[3, j]))
+        got = ndt.host_chain_pose(a, b)
+        assert np.array_equal(got, ref)
+        assert np.allclose(got, a.astype(np.float64) @ b.astype(np.float64), atol=1e-4)
+    assert np.array_equal(ndt.host_chain_pose(np.eye(4), a), a)
+
+
 def test_pose_to_matrix_bit_exact(ndt):
     rng = np.random.default_rng(1)
     for _ in range(200):

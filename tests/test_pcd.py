@@ -1,0 +1,181 @@
+"""Row N3: PCD v0.7 reader / writer of the C-ABI (host only, no GPU) against independent Python
+encoders / decoders of the same format and, when the reference tree is mounted, its own fixtures."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+REF_PCD = "/root/reference/ndt_omp/data/251370668.pcd"
+
+
+@pytest.fixture(scope="module")
+def ndt(built_lib):
+    from toyslam_amd import ndt as m
+    return m
+
+
+def lzf_compress(data):
+    """Independent LZF encoder (literal runs + back references) used only to make test inputs."""
+    out = bytearray()
+    lit = bytearray()
+    table = {}
+    i, n = 0, len(data)
+
+    def flush():
+        for k in range(0, len(lit), 32):
+            chunk = lit[k:k + 32]
+            out.append(len(chunk) - 1)
+            out.extend(chunk)
+        lit.clear()
+
+    while i < n:
+        key = bytes(data[i:i + 3])
+        j = table.get(key, -1)
+        if len(key) == 3:
+            table[key] = i
+        if j >= 0 and i - j <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[j + length] == data[i + length]:
+                length += 1
+            flush()
+            dist, l2 = i - j - 1, length - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8))
+                out.append(l2 - 7)
+            out.append(dist & 0xFF)
+            i += length
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def header(fields, sizes, types, counts, n, kind):
+    return ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\n"
+            "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n"
+            % (" ".join(fields), " ".join(map(str, sizes)), " ".join(types), " ".join(map(str, counts)), n, n, kind)).encode()
+
+
+def test_binary_round_trip_and_python_reader(ndt, tmp_path):
+    from toyslam_amd import clouds
+    rng = np.random.default_rng(3)
+    xyz = (rng.standard_normal((5000, 3)) * [30, 30, 3]).astype(np.float32)
+    p = str(tmp_path / "a.pcd")
+    ndt.pcd_write_xyz(p, xyz)
+    got, dense = ndt.pcd_read_xyz(p)
+    assert dense and np.array_equal(got, xyz)
+    py, names = clouds.read_pcd(p)
+    assert names == ["x", "y", "z"] and np.array_equal(py, xyz)
+    # written by the Python writer, read by the library
+    q = str(tmp_path / "b.pcd")
+    clouds.write_pcd_xyz(q, xyz)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    # 32-byte input records (XYZI-shaped cloud in memory)
+    wide = np.zeros((len(xyz), 8), np.float32)
+    wide[:, :3] = xyz
+    ndt.pcd_write_xyz(q, wide)
+    assert np.array_equal(ndt.pcd_read_xyz(q)[0], xyz)
+    # empty cloud
+    ndt.pcd_write_xyz(q, np.zeros((0, 3), np.float32))
+    assert ndt.pcd_read_xyz(q)[0].shape == (0, 3)
+
+
+def test_extra_fields_orders_and_types(ndt, tmp_path):
+    rng = np.random.default_rng(4)
+    n = 777
+    xyz = rng.standard_normal((n, 3)).astype(np.float32)
+    inten = rng.uniform(0, 255, n).astype(np.float32)
+    ring = rng.integers(0, 64, n).astype(np.uint16)
+    t64 = rng.standard_normal(n)
+    # fields out of order, mixed sizes, a COUNT 2 field in front of x
+    rec = np.zeros(n, dtype=[("pad", "<f4", (2,)), ("z", "<f4"), ("ring", "<u2"), ("x", "<f4"), ("t", "<f8"),
+                             ("intensity", "<f4"), ("y", "<f4")])
+    rec["z"], rec["x"], rec["y"] = xyz[:, 2], xyz[:, 0], xyz[:, 1]
+    rec["ring"], rec["t"], rec["intensity"] = ring, t64, inten
+    p = str(tmp_path / "m.pcd")
+    with open(p, "wb") as f:
+        f.write(header(["pad", "z", "ring", "x", "t", "intensity", "y"], [4, 4, 2, 4, 8, 4, 4],
+                       ["F", "F", "U", "F", "F", "F", "F"], [2, 1, 1, 1, 1, 1, 1], n, "binary"))
+        f.write(rec.tobytes())
+    got, dense = ndt.pcd_read_xyz(p)
+    assert dense and np.array_equal(got, xyz)
+    # f64 coordinates are narrowed like PCL's field mapping does
+    rec64 = np.zeros(n, dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8")])
+    rec64["x"], rec64["y"], rec64["z"] = t64, t64 * 2, t64 * 3
+    with open(p, "wb") as f:
+        f.write(header(["x", "y", "z"], [8, 8, 8], ["F", "F", "F"], [1, 1, 1], n, "binary"))
+        f.write(rec64.tobytes())
+    got, _ = ndt.pcd_read_xyz(p)
+    assert np.array_equal(got, np.stack([t64, t64 * 2, t64 * 3], 1).astype(np.float32))
+
+
+def test_ascii(ndt, tmp_path):
+    rng = np.random.default_rng(5)
+    xyz = (rng.standard_normal((300, 3)) * 10).astype(np.float32)
+    xyz[7, 1] = np.nan
+    p = str(tmp_path / "t.pcd")
+    ndt.pcd_write_xyz(p, xyz, binary=False)
+    got, dense = ndt.pcd_read_xyz(p)
+    assert not dense and np.isnan(got[7, 1])
+    ok = np.isfinite(xyz)
+    assert np.allclose(got[ok], xyz[ok], rtol=1e-7, atol=0)  # PCDWriter's 8 significant digits
+    # hand-written ascii with an intensity column and blank / comment lines
+    with open(p, "wb") as f:
+        f.write(header(["x", "y", "z", "intensity"], [4, 4, 4, 4], ["F"] * 4, [1] * 4, 3, "ascii"))
+        f.write(b"1 2 3 0.5\n\n-1.5e1 2.25 nan 7\n0.1 0.2 0.3 9\n")
+    got, dense = ndt.pcd_read_xyz(p)
+    assert not dense
+    assert np.array_equal(got[[0, 2]], np.array([[1, 2, 3], [0.1, 0.2, 0.3]], np.float32))
+    assert got[1, 0] == -15.0 and got[1, 1] == 2.25 and np.isnan(got[1, 2])
+
+
+def test_binary_compressed(ndt, tmp_path):
+    rng = np.random.default_rng(6)
+    n = 600
+    xyz = np.round(rng.standard_normal((n, 3)) * 4, 1).astype(np.float32)  # coarse values: the stream has back references
+    inten = np.repeat(np.float32(3.0), n)
+    soa = xyz[:, 0].tobytes() + xyz[:, 1].tobytes() + xyz[:, 2].tobytes() + inten.tobytes()
+    comp = lzf_compress(soa)
+    assert len(comp) < len(soa)
+    p = str(tmp_path / "c.pcd")
+    with open(p, "wb") as f:
+        f.write(header(["x", "y", "z", "intensity"], [4] * 4, ["F"] * 4, [1] * 4, n, "binary_compressed"))
+        f.write(struct.pack("<II", len(comp), len(soa)))
+        f.write(comp)
+    got, dense = ndt.pcd_read_xyz(p)
+    assert dense and np.array_equal(got, xyz)
+
+
+def test_errors(ndt, tmp_path):
+    from toyslam_amd import NdtError
+    with pytest.raises(NdtError):
+        ndt.pcd_read_xyz(str(tmp_path / "missing.pcd"))
+    p = str(tmp_path / "bad.pcd")
+    with open(p, "wb") as f:
+        f.write(header(["x", "y", "z"], [4, 4, 4], ["F"] * 3, [1] * 3, 10, "binary"))
+        f.write(b"\0" * 50)  # truncated
+    with pytest.raises(NdtError):
+        ndt.pcd_read_xyz(p)
+    with open(p, "wb") as f:
+        f.write(header(["a", "b", "c"], [4, 4, 4], ["F"] * 3, [1] * 3, 1, "binary"))
+        f.write(b"\0" * 12)
+    with pytest.raises(NdtError):
+        ndt.pcd_read_xyz(p)
+    with open(p, "wb") as f:
+        f.write(b"VERSION 0.7\nFIELDS x y z\n")  # no DATA line
+    with pytest.raises(NdtError):
+        ndt.pcd_read_xyz(p)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PCD), reason="reference tree not mounted")
+def test_reference_fixture(ndt):
+    """The reference's own scan (FIELDS x y z intensity, binary, 69 088 points)."""
+    from toyslam_amd import clouds
+    got, dense = ndt.pcd_read_xyz(REF_PCD)
+    py, names = clouds.read_pcd(REF_PCD)
+    assert names[:3] == ["x", "y", "z"] and got.shape == (69088, 3) and dense
+    assert np.array_equal(got, py[:, :3])

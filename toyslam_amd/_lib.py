@@ -69,6 +69,16 @@ SIGNATURES = {
     "ndt_calculate_score": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, dp]),
     "ndt_voxel_grid_filter": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, C.c_size_t, szp]),
     "ndt_voxel_grid_filter_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, szp]),
+    "ndt_map_clear": (C.c_int, [vp]),
+    "ndt_map_update": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, fp, C.c_float, ip]),
+    "ndt_map_update_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, fp, C.c_float, ip]),
+    "ndt_map_size": (C.c_int, [vp, szp]),
+    "ndt_map_get": (C.c_int, [vp, vp, C.c_size_t]),
+    "ndt_map_get_device": (C.c_int, [vp, C.POINTER(C.c_void_p), szp]),
+    "ndt_host_chain_pose": (None, [fp, fp, fp]),
+    "ndt_pcd_read_header": (C.c_int, [C.c_char_p, szp, ip, ip]),
+    "ndt_pcd_read_xyz": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.c_size_t, szp, ip]),
+    "ndt_pcd_write_xyz": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.c_size_t, C.c_int]),
     "ndt_align_batch": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_align_batch_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int]),

@@ -22,6 +22,7 @@
 
 #include "ndt_driver.hpp"
 #include "ndt_kernels.hpp"
+#include "ndt_pcd.hpp"
 #include "ndt_mi355.h"
 
 namespace {
@@ -211,6 +212,10 @@ struct ndt_context {
   size_t out_n = 0;
   // persistent evaluation server (single-scan align)
   bool server_running = false;
+  // N2: accumulated global map (dense float4, HBM resident)
+  DevBuf<float4> map_pts;
+  size_t map_n = 0;
+  int map_dense = 1;
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
   // Two command mailboxes, used by alternate server instances: a server told to finish (transform +
   // exit) is not waited for, and the next instance's first command must not overwrite the line the
@@ -1156,13 +1161,13 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
 }
 
 // ---- N1: voxel-grid centroid down-sample -----------------------------------
-static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf,
-                                    bool on_device, void* out, size_t out_stride, size_t* n_out) {
-  if (!h || !n_out || (n && !out) || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+// [PCL] VoxelGrid::applyFilter on a dense float4 device cloud: d_out (capacity n) receives one centroid
+// per occupied voxel in ascending voxel-index order; *overflow = the leaf is too small for the
+// bounding box and, as PCL does, the input was copied through.  Synchronises h->stream.
+static ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
+                                      size_t* n_out, bool* overflow) {
   *n_out = 0;
-  std::shared_ptr<DeviceCloud> c;
-  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
-  if (s) return s;
+  *overflow = false;
   if (n == 0) return NDT_OK;
   hipStream_t st = h->stream;
   const int ni = static_cast<int>(n);
@@ -1170,7 +1175,7 @@ static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, siz
   const int nb = std::min(1024, (ni + 255) / 256);
   DevBuf<float> d_mm;
   HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
-  HIP_TRY(ndt::launch_bbox(c->pts.p, ni, is_dense, d_mm.p, nb, st));
+  HIP_TRY(ndt::launch_bbox(d_in, ni, is_dense, d_mm.p, nb, st));
   std::vector<float> mm(static_cast<size_t>(nb) * 6);
   HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1188,6 +1193,61 @@ static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, siz
     geo.inv_leaf[k] = 1.0f / leaf;
     d[k] = static_cast<long long>((max_p[k] - min_p[k]) * geo.inv_leaf[k]) + 1;
   }
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
+    HIP_TRY(hipMemcpyAsync(d_out, d_in, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_out = n;
+    *overflow = true;
+    return NDT_OK;
+  }
+  for (int k = 0; k < 3; k++) {
+    geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+    geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+    geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(d_in, ni, is_dense, geo, key.p, rank.p, cell_count.p, st));
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const size_t n_leaves = tot[1];
+  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
+  HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
+  *n_out = n_leaves;
+  return NDT_OK;
+}
+
+static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf,
+                                    bool on_device, void* out, size_t out_stride, size_t* n_out) {
+  if (!h || !n_out || (n && !out) || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n_out = 0;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  if (n == 0) return NDT_OK;
   DevBuf<float4> d_out_tmp;
   float4* d_out = on_device ? static_cast<float4*>(out) : nullptr;
   if (!on_device) {
@@ -1195,57 +1255,17 @@ static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, siz
     d_out = d_out_tmp.p;
   }
   size_t n_written = 0;
-  ndt_status result = NDT_OK;
-  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
-    HIP_TRY(hipMemcpyAsync(d_out, c->pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
-    n_written = n;
-    result = fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
-  } else {
-    for (int k = 0; k < 3; k++) {
-      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
-      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
-      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
-    }
-    geo.mul[0] = 1;
-    geo.mul[1] = geo.div_b[0];
-    geo.mul[2] = geo.div_b[0] * geo.div_b[1];
-    geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
-    DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
-    DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
-    HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
-    HIP_TRY(key.reserve(n));
-    HIP_TRY(rank.reserve(n));
-    HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
-    HIP_TRY(ndt::launch_count(c->pts.p, ni, is_dense, geo, key.p, rank.p, cell_count.p, st));
-    const int n_tiles = ndt::scan_tiles(geo.n_cells);
-    HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
-    HIP_TRY(totals.reserve(4));
-    HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
-    HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
-    unsigned tot[3];
-    HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const size_t n_leaves = tot[1];
-    HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
-    HIP_TRY(leaf_cell.reserve(n_leaves));
-    HIP_TRY(leaf_start.reserve(n_leaves));
-    HIP_TRY(leaf_count.reserve(n_leaves));
-    HIP_TRY(leaf_rec.reserve(n_leaves));
-    HIP_TRY(sorted_idx.reserve(n));
-    HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
-                                   leaf_count.p, leaf_rec.p, st));
-    HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-    HIP_TRY(ndt::launch_voxel_centroids(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
-    HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
-    n_written = n_leaves;
-  }
+  bool overflow = false;
+  s = voxel_filter_device(h, c->pts.p, n, is_dense, leaf, d_out, &n_written, &overflow);
+  if (s) return s;
   if (!on_device && n_written) {
     if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
-    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_out, sizeof(float4), sizeof(float4), n_written, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_out, sizeof(float4), sizeof(float4), n_written, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  HIP_TRY(hipStreamSynchronize(st));
   *n_out = n_written;
-  return result;
+  if (overflow) return fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
+  return NDT_OK;
 }
 
 ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf, void* out,
@@ -1255,6 +1275,99 @@ ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t
 ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t n, size_t stride, int is_dense, float leaf,
                                         void* d_out, size_t* n_out) {
   return voxel_filter_impl(h, d_pts, n, stride, is_dense, leaf, true, d_out, 16, n_out);
+}
+
+// ---- N2: global map accumulation --------------------------------------------
+// update_global_map of the mapping nodes (ndt_omp_mapping_node.cpp:195-211,
+// ndt_rosbag_mapping_node.cpp:146-161): transformPointCloud(scan, pose); global_map += it;
+// global_map = VoxelGrid(leaf).filter(global_map).  The map stays in HBM.
+static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, bool on_device,
+                                  const float* pose, float leaf, int* overflowed) {
+  if (!h || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (overflowed) *overflowed = 0;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, scan, n, stride, on_device, c);
+  if (s) return s;
+  const size_t total = h->map_n + n;
+  if (total > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "map too large");
+  if (total == 0) return NDT_OK;
+  // concatenation [map | transformed scan] (operator+= keeps the map's points first)
+  DevBuf<float4> cat;
+  HIP_TRY(cat.reserve(total));
+  if (h->map_n) HIP_TRY(hipMemcpyAsync(cat.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+  if (n) {
+    float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float T12[12];
+    colmajor_to_T12(pose ? pose : I, T12);
+    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, cat.p + h->map_n, h->stream, is_dense));
+  }
+  HIP_TRY(h->map_pts.reserve(total));
+  size_t n_new = 0;
+  bool overflow = false;
+  // the accumulated map is dense only if every scan was; PCL carries is_dense through operator+=
+  h->map_dense = (h->map_n == 0 ? 1 : h->map_dense) && is_dense;
+  s = voxel_filter_device(h, cat.p, total, h->map_dense, leaf, h->map_pts.p, &n_new, &overflow);
+  if (s) return s;
+  h->map_n = n_new;
+  if (overflowed) *overflowed = overflow ? 1 : 0;
+  return NDT_OK;
+}
+
+ndt_status ndt_map_clear(ndt_handle h) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  h->map_n = 0;
+  h->map_dense = 1;
+  return NDT_OK;
+}
+ndt_status ndt_map_update(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, const float* pose, float leaf,
+                          int* overflowed) {
+  return map_update_impl(h, scan, n, stride, is_dense, false, pose, leaf, overflowed);
+}
+ndt_status ndt_map_update_device(ndt_handle h, const void* d_scan, size_t n, size_t stride, int is_dense, const float* pose,
+                                 float leaf, int* overflowed) {
+  return map_update_impl(h, d_scan, n, stride, is_dense, true, pose, leaf, overflowed);
+}
+ndt_status ndt_map_size(ndt_handle h, size_t* n) {
+  if (!h || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n = h->map_n;
+  return NDT_OK;
+}
+ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride) {
+  if (!h || (h->map_n && !out)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+  if (h->map_n == 0) return NDT_OK;
+  HIP_TRY(hipMemcpy2DAsync(out, out_stride, h->map_pts.p, sizeof(float4), sizeof(float4), h->map_n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts, size_t* n) {
+  if (!h || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->device_ready) HIP_TRY(hipStreamSynchronize(h->stream));
+  *d_pts = h->map_pts.p;
+  *n = h->map_n;
+  return NDT_OK;
+}
+void ndt_host_chain_pose(const float* pose, const float* transform, float* out) { ndt::chain_pose(pose, transform, out); }
+
+// ---- N3: PCD files -------------------------------------------------------------
+ndt_status ndt_pcd_read_header(const char* path, size_t* n_points, int* n_fields, int* data_kind) {
+  if (!path) return fail(NDT_ERR_INVALID, "null path");
+  std::string err;
+  if (ndt::pcd_read_header(path, n_points, n_fields, data_kind, err)) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
+}
+ndt_status ndt_pcd_read_xyz(const char* path, void* out, size_t capacity_points, size_t stride_bytes, size_t* n_points,
+                            int* is_dense) {
+  if (!path || (capacity_points && !out) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  std::string err;
+  if (ndt::pcd_read_xyz(path, out, capacity_points, stride_bytes, n_points, is_dense, err)) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
+}
+ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t stride_bytes, int binary) {
+  if (!path || (n && !pts) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  std::string err;
+  if (ndt::pcd_write_xyz(path, pts, n, stride_bytes, binary, err)) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
 }
 
 // ---- batch ---------------------------------------------------------------

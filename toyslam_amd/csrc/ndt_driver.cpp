@@ -261,6 +261,14 @@ void matrix_to_pose(const float T[16], double p[6]) {
 }
 
 // ---------------------------------------------------------------------------
+void chain_pose(const float a[16], const float b[16], float out[16]) {
+  float r[16];
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++)
+      r[j * 4 + i] = ((a[0 * 4 + i] * b[j * 4 + 0] + a[1 * 4 + i] * b[j * 4 + 1]) + a[2 * 4 + i] * b[j * 4 + 2]) + a[3 * 4 + i] * b[j * 4 + 3];
+  std::memcpy(out, r, sizeof(r));
+}
+
 void snapped_cos_sin(const double p[6], double cs[6]) {
   for (int k = 0; k < 3; k++) {
     if (std::fabs(p[3 + k]) < 10e-5) {

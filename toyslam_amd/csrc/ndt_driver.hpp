@@ -27,6 +27,10 @@ void pose_to_matrix(const double p[6], float T[16]);
 // translation + rotation().eulerAngles(0,1,2)  (ndt_omp_impl.hpp:103-111).
 void matrix_to_pose(const float T[16], double p[6]);
 
+// pose * transform of the mapping nodes (ndt_omp_mapping_node.cpp:88-99, ndt_rosbag_mapping_node.cpp:62-68):
+// [Eigen] fixed-size Matrix4f product, column-major, each entry ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j) + a_i3 b_3j.
+void chain_pose(const float a[16], const float b[16], float out[16]);
+
 // computeAngleDerivatives, ndt_omp_impl.hpp:288-395.  j/h are the f32 matrices
 // (h row 6 carries +sy, :383); jd/hd the f64 vectors used by computeHessian
 // (hd row 6 carries -sy, :361).

@@ -688,13 +688,14 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const double* __restr
   }
 }
 
-// transformed source cloud ("output" of align), w = 1
+// transformed source cloud ("output" of align), w = 1.  dense = 0: [PCL] transformPointCloud leaves
+// non-finite points as they are.
 __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__ src, int n, EvalParams P,
-                                                      float4* __restrict__ dst) {
+                                                      float4* __restrict__ dst, int dense) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 pt = src[i];
-    float tx, ty, tz;
-    xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    float tx = pt.x, ty = pt.y, tz = pt.z;
+    if (dense || finite3(pt.x, pt.y, pt.z)) xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
     dst[i] = make_float4(tx, ty, tz, 1.0f);
   }
 }
@@ -919,11 +920,11 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
   return hipGetLastError();
 }
 
-hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream) {
+hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream, int dense) {
   if (n == 0) return hipSuccess;
   EvalParams P = {};
   for (int i = 0; i < 12; i++) P.T[i] = T12[i];
-  hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, src, n, P, dst);
+  hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, src, n, P, dst, dense);
   return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@ lidar_subscriber/src/ndt_omp_mapping_node.cpp:151-169).  All compute happens in
 libndt_mi355.so on the GPU; nothing here falls back to numpy.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -182,6 +183,31 @@ class NormalDistributionsTransform:
                                                    float(leaf_size), C.c_void_p(out_dev_ptr), C.byref(m)))
         return m.value
 
+    # ---- global map (N2) ------------------------------------------------------------
+    def mapClear(self):
+        check(self._L.ndt_map_clear(self._h))
+
+    def mapUpdate(self, scan, pose=None, leaf_size=0.5, is_dense=True):
+        """update_global_map of the mapping nodes: transform the scan by `pose`, append it to the
+        HBM-resident map, voxel-filter the map.  Returns (map size, overflowed)."""
+        a = _cloud(scan)
+        T = None if pose is None else _colmajor(pose)
+        ov = C.c_int(0)
+        check(self._L.ndt_map_update(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, int(is_dense),
+                                     _f(T) if T is not None else None, float(leaf_size), C.byref(ov)))
+        return self.mapSize(), bool(ov.value)
+
+    def mapSize(self):
+        n = C.c_size_t(0)
+        check(self._L.ndt_map_size(self._h, C.byref(n)))
+        return n.value
+
+    def mapGet(self):
+        n = self.mapSize()
+        out = np.zeros((max(n, 1), 4), dtype=np.float32)
+        check(self._L.ndt_map_get(self._h, out.ctypes.data, 16))
+        return out[:n, :3].copy()
+
     # ---- batch (map-build) ---------------------------------------------------------
     def alignBatch(self, clouds=None, guesses=None, device_ptr=None, offsets=None, stride_bytes=16):
         """Register many sources against the one target in lock-step.
@@ -306,6 +332,29 @@ def host_solve6(H, b):
     x = np.zeros(6)
     _lib.lib().ndt_host_solve6(_d(H), _d(b), _d(x))
     return x
+
+
+def pcd_read_xyz(path):
+    """loadPCDFile<PointXYZ> through the C-ABI: ((N, 3) float32, is_dense)."""
+    L = _lib.lib()
+    n, nf, kind = C.c_size_t(0), C.c_int(0), C.c_int(0)
+    check(L.ndt_pcd_read_header(os.fsencode(path), C.byref(n), C.byref(nf), C.byref(kind)))
+    out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+    dense = C.c_int(1)
+    check(L.ndt_pcd_read_xyz(os.fsencode(path), out.ctypes.data, n.value, 16, C.byref(n), C.byref(dense)))
+    return out[:n.value, :3].copy(), bool(dense.value)
+
+
+def pcd_write_xyz(path, xyz, binary=True):
+    a = _cloud(xyz)
+    check(_lib.lib().ndt_pcd_write_xyz(os.fsencode(path), a.ctypes.data, a.shape[0], a.shape[1] * 4, int(binary)))
+
+
+def host_chain_pose(pose, transform):
+    """pose * transform in Eigen's f32 rounding (the nodes' trajectory chaining)."""
+    out = np.zeros(16, dtype=np.float32)
+    _lib.lib().ndt_host_chain_pose(_f(_colmajor(pose)), _f(_colmajor(transform)), _f(out))
+    return _from_colmajor(out)
 
 
 def host_pose_to_matrix(p):
