@@ -14,8 +14,9 @@ independent, so every rank registers its own scan against its own replica of the
 no collective in the data path ("scaling": "weak"); value = N*K / max-over-ranks time.
 
 Rank 0 prints ONE JSON line.  Extra legs on rank 0 (outside the timed region):
-  roofline     -- average duration of the dominant kernel (k_derivatives<DIRECT7, hessian>) from
-                  HIP events on the library's own stream, over a second pass of the same steps.
+  roofline     -- average duration of the dominant kernel (k_eval_server: one persistent launch per
+                  registration) from HIP events on the library's own stream, over a second pass of
+                  the same steps; algorithmic bytes = evaluations served x bytes per evaluation.
   cpu_baseline -- the oracle (oracle/, a faithful OpenMP port of the reference's algorithm; the real
                   pclomp cannot be built here) on the same inputs on the host cores (N = 1 only).
 """
@@ -140,6 +141,8 @@ def main():
     out = None
     if rank == 0:
         st = reg.stats() if args.workload in ("single", "large") else {}
+        T_timed = reg.getFinalTransformation() if args.workload in ("single", "large") else None
+        it_timed = reg.getFinalNumIteration() if args.workload in ("single", "large") else None
         value = world * args.steps * regs_per_step / dt
         out = {
             "metric": METRIC, "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
@@ -162,16 +165,27 @@ def main():
             out["f64_hessian_recomputes"] = st["n_hessian_recomputes"]
             out["mean_neighbors"] = st["mean_neighbors"]
             # ---- roofline leg: HIP events on the library's stream, second pass of the same steps ----
-            reg.profile(True)
-            reg.profile_read(0)
-            for _ in range(min(args.steps, 10)):
+            # The kernel of the timed region is k_eval_server: ONE launch per registration that serves
+            # every evaluation of it.  ndt_profile_enable(2) brackets that launch with an event pair.
+            n_rep = min(args.steps, 10)
+            reg.profile(2)
+            reg.profile_read(3)
+            for _ in range(n_rep):
                 reg.align()
-            n_launch, ms = reg.profile_read(0)
-            reg.profile(False)
-            full = reg.eval(ndt.host_matrix_to_pose(reg.getFinalTransformation()), True)
-            hbar = full[3]
+            n_launch, ms = reg.profile_read(3)
+            st2 = reg.stats()
+            # ... and, for reference, the same device code as one launch per evaluation (profile mode 1)
+            reg.profile(1)
+            reg.profile_read(0)
+            for _ in range(n_rep):
+                reg.align()
+            n_eval_launch, ms_eval = reg.profile_read(0)
+            reg.profile(0)
+            hbar = st2["mean_neighbors"]
             avg_s = ms * 1e-3 / max(n_launch, 1)
-            bytes_per_launch = algorithmic_bytes_per_eval(N_SOURCE, hbar)
+            bytes_per_eval = algorithmic_bytes_per_eval(N_SOURCE, hbar)
+            evals_per_launch = st2["n_evals"] + st2["n_hessian_recomputes"]
+            bytes_per_launch = evals_per_launch * bytes_per_eval
             achieved = bytes_per_launch / avg_s / 1e9
             # HBM traffic of the same kernel from the committed PMC passes of this command
             # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; unit KB; gfx950
@@ -180,22 +194,28 @@ def main():
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", "r01_profile_summary.json")))
                 for name, c in prof["pmc"].items():
-                    if "k_derivatives_fused<7, true" in name and args.workload == "single":
+                    if "k_eval_server<7>" in name and args.workload == "single":
                         traffic = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
                         traffic_src = "profiles/r01_profile_summary.json"
             except Exception:
                 pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "k_derivatives_fused<DIRECT7, hessian> (derivatives + final reduce + publish)",
-                               "avg_kernel_us": avg_s * 1e6,
-                               "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                               "mean_neighbors": hbar,
-                               "how": "hipEvent pairs on the library stream around each launch, in a second pass of the "
-                                      "same steps with one launch per evaluation; the timed region itself runs the "
-                                      "same device code inside one persistent launch per registration (k_eval_server)"}
+                               "kernel": "k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
+                                         "their reductions, the f64 Hessian recompute and the output transform)",
+                               "avg_kernel_us": avg_s * 1e6, "launches_timed": n_launch,
+                               "evaluations_per_launch": evals_per_launch,
+                               "algorithmic_bytes_per_evaluation": bytes_per_eval,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "mean_neighbors": hbar,
+                               "how": "one hipEvent pair on the library stream around the kernel of each registration "
+                                      "(ndt_profile_enable(2)), in a second pass of the same steps",
+                               "per_evaluation_kernel": {
+                                   "kernel": "k_derivatives_fused<DIRECT7, hessian>: the same device code as one launch "
+                                             "per evaluation (ndt_profile_enable(1))",
+                                   "avg_event_us": ms_eval * 1e3 / max(n_eval_launch, 1), "launches_timed": n_eval_launch,
+                                   "achieved_GBs": bytes_per_eval / (ms_eval * 1e-3 / max(n_eval_launch, 1)) / 1e9}}
             out["us_per_evaluation_in_timed_region"] = dt / args.steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
-            out["registration_algorithmic_GBs"] = st["n_evals"] * bytes_per_launch / (dt / args.steps) / 1e9
+            out["registration_algorithmic_GBs"] = (st["n_evals"] + st["n_hessian_recomputes"]) * bytes_per_eval / (dt / args.steps) / 1e9
             # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
             if world == 1 and not args.no_cpu_baseline and args.workload == "single":
                 from oracle import pyoracle as po
@@ -216,7 +236,7 @@ def main():
                     o.align()
                     times.append(time.perf_counter() - ta)
                 med = float(np.median(times))
-                T = reg.getFinalTransformation()
+                T = T_timed  # result of the timed region's last registration
                 out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
                                        "sample": "%d full registrations of the same workload (median), after 1 warm-up; "
                                                  "align only, target grid resident" % len(times),
@@ -224,7 +244,7 @@ def main():
                                        "evaluations": r["n_evals"], "host_cores_visible": len(os.sched_getaffinity(0))}
                 out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T[:3, :3] - r["T"][:3, :3]).max()),
                                            "trans_max_abs_m": float(np.abs(T[:3, 3] - r["T"][:3, 3]).max()),
-                                           "iterations_gpu": reg.getFinalNumIteration(), "iterations_oracle": r["iterations"],
+                                           "iterations_gpu": it_timed, "iterations_oracle": r["iterations"],
                                            "evals_gpu": st["n_evals"], "evals_oracle": r["n_evals"]}
                 out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
         print(json.dumps(out), flush=True)

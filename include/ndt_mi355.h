@@ -193,11 +193,12 @@ ndt_status ndt_grid_info(ndt_handle h, int* min_b /*3*/, int* max_b /*3*/, int* 
 ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mean, double* cov, double* icov,
                          double* evals);
 
-/* Live kernel timing with HIP events recorded on the handle's own stream
- * (bench.py's roofline leg).  While enabled, every derivative-kernel launch is
- * bracketed by an event pair; kind 0 = derivatives with Hessian (the dominant
- * kernel), 1 = without, 2 = f64 Hessian.  Off by default (the event pairs cost
- * host time). */
+/* Live kernel timing with HIP events recorded on the handle's own stream (bench.py's roofline leg).
+ * on = 1: ndt_align runs one launch per evaluation and brackets each with an event pair; kind 0 =
+ *         derivatives with Hessian, 1 = without, 2 = f64 Hessian.
+ * on = 2: ndt_align keeps its persistent kernel (one launch per registration, the kernel of the
+ *         timed region) and brackets that launch with one event pair; kind 3.
+ * Off (0) by default: the event records cost host time. */
 ndt_status ndt_profile_enable(ndt_handle h, int on);
 
 /* How ndt_align evaluates: 1 (default) = one persistent kernel per registration, fed one command

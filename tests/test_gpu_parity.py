@@ -279,6 +279,35 @@ def test_persistent_server_equals_launch_per_evaluation(mods, pair, method):
     assert np.array_equal(a[4], b[4])
 
 
+def test_profiled_align_is_the_same_align(mods, pair):
+    """bench.py's roofline leg times the kernels with HIP events (ndt_profile_enable): that mode must
+    run the same registration, evaluation for evaluation."""
+    ndt, po, clouds = mods
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    g.setInputSource(s)
+    g.align()
+    T0, it0, st0 = g.getFinalTransformation().copy(), g.getFinalNumIteration(), g.stats()
+    g.profile(True)
+    g.profile_read(0), g.profile_read(1), g.profile_read(2)
+    g.align()
+    n0, ms0 = g.profile_read(0)
+    n1, _ = g.profile_read(1)
+    n2, _ = g.profile_read(2)
+    g.profile(False)
+    assert np.array_equal(g.getFinalTransformation(), T0) and g.getFinalNumIteration() == it0
+    assert n0 + n1 == st0["n_evals"] and n2 == st0["n_hessian_recomputes"] and n0 >= 1 and ms0 > 0
+    # mode 2: the persistent kernel of the registration between one event pair
+    g.profile(2)
+    g.profile_read(3)
+    g.align()
+    g.align()
+    n3, ms3 = g.profile_read(3)
+    g.profile(0)
+    assert np.array_equal(g.getFinalTransformation(), T0) and n3 == 2 and 0 < ms3 < 1e3
+
+
 def test_point_stride_32_and_clone(mods, pair):
     """PointXYZI/XYZRGB are 32-byte records; copies share the device grid (value semantics of the nodes)."""
     ndt, _, _ = mods

@@ -229,10 +229,12 @@ struct ndt_context {
   bool server_want_dbg = false;
   int cu_count = 0;
   // live kernel timing (HIP events on `stream`)
-  bool profiling = false;
+  bool profiling = false;       // mode 1: one launch per evaluation, an event pair around each
+  bool profile_server = false;  // mode 2: the persistent kernel of each registration between one event pair
+  bool server_timed = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  long long prof_n[3] = {0, 0, 0};
-  double prof_ms[3] = {0, 0, 0};
+  long long prof_n[4] = {0, 0, 0, 0};
+  double prof_ms[4] = {0, 0, 0, 0};
   // collective hook
   ndt_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -739,6 +741,10 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   } else {
     if (!fused) HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (fused) {
+      if (!pub_ready(h->host_pub, seq)) return fail(NDT_ERR_HIP, "evaluation finished without publishing its result");
+      pub_gather(h->host_pub, h->host_result);
+    }
   }
   if (h->profiling) {
     float ms = 0;
@@ -797,6 +803,8 @@ ndt_status server_start(ndt_context* h) {
   const float r2 = kd_radius2(h->resolution);
   int pad_bits;
   std::memcpy(&pad_bits, &r2, sizeof(int));
+  h->server_timed = h->profile_server;
+  if (h->server_timed) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
                                   h->partials.p, h->server_counter.p, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
@@ -1092,6 +1100,15 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   const int n = static_cast<int>(h->source->n);
   if (h->server_running) {
     server_finish(h, h->final_T);  // the server writes it on its way out
+    if (h->server_timed) {  // ndt_profile_enable(h, 2): duration of this registration's kernel
+      HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+      HIP_TRY(hipEventSynchronize(h->ev_b));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+      h->prof_n[3]++;
+      h->prof_ms[3] += ms;
+      h->server_timed = false;
+    }
   } else {
     HIP_TRY(h->out_cloud.reserve(n));
     float T12[12];
@@ -1697,12 +1714,13 @@ ndt_status ndt_profile_enable(ndt_handle h, int on) {
     if (!h->ev_a) HIP_TRY(hipEventCreate(&h->ev_a));
     if (!h->ev_b) HIP_TRY(hipEventCreate(&h->ev_b));
   }
-  h->profiling = on != 0;
+  h->profiling = on == 1;
+  h->profile_server = on == 2;
   return NDT_OK;
 }
 
 ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset) {
-  if (!h || kind < 0 || kind > 2) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h || kind < 0 || kind > 3) return fail(NDT_ERR_INVALID, "bad arguments");
   if (n_launches) *n_launches = h->prof_n[kind];
   if (total_ms) *total_ms = h->prof_ms[kind];
   if (reset) {

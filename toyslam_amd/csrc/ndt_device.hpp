@@ -637,7 +637,9 @@ __device__ __forceinline__ void finish_point64(double (&acc)[kNumAcc], const Poi
 
 // all-f64 Hessian contributions (computeHessian / updateHessian, ndt_omp_impl.hpp:584-645) of the
 // points first, first + stride, ... into acc
-template <int NNB>
+// LATE_TABLES: a compiler-level memory fence in front of the per-point finish keeps the 69 f64 table
+// entries from being loaded (and, in the evaluation server, spilled) ahead of the neighbour loop.
+template <int NNB, bool LATE_TABLES = false>
 __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, int n, const GridView& gv,
                                                const Hess64Params& prm, int first, int stride, double (&acc)[kNumAcc]) {
   for (int i = first; i < n; i += stride) {
@@ -671,6 +673,7 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
       pa.a00 += e * c00 + t0 * xc0; pa.a01 += e * c01 + t0 * xc1; pa.a02 += e * c02 + t0 * xc2;
       pa.a11 += e * c11 + t1 * xc1; pa.a12 += e * c12 + t1 * xc2; pa.a22 += e * c22 + t2 * xc2;
     }
+    if (LATE_TABLES) asm volatile("" ::: "memory");
     if (any) finish_point64(acc, pa, prm, pt.x, pt.y, pt.z);
   }
 }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       // into registers the hot rounds need (the opaque copy of `first` pins them inside the branch)
       int first64 = first;
       asm volatile("" : "+v"(first64));
-      hessian64_body<NNB>(src, n, gv, sP64, first64, stride, acc);
+      hessian64_body<NNB, true>(src, n, gv, sP64, first64, stride, acc);
     } else if (NNB == 27) {
       if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
       else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);

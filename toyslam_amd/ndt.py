@@ -279,7 +279,8 @@ class NormalDistributionsTransform:
         check(self._L.ndt_profile_enable(self._h, int(on)))
 
     def profile_read(self, kind=0, reset=True):
-        """(launches, total_ms) of the derivative kernel of `kind`, from HIP events on the handle's stream."""
+        """(launches, total_ms) of the kernel of `kind` (0/1/2: per-evaluation launches of profile(1);
+        3: the per-registration persistent kernel of profile(2)), from HIP events on the handle's stream."""
         n = C.c_longlong(0)
         ms = C.c_double(0)
         check(self._L.ndt_profile_read(self._h, kind, C.byref(n), C.byref(ms), int(reset)))
