@@ -193,7 +193,6 @@ struct ndt_context {
   DevBuf<unsigned> ticket;  // zero between launches (reset by the last block of the fused kernel)
   DevBuf<double> batch_out;
   DevBuf<ndt::ScanDesc> descs;
-  DevBuf<int> batch_active;  // per kind: indices of the scans that want it this step
   void* batch_pinned = nullptr;  // pinned staging: [n_scans] ScanDesc + [3 n_scans] int
   size_t batch_pinned_bytes = 0;
   DevBuf<float4> out_cloud;
@@ -1411,7 +1410,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   std::vector<ndt::ScanSolver> solvers(n_scans);
   // per-step descriptors live in pinned host memory: the H2D copies are then truly asynchronous
-  const size_t pinned_need = n_scans * sizeof(ndt::ScanDesc) + 3 * n_scans * sizeof(int);
+  const size_t pinned_need = n_scans * sizeof(ndt::ScanDesc) + 4 * n_scans * sizeof(int);  // + per-kind and all-kinds active lists
   if (pinned_need > h->batch_pinned_bytes) {
     if (h->batch_pinned) (void)hipHostFree(h->batch_pinned);
     h->batch_pinned = nullptr;
@@ -1436,8 +1435,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   constexpr int kBlockBudget = 4096;
   HIP_TRY(h->partials.reserve(n_scans * max_blocks * ndt::kEvalStride));
   HIP_TRY(h->batch_out.reserve(n_scans * ndt::kEvalStride));
-  HIP_TRY(h->descs.reserve(n_scans));
-  HIP_TRY(h->batch_active.reserve(3 * n_scans));
+  HIP_TRY(h->descs.reserve((pinned_need + sizeof(ndt::ScanDesc) - 1) / sizeof(ndt::ScanDesc)));  // descriptors + the 3 active lists
   const ndt::GridView gv = h->grid->view();
   const bool degenerate = h->grid->empty;
   static const int n_host_threads = [] {
@@ -1446,7 +1444,13 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     return static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
   }();
   StepPool pool(n_scans >= 32 ? n_host_threads : 1);
+  static const bool batch_timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
+  double t_fill = 0, t_gpu = 0, t_feed = 0;
+  int n_steps = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   for (;;) {
+    const auto tb0 = now();
     int n_act[3] = {0, 0, 0};
     for (size_t k = 0; k < n_scans; k++) {
       if (solvers[k].done()) {
@@ -1460,6 +1464,17 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     if (n_act[0] + n_act[1] + n_act[2] == 0) break;
     int nblk_kind[3];
     for (int c = 0; c < 3; c++) nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / std::max(1, n_act[c])));
+    // scans asking for different kinds in the same step: one launch over all of them
+    const int n_live = n_act[0] + n_act[1] + n_act[2];
+    const bool mixed = (n_act[0] != n_live && n_act[1] != n_live && n_act[2] != n_live) && ndt::derivative_variant() == 0;
+    if (mixed) {
+      int* all = active + 3 * n_scans;
+      int m = 0;
+      for (int c = 0; c < 3; c++) {
+        nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / n_live));
+        for (int i = 0; i < n_act[c]; i++) all[m++] = active[c * n_scans + i];
+      }
+    }
     pool.run(n_scans, [&](size_t k) {  // per-scan parameter tables (sin/cos, pose -> matrix)
       if (descs[k].kind == ndt::EVAL_NONE) return;
       const ndt::EvalRequest& rq = solvers[k].request();
@@ -1467,36 +1482,78 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, kd_radius2(h->resolution), descs[k].P64);
       else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[k].P);
     });
+    const auto tb1 = now();
     if (degenerate) {
       std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
     } else {
-      HIP_TRY(hipMemcpyAsync(h->descs.p, descs, n_scans * sizeof(ndt::ScanDesc), hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipMemcpyAsync(h->batch_active.p, active, 3 * n_scans * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      // one H2D copy: descriptors and the three active lists are contiguous in the pinned block
+      HIP_TRY(hipMemcpyAsync(h->descs.p, descs, pinned_need, hipMemcpyHostToDevice, h->stream));
+      const int* d_active = reinterpret_cast<const int*>(h->descs.p + n_scans);
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
-      if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, h->batch_active.p, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));
-      if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, h->batch_active.p + n_scans, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
-      if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, h->batch_active.p + 2 * n_scans, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
-      HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
-      if (h->allreduce && h->allreduce_on_device) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->allreduce(h->batch_out.p, n_scans * ndt::kEvalStride, 1, h->allreduce_user))
-          return fail(NDT_ERR_COMM, "allreduce callback failed");
+      if (mixed) {
+        HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * n_scans, n_live, max_blocks, nblk_kind[0], h->partials.p, h->stream));
+      } else {
+        if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, d_active, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));
+        if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + n_scans, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
+        if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * n_scans, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
       }
-      HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, n_scans * ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      if (h->allreduce && !h->allreduce_on_device) {
-        if (h->allreduce(h->host_result, n_scans * ndt::kEvalStride, 0, h->allreduce_user))
-          return fail(NDT_ERR_COMM, "allreduce callback failed");
+      if (h->allreduce) {
+        HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
+        if (h->allreduce_on_device) {
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          if (h->allreduce(h->batch_out.p, n_scans * ndt::kEvalStride, 1, h->allreduce_user))
+            return fail(NDT_ERR_COMM, "allreduce callback failed");
+        }
+        HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, n_scans * ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (!h->allreduce_on_device) {
+          if (h->allreduce(h->host_result, n_scans * ndt::kEvalStride, 0, h->allreduce_user))
+            return fail(NDT_ERR_COMM, "allreduce callback failed");
+        }
+      } else {
+        // the reduce kernel writes every live scan's row and then its sequence word (slot 31)
+        // straight into pinned host memory; poll those instead of a D2H copy + stream synchronise
+        const unsigned long long seq = ++h->eval_seq;
+        HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->host_result, h->stream, seq));
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        for (size_t k = 0; k < n_scans; k++) {
+          if (descs[k].kind == ndt::EVAL_NONE) continue;
+          volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result + k * ndt::kEvalStride) + (ndt::kEvalStride - 1);
+          while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+              if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                return fail(NDT_ERR_HIP, "batch step finished without publishing its results");
+              }
+              if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+                return fail(NDT_ERR_HIP, "timed out waiting for the batch step");
+            }
+          }
+        }
       }
     }
+    const auto tb2 = now();
     pool.run(n_scans, [&](size_t k) {  // Newton / More-Thuente step of every live scan
       if (descs[k].kind == ndt::EVAL_NONE) return;
       ndt::EvalResult r;
       unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, nullptr);
       solvers[k].feed(r);
     });
+    const auto tb3 = now();
+    static const bool step_dump = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) >= 2; }();
+    if (step_dump) std::fprintf(stderr, "[step %d] act H=%d noH=%d h64=%d blocks/scan=%d/%d/%d gpu=%.1fus\n", n_steps, n_act[0], n_act[1], n_act[2], nblk_kind[0], nblk_kind[1], nblk_kind[2], secs(tb1, tb2) * 1e6);
+    t_fill += secs(tb0, tb1);
+    t_gpu += secs(tb1, tb2);
+    t_feed += secs(tb2, tb3);
+    n_steps++;
   }
+  if (batch_timing)
+    std::fprintf(stderr, "[ndt batch timing] scans=%zu steps=%d fill=%.1fus gpu(launch+wait)=%.1fus feed=%.1fus per step\n", n_scans,
+                 n_steps, t_fill / std::max(1, n_steps) * 1e6, t_gpu / std::max(1, n_steps) * 1e6, t_feed / std::max(1, n_steps) * 1e6);
   for (size_t k = 0; k < n_scans; k++) {
     if (final_T) std::memcpy(final_T + 16 * k, solvers[k].final_T, 16 * sizeof(float));
     if (conv) conv[k] = solvers[k].converged ? 1 : 0;

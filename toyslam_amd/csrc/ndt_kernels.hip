@@ -645,6 +645,46 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
 
+// One launch for a lock-step batch step in which the scans ask for DIFFERENT kinds of evaluation
+// (late in a batch: a few scans still in their line search, some recomputing the f64 Hessian).
+// grid.y walks all live scans; the kind is block-uniform (read from the scan's descriptor).  Three
+// separate launches of the specialised kernels serialise and each pays its own ramp-up; steps in which
+// every live scan wants the same kind keep using those.
+template <int NNB>
+__global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict__ src, GridView gv,
+                                                       const ScanDesc* __restrict__ descs, const int* __restrict__ active,
+                                                       int max_blocks, double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * 32];
+  __shared__ EvalParams sP;
+  __shared__ Hess64Params sP64;
+  const int scan = active[blockIdx.y];
+  const ScanDesc* dsc = descs + scan;
+  const int kind = dsc->kind;
+  {
+    const int* sp = (kind == 2) ? reinterpret_cast<const int*>(&dsc->P64) : reinterpret_cast<const int*>(&dsc->P);
+    int* dp = (kind == 2) ? reinterpret_cast<int*>(&sP64) : reinterpret_cast<int*>(&sP);
+    const int words = static_cast<int>(((kind == 2) ? sizeof(Hess64Params) : sizeof(EvalParams)) / 4);
+    for (int t = threadIdx.x; t < words; t += kBlock) dp[t] = sp[t];
+  }
+  __syncthreads();
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  const float4* pts = src + dsc->offset;
+  const int n = dsc->count;
+  if (kind == 2) {
+    hessian64_body<NNB, true>(pts, n, gv, sP64, first, stride, acc);
+  } else if (NNB == 27) {
+    if (kind == 0) derivatives_body_kd<true>(pts, n, gv, sP, first, stride, acc);
+    else derivatives_body_kd<false>(pts, n, gv, sP, first, stride, acc);
+  } else {
+    if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(pts, n, gv, sP, first, stride, acc);
+    else derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(pts, n, gv, sP, first, stride, acc);
+  }
+  block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
+}
+
 // ---------------------------------------------------------------------------
 // fixed-order reduction of the per-block partials
 // ---------------------------------------------------------------------------
@@ -889,6 +929,16 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
     if (want_hessian) NDT_LAUNCH_DERIV(7, true, 0); else NDT_LAUNCH_DERIV(7, false, 0);
   }
 #undef NDT_LAUNCH_DERIV
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
+                             int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream) {
+  const dim3 grid(n_blocks, n_active), block(kBlock);
+  if (search == 0) hipLaunchKernelGGL(k_batch_step<27>, grid, block, 0, stream, src, gv, descs, active, max_blocks, partials);
+  else if (search == 1) hipLaunchKernelGGL(k_batch_step<26>, grid, block, 0, stream, src, gv, descs, active, max_blocks, partials);
+  else if (search == 3) hipLaunchKernelGGL(k_batch_step<1>, grid, block, 0, stream, src, gv, descs, active, max_blocks, partials);
+  else hipLaunchKernelGGL(k_batch_step<7>, grid, block, 0, stream, src, gv, descs, active, max_blocks, partials);
   return hipGetLastError();
 }
 

@@ -136,6 +136,9 @@ hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const 
 // host memory polled by the host; slot kEvalStride-1 of each row then receives `seq` (u64) last.
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
                          hipStream_t stream, unsigned long long seq = 0);
+// all live scans of a lock-step batch step in one launch, kinds mixed (descs[scan].kind, .pad = rows written)
+hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
+                             int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);
 hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream, int dense = 1);
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
                              int search, float r2, int n_blocks, double* partials, hipStream_t stream);
