@@ -107,6 +107,14 @@ ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hessian_recomputes, 
 /* calculateScore(cloud), ndt_omp_impl.hpp:935-983 (cloud is used as given). */
 ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride_bytes, double* score);
 
+/* [PCL 1.10] pcl::Registration::getFitnessScore(max_range) (printed by apps/align.cpp:24-33 and
+ * ndt_rosbag_mapping_node.cpp:133): the source transformed by the last align's final transformation,
+ * nearest target point of each (exact search, f32 squared distances as FLANN's L2_Simple), mean of the
+ * squared distances that are <= max_range (PCL compares the SQUARED distance with max_range; kept),
+ * DBL_MAX when none qualifies.  Runs on the GPU over the target's voxel grid; pass DBL_MAX for PCL's
+ * default.  Non-finite source points are skipped. */
+ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness);
+
 /* ---- scan prefilter (row N1 of the scope table) -----------------------------
  * pcl::VoxelGrid<PointT>::filter -- one centroid per occupied voxel, output in ascending
  * voxel-index order -- as every caller runs it before NDT (ndt_omp/apps/align.cpp:60-69,

@@ -22,6 +22,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -135,6 +136,16 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     check(ndt_calculate_score(handle_, cloud.points.data(), cloud.points.size(), sizeof(PointSource), &score),
           "ndt_calculate_score");
     return score;
+  }
+
+  /** pcl::Registration::getFitnessScore(max_range) of the last align, on the GPU (exact nearest
+   *  neighbour over the target's voxel grid).  Hides the base's non-virtual KD-tree version for
+   *  callers that hold the derived type (ndt_rosbag_mapping_node.cpp:133); through a
+   *  pcl::Registration pointer (apps/align.cpp:24-33) PCL's own implementation still answers. */
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double fitness = 0;
+    check(ndt_get_fitness_score(handle_, max_range, &fitness), "ndt_get_fitness_score");
+    return fitness;
   }
 
   /** Access for callers that want the batch / device entry points of the C-ABI. */

@@ -75,5 +75,7 @@ int main(int argc, char** argv) {
   copy.align(*aligned2, copy.getFinalTransformation());
   print("rosbag_node", copy.getFinalTransformation(), copy.hasConverged(), copy.getFinalNumIteration());
   std::printf("trans_probability %.12g\n", copy.getTransformationProbability());
+  // ndt_rosbag_mapping_node.cpp:133 prints the fitness of the derived object
+  std::printf("fitness %.12g\n", copy.getFitnessScore());
   return 0;
 }

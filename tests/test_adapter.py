@@ -70,3 +70,8 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     assert conv == 1 and iters == r3["iterations"]
     assert rot_err(T3, r3["T"]) < 1e-4 and trans_err(T3, r3["T"]) < 1e-3
     assert float(rows["trans_probability"]) == pytest.approx(r3["trans_probability"], rel=1e-5)
+    # getFitnessScore() of the derived type runs on the GPU: mean squared nearest-neighbour distance
+    from scipy.spatial import cKDTree
+    moved = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)].astype(np.float32), T3.astype(np.float32))[:, :3]
+    d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
+    assert float(rows["fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-5)

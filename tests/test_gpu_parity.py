@@ -233,6 +233,58 @@ def test_readme_fitness_on_gpu(mods, pair, golden):
         d, _ = cKDTree(t.astype(np.float64)).query(out[:, :3].astype(np.float64))
         fit = float(np.mean((d.astype(np.float32) ** 2).astype(np.float64)))
         assert fit == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        # ... and computed by the library itself (row N4: getFitnessScore on the GPU)
+        assert g.getFitnessScore() == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        assert g.getFitnessScore() == pytest.approx(fit, rel=1e-6)
+
+
+def brute_force_fitness(target, moved, max_range=np.inf):
+    """[PCL] getFitnessScore with [FLANN] L2_Simple arithmetic: f32 (dx*dx + dy*dy) + dz*dz, exact minimum."""
+    f = np.float32
+    best = np.full(len(moved), np.inf, dtype=f)
+    for a in range(0, len(target), 4096):
+        t = target[a:a + 4096].astype(f)
+        dx = moved[:, None, 0] - t[None, :, 0]
+        dy = moved[:, None, 1] - t[None, :, 1]
+        dz = moved[:, None, 2] - t[None, :, 2]
+        d2 = (dx * dx + dy * dy).astype(f) + (dz * dz).astype(f)
+        best = np.minimum(best, d2.min(axis=1))
+    ok = best.astype(np.float64) <= max_range
+    return float(best[ok].astype(np.float64).sum() / ok.sum()) if ok.any() else np.finfo(np.float64).max
+
+
+def test_fitness_score_exact_nearest_neighbour(mods, pair):
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(31)
+    sub = s[rng.choice(len(s), 3000, replace=False)]
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    # (a) after a registration; (b) far off (2 m), so that many nearest points are several shells away
+    for guess, iters in ((None, 35), (clouds.make_T([2.0, -1.5, 0.8], np.deg2rad([3.0, 2.0, -8.0])).astype(np.float32), 0)):
+        g.setInputSource(sub)
+        g.setMaximumIterations(iters)
+        moved = g.align(guess, n_out=len(sub))[:, :3]
+        ref = brute_force_fitness(t, moved)
+        assert g.getFitnessScore() == pytest.approx(ref, rel=1e-12)
+        # max_range is compared with the SQUARED distance (PCL's rule)
+        ref_r = brute_force_fitness(t, moved, max_range=0.05)
+        assert ref_r < ref
+        assert g.getFitnessScore(0.05) == pytest.approx(ref_r, rel=1e-12)
+    assert g.getFitnessScore(0.0) == np.finfo(np.float64).max  # nothing within range
+    # source far outside the target's bounding box and a sparse target: the exhaustive fallback
+    g2 = ndt.NormalDistributionsTransform()
+    sparse = (rng.uniform(-40, 40, (400, 3)) * [1, 1, 0.1]).astype(np.float32)
+    g2.setInputTarget(sparse)
+    far = (rng.uniform(-5, 5, (300, 3)) + [150.0, -90.0, 30.0]).astype(np.float32)
+    g2.setInputSource(far)
+    g2.setMaximumIterations(0)
+    moved = g2.align(n_out=len(far))[:, :3]
+    assert g2.getFitnessScore() == pytest.approx(brute_force_fitness(sparse, moved), rel=1e-12)
+    inside = rng.uniform(-40, 40, (500, 3)).astype(np.float32)
+    g2.setInputSource(inside)
+    moved = g2.align(n_out=len(inside))[:, :3]
+    assert g2.getFitnessScore() == pytest.approx(brute_force_fitness(sparse, moved), rel=1e-12)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "surfaces"])

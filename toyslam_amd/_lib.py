@@ -69,6 +69,7 @@ SIGNATURES = {
     "ndt_calculate_score": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, dp]),
     "ndt_voxel_grid_filter": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, C.c_size_t, szp]),
     "ndt_voxel_grid_filter_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, szp]),
+    "ndt_get_fitness_score": (C.c_int, [vp, C.c_double, dp]),
     "ndt_map_clear": (C.c_int, [vp]),
     "ndt_map_update": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, fp, C.c_float, ip]),
     "ndt_map_update_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, fp, C.c_float, ip]),

@@ -164,6 +164,11 @@ struct DeviceGrid {
   DevBuf<ndt::VoxelRec> recs;
   DevBuf<int> leaf_cell, leaf_count, leaf_rec, sorted_idx;
   DevBuf<unsigned> leaf_start;
+  size_t n_sorted = 0;  // target points that landed in a voxel (finite ones)
+  // getFitnessScore's nearest-neighbour search: cell -> leaf ordinal (or -1), built on first use
+  std::mutex fit_mu;
+  DevBuf<int> cell2leaf;
+  bool have_cell2leaf = false;
   ndt::GridView view() const {
     ndt::GridView v;
     v.lut = lut.p;
@@ -567,6 +572,7 @@ ndt_status build_grid(ndt_context* h) {
   unsigned tot[3];
   HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  g->n_sorted = tot[0];
   g->n_leaves = tot[1];
   g->n_cand = tot[2];
   HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.n_cells)));
@@ -1173,6 +1179,45 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
   HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   *score = h->host_result[0] / static_cast<double>(n);
+  return NDT_OK;
+}
+
+// ---- N4: getFitnessScore ------------------------------------------------------
+ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness) {
+  if (!h || !fitness) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  *fitness = std::numeric_limits<double>::max();  // nr == 0 in the reference
+  DeviceGrid* g = h->grid.get();
+  const int n = static_cast<int>(h->source->n);
+  if (n == 0 || g->empty || g->n_sorted == 0) return NDT_OK;
+  {
+    std::lock_guard<std::mutex> lock(g->fit_mu);
+    if (!g->have_cell2leaf) {
+      HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
+      HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
+      HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      g->have_cell2leaf = true;
+    }
+  }
+  s = ensure_host_rows(h, 1);
+  if (s) return s;
+  float T12[12];
+  colmajor_to_T12(h->final_T, T12);
+  // slack of the shell bound: the build-time and search-time cell indices of a coordinate can differ
+  // at cell borders by rounding (SURVEY 8a trap 2) -- a few ulps of the largest coordinate
+  float max_abs = 0.f;
+  for (int k = 0; k < 3; k++)
+    max_abs = std::max(max_abs, std::max(std::fabs(g->geom.min_b[k] * g->geom.leaf[k]), std::fabs((g->geom.max_b[k] + 1) * g->geom.leaf[k])));
+  const float slack = 1e-3f * h->resolution + 4e-6f * max_abs;
+  const int nblk = std::max(1, std::min(2048, (n + 255) / 256));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(ndt::launch_fitness(h->source->pts.p, n, T12, g->geom, g->cell2leaf.p, g->leaf_start.p, g->leaf_count.p, g->sorted_idx.p,
+                              static_cast<int>(g->n_sorted), g->target->pts.p, max_range, slack, nblk, h->partials.p, h->stream));
+  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->host_result[1] > 0) *fitness = h->host_result[0] / h->host_result[1];
   return NDT_OK;
 }
 

@@ -740,6 +740,95 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// N4: [PCL 1.10] Registration::getFitnessScore -- mean squared distance from every transformed source
+// point to its nearest target point.  Exact nearest neighbour over the target's own voxel grid (K1's
+// counting sort already groups the target points by cell): scan the query's cell, then cubic shells
+// of cells around it, and stop once the best distance cannot be beaten by any unvisited shell.
+// Distances as [FLANN] L2_Simple computes them: f32, (dx*dx + dy*dy) + dz*dz, no contraction.
+// acc[0] = sum of the accepted squared distances (f64), acc[1] = their count.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cell_to_leaf(const int* __restrict__ leaf_cell, int n_leaves, int* __restrict__ cell2leaf) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += gridDim.x * kBlock) cell2leaf[leaf_cell[i]] = i;
+}
+
+__device__ __forceinline__ float dist2_f32(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+constexpr int kFitMaxRing = 6;  // beyond this many shells the query falls back to a scan of all target points
+
+__global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ src, int n, EvalParams P, GridGeom g,
+                                                    const int* __restrict__ cell2leaf, const unsigned* __restrict__ leaf_start,
+                                                    const int* __restrict__ leaf_count, const int* __restrict__ sorted_idx,
+                                                    int n_sorted, const float4* __restrict__ tgt, double max_range, float slack,
+                                                    double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / kWave) * 32];
+  double acc[kNumAcc];
+#pragma unroll
+  for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+  const float leaf = fminf(g.leaf[0], fminf(g.leaf[1], g.leaf[2]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 pt = src[i];
+    if (!finite3(pt.x, pt.y, pt.z)) continue;  // transformPointCloud leaves it non-finite; no neighbour to report
+    float tx, ty, tz;
+    xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    if (!finite3(tx, ty, tz)) continue;
+    int ci, cj, ck;
+    search_ijk(g, tx, ty, tz, ci, cj, ck);
+    // nearest grid cell when the point is outside the bounding box
+    ci = max(g.min_b[0], min(g.max_b[0], ci)) - g.min_b[0];
+    cj = max(g.min_b[1], min(g.max_b[1], cj)) - g.min_b[1];
+    ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
+    float best = INFINITY;
+    bool done = false;
+    auto scan_leaf = [&](int lf) {
+      const unsigned s0 = leaf_start[lf];
+      const int cnt = leaf_count[lf];
+      for (int q = 0; q < cnt; q++) {
+        const float4 t = tgt[sorted_idx[s0 + q]];
+        best = fminf(best, dist2_f32(tx, ty, tz, t.x, t.y, t.z));
+      }
+    };
+    const int r_lim = max(g.div_b[0], max(g.div_b[1], g.div_b[2]));
+    for (int r = 0; r <= kFitMaxRing && !done; r++) {
+      for (int dz = -r; dz <= r; dz++) {
+        const int z = ck + dz;
+        if (z < 0 || z >= g.div_b[2]) continue;
+        for (int dy = -r; dy <= r; dy++) {
+          const int y = cj + dy;
+          if (y < 0 || y >= g.div_b[1]) continue;
+          const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+          const int step = face ? 1 : max(2 * r, 1);  // interior rows of the shell: only dx = -r and dx = +r
+          for (int dx = -r; dx <= r; dx += step) {
+            const int x = ci + dx;
+            if (x < 0 || x >= g.div_b[0]) continue;
+            const int lf = cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+            if (lf >= 0) scan_leaf(lf);
+          }
+        }
+      }
+      // every unvisited cell is at least r cells away (less the slack for the build-time / search-time
+      // index rounding, trap 2)
+      const float reach = static_cast<float>(r) * leaf - slack;
+      if ((reach > 0.0f && best <= reach * reach) || r >= r_lim) done = true;
+    }
+    if (!done) {  // sparse neighbourhood: exhaustive scan
+      for (int q = 0; q < n_sorted; q++) {
+        const float4 t = tgt[sorted_idx[q]];
+        best = fminf(best, dist2_f32(tx, ty, tz, t.x, t.y, t.z));
+      }
+    }
+    if (static_cast<double>(best) <= max_range) {  // the squared distance against max_range, as PCL does
+      acc[0] += static_cast<double>(best);
+      acc[1] += 1.0;
+    }
+  }
+  block_reduce_store<kNumAcc>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
+}
+
 // calculateScore (ndt_omp_impl.hpp:935-983): cloud used as given, f64 throughout
 template <int NNB>
 __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict__ cloud, int n, GridView gv, double d1,
@@ -988,6 +1077,21 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
     hipLaunchKernelGGL(k_calc_score<1>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
   else
     hipLaunchKernelGGL(k_calc_score<7>, dim3(n_blocks), dim3(kBlock), 0, stream, cloud, n, gv, d1, d2, d3, r2, partials);
+  return hipGetLastError();
+}
+
+hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, hipStream_t stream) {
+  hipLaunchKernelGGL(k_cell_to_leaf, dim3(grid_for(n_leaves, 1024)), dim3(kBlock), 0, stream, leaf_cell, n_leaves, cell2leaf);
+  return hipGetLastError();
+}
+
+hipError_t launch_fitness(const float4* src, int n, const float* T12, const GridGeom& g, const int* cell2leaf,
+                          const unsigned* leaf_start, const int* leaf_count, const int* sorted_idx, int n_sorted,
+                          const float4* tgt, double max_range, float slack, int n_blocks, double* partials, hipStream_t stream) {
+  EvalParams P = {};
+  for (int i = 0; i < 12; i++) P.T[i] = T12[i];
+  hipLaunchKernelGGL(k_fitness, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, P, g, cell2leaf, leaf_start, leaf_count, sorted_idx,
+                     n_sorted, tgt, max_range, slack, partials);
   return hipGetLastError();
 }
 

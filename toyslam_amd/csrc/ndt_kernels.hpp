@@ -139,6 +139,10 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
 // all live scans of a lock-step batch step in one launch, kinds mixed (descs[scan].kind, .pad = rows written)
 hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
                              int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);
+hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, hipStream_t stream);
+hipError_t launch_fitness(const float4* src, int n, const float* T12, const GridGeom& g, const int* cell2leaf,
+                          const unsigned* leaf_start, const int* leaf_count, const int* sorted_idx, int n_sorted,
+                          const float4* tgt, double max_range, float slack, int n_blocks, double* partials, hipStream_t stream);
 hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream, int dense = 1);
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
                              int search, float r2, int n_blocks, double* partials, hipStream_t stream);

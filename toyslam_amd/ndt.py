@@ -183,6 +183,12 @@ class NormalDistributionsTransform:
                                                    float(leaf_size), C.c_void_p(out_dev_ptr), C.byref(m)))
         return m.value
 
+    def getFitnessScore(self, max_range=np.finfo(np.float64).max):
+        """pcl::Registration::getFitnessScore of the last align (exact NN search on the GPU)."""
+        v = C.c_double(0)
+        check(self._L.ndt_get_fitness_score(self._h, float(max_range), C.byref(v)))
+        return v.value
+
     # ---- global map (N2) ------------------------------------------------------------
     def mapClear(self):
         check(self._L.ndt_map_clear(self._h))
