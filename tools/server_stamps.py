@@ -1,5 +1,6 @@
+"""Per-block phase stamps of one evaluation-server round (development aid): writes gpurun_out/stamps.bin and prints the distribution."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from toyslam_amd import clouds, ndt
 tgt = clouds.target_uniform(1000000); src = clouds.source_from_target(tgt, 100000)

@@ -1,5 +1,6 @@
+"""Median wall time of ndt_align on the headline workload (development aid; NDT_TIMING=1 adds the library's own breakdown)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from toyslam_amd import clouds, ndt
 tgt = clouds.target_uniform(1000000); src = clouds.source_from_target(tgt, 100000)
