@@ -203,6 +203,13 @@ class NormalDistributionsTransform:
                                      _f(T) if T is not None else None, float(leaf_size), C.byref(ov)))
         return self.mapSize(), bool(ov.value)
 
+    def mapUpdateDevice(self, dev_ptr, n, stride_bytes, pose=None, leaf_size=0.5, is_dense=True):
+        T = None if pose is None else _colmajor(pose)
+        ov = C.c_int(0)
+        check(self._L.ndt_map_update_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense),
+                                            _f(T) if T is not None else None, float(leaf_size), C.byref(ov)))
+        return self.mapSize(), bool(ov.value)
+
     def mapSize(self):
         n = C.c_size_t(0)
         check(self._L.ndt_map_size(self._h, C.byref(n)))
