@@ -591,3 +591,33 @@ def test_map_accumulation_matches_reference_loop(mods, pair):
     far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
     n_map, ov = g.mapUpdate(far, None, 0.01)
     assert ov and n_map == 2 and np.array_equal(g.mapGet(), far)
+
+
+# ------------------------------------------------------------------ configs[4] shape: voxel pyramid
+def test_multiresolution_pyramid_matches_oracle(mods):
+    """Coarse-to-fine NDT (2.0 -> 1.0 -> 0.5 m), each level's result the next level's guess
+    (BASELINE configs[4] at test size): level by level the GPU follows the oracle."""
+    ndt, po, clouds = mods
+    tgt = clouds.target_surfaces(400000, extent=80.0, n_boxes=40)
+    T_gt = clouds.make_T([0.9, -0.6, 0.15], np.deg2rad([1.0, -0.8, 4.0]))
+    src = clouds.source_from_target(tgt, 40000, T_gt=T_gt)
+    g = ndt.NormalDistributionsTransform()
+    o = po.OracleNDT(num_threads=8)
+    g.setTransformationEpsilon(1e-3)
+    g.setMaximumIterations(40)
+    o.set(trans_eps=1e-3, max_iter=40)
+    g.setInputSource(src)
+    o.set_source(src)
+    guess_g = guess_o = None
+    for res in (2.0, 1.0, 0.5):
+        g.setResolution(res)
+        o.set(resolution=res)
+        g.setInputTarget(tgt)
+        o.set_target(tgt)
+        g.align(guess_g)
+        r = o.align(guess_o)
+        T = g.getFinalTransformation()
+        assert rot_err(T, r["T"]) < ROT_TOL and trans_err(T, r["T"]) < TRANS_TOL, "level %.1f m" % res
+        assert g.getFinalNumIteration() == r["iterations"]
+        guess_g, guess_o = T, r["T"]
+    assert rot_err(T, T_gt) < 2e-3 and trans_err(T, T_gt) < 3e-2
