@@ -88,9 +88,11 @@ ndt_status ndt_set_input_source_device(ndt_handle h, const void* d_pts, size_t n
 /* ---- registration --------------------------------------------------------
  * pcl::Registration::align(output, guess) -> computeTransformation
  * (ndt_omp_impl.hpp:80-171) with the More-Thuente line search (:772-932).
- * guess == NULL means Identity.  out_cloud (optional) receives the source
+ * guess == NULL means Identity.  out_cloud (optional, host memory) receives the source
  * transformed by the last line-search trial, n_source records of
- * out_stride_bytes (x,y,z,1.0f written at offset 0). */
+ * out_stride_bytes (x,y,z,1.0f written at offset 0).  With out_cloud == NULL the call
+ * returns as soon as the result is known; the aligned cloud is then completed in stream
+ * order and ndt_get_output_device waits for it. */
 ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformation, int* has_converged,
                      int* final_num_iteration, double* transformation_probability, void* out_cloud,
                      size_t out_stride_bytes);

@@ -1,5 +1,6 @@
-// ndt_kernels.hip -- hand-written HIP kernels of the MI355X NDT core (gfx950,
-// wave64).  Two kernel families:
+// ndt_kernels.hip -- hand-written HIP kernels of the MI355X NDT core (gfx950, wave64): the grid build
+// and the throughput side of the evaluation.  (The single-scan latency path -- one-launch evaluation and
+// the persistent evaluation server -- lives in ndt_latency.hip; both units share ndt_device.hpp.)
 //
 //  K1  target voxel grid  (VoxelGridCovariance::applyFilter,
 //      voxel_grid_covariance_omp_impl.hpp:48-370):
@@ -11,16 +12,20 @@
 //                the reference's sequential accumulation), mean, covariance
 //                with the reference's quirks, 3x3 symmetric eigen-solve,
 //                eigenvalue inflation, inverse, validity -> 64-B VoxelRec.
+//      The same count / scan / scatter machinery serves the scan prefilter (N1, k_voxel_centroids),
+//      the global-map update (N2) and the spatial ordering of source scans (k_sort_gather).
 //  K2  per-evaluation score / gradient / Hessian (computeDerivatives,
 //      ndt_omp_impl.hpp:179-285 with updateDerivatives :484-537 fused with the
-//      f32 point transform), plus the all-f64 Hessian (computeHessian
-//      :540-645) and calculateScore (:935-983).
+//      f32 point transform): k_derivatives (one launch per evaluation, also over
+//      a whole lock-step batch), k_batch_step (mixed-kind batch steps), the all-f64
+//      Hessian k_hessian64 (computeHessian :540-645), k_reduce (fixed-order sum of
+//      the per-block rows), calculateScore (:935-983), getFitnessScore (k_fitness).
 //
-// HBM-bound gather work: no MFMA (there is no dense contraction).  Loads are
-// 16-B per lane (float4 points, 3 x dwordx4 per 64-B voxel record), the LUT
-// probe + record gather is served from L2 / Infinity Cache for the target
-// sizes of interest, and the 29 f64 accumulators are reduced with wave64
-// shuffles, then LDS across the 4 waves, then a fixed-order second kernel.
+// Gather work: no MFMA (there is no dense contraction).  Loads are 16 B per lane
+// (float4 points, 3 x dwordx4 per 64-B voxel record), the LUT probe + record gather
+// is served from L2 / Infinity Cache for the target sizes of interest, and the 29 f64
+// accumulators are reduced with a VALU-only wave64 fold, then LDS across the waves of
+// a block, then a fixed-order sum over the blocks.
 #include "ndt_device.hpp"
 
 namespace ndt {
