@@ -18,6 +18,7 @@
 #include <mutex>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "ndt_driver.hpp"
@@ -43,9 +44,13 @@ ndt_status fail(ndt_status s, const std::string& msg) {
 
 // Caching device allocator: setInputTarget / setInputSource run once per scan in the nodes, and a
 // dozen hipMalloc/hipFree pairs per call (~100 us each) would dominate the GPU time of the grid
-// build.  Freed blocks go to a per-device free list keyed by a rounded size class and are reused;
-// the cache is trimmed when it exceeds kPoolTrimBytes.  All users synchronise their stream before
-// releasing a buffer.
+// build.  Freed blocks go to a free list keyed by (device, STREAM, rounded size class) and are reused
+// only by work queued on the same stream: a block may be released while the kernels that use it are
+// still in flight (the grid build does not wait for the GPU), and stream order is what makes the
+// next user safe.  The calling thread's current stream is set by every API entry (ensure_device).
+// The cache is trimmed (hipFree, which synchronises) when it exceeds kPoolTrimBytes.
+thread_local hipStream_t tls_pool_stream = nullptr;
+
 class DevPool {
  public:
   static DevPool& instance() {
@@ -59,13 +64,14 @@ class DevPool {
     const size_t step = p2 / 8;
     return (bytes + step - 1) / step * step;
   }
+  using Key = std::tuple<int, hipStream_t, size_t>;
   hipError_t alloc(size_t bytes, void** out, size_t* got) {
     const size_t cls = size_class(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
     {
       std::lock_guard<std::mutex> g(m_);
-      auto it = free_.find(std::make_pair(dev, cls));
+      auto it = free_.find(Key(dev, tls_pool_stream, cls));
       if (it != free_.end()) {
         *out = it->second;
         *got = cls;
@@ -88,16 +94,29 @@ class DevPool {
     (void)hipGetDevice(&dev);
     {
       std::lock_guard<std::mutex> g(m_);
-      free_.insert(std::make_pair(std::make_pair(dev, cls), p));
+      free_.insert(std::make_pair(Key(dev, tls_pool_stream, cls), p));
       cached_ += cls;
     }
     if (cached_ > kPoolTrimBytes) trim(kPoolTrimBytes / 2);
+  }
+  // blocks cached for a stream that is about to be destroyed: give them back
+  void forget_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> g(m_);
+    for (auto it = free_.begin(); it != free_.end();) {
+      if (std::get<1>(it->first) == st) {
+        (void)hipFree(it->second);
+        cached_ -= std::get<2>(it->first);
+        it = free_.erase(it);
+      } else {
+        ++it;
+      }
+    }
   }
   void trim(size_t keep) {
     std::lock_guard<std::mutex> g(m_);
     for (auto it = free_.begin(); it != free_.end() && cached_ > keep;) {
       (void)hipFree(it->second);
-      cached_ -= it->first.second;
+      cached_ -= std::get<2>(it->first);
       it = free_.erase(it);
     }
   }
@@ -105,7 +124,7 @@ class DevPool {
  private:
   static constexpr size_t kPoolTrimBytes = size_t(16) << 30;
   std::mutex m_;
-  std::multimap<std::pair<int, size_t>, void*> free_;
+  std::multimap<Key, void*> free_;
   size_t cached_ = 0;
 };
 
@@ -165,6 +184,8 @@ struct DeviceGrid {
   DevBuf<int> leaf_cell, leaf_count, leaf_rec, sorted_idx;
   DevBuf<unsigned> leaf_start;
   size_t n_sorted = 0;  // target points that landed in a voxel (finite ones)
+  DevBuf<unsigned> counts;      // device copy of {n_sorted, n_leaves, n_cand, n_valid}
+  bool counts_known = true;     // host copies above are current (grid_counts() fetches them lazily)
   // getFitnessScore's nearest-neighbour search: cell -> leaf ordinal (or -1), built on first use
   std::mutex fit_mu;
   DevBuf<int> cell2leaf;
@@ -245,15 +266,42 @@ struct ndt_context {
   int allreduce_on_device = 0;
 
   ~ndt_context() {
+    if (stream) {  // nothing of this handle may still be running when its buffers go back to the pool
+      (void)hipSetDevice(device);
+      (void)hipStreamSynchronize(stream);
+      tls_pool_stream = stream;
+    }
+    release_buffers();
     if (host_result) (void)hipHostFree(host_result);
     if (host_pub) (void)hipHostFree(host_pub);
     if (server_host_mbs) (void)hipHostFree(server_host_mbs);
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) {
+      DevPool::instance().forget_stream(stream);
+      (void)hipStreamDestroy(stream);
+    }
+    tls_pool_stream = nullptr;
   }
+  void release_buffers();
 };
+
+void ndt_context::release_buffers() {
+  target.reset();
+  source.reset();
+  grid.reset();
+  partials.release();
+  ticket.release();
+  batch_out.release();
+  descs.release();
+  out_cloud.release();
+  staging.release();
+  map_pts.release();
+  server_dev_mb.release();
+  server_counter.release();
+  server_dbg.release();
+}
 
 namespace {
 
@@ -266,6 +314,7 @@ int usable_devices() {
 ndt_status ensure_device(ndt_context* h) {
   if (h->device_ready) {
     HIP_TRY(hipSetDevice(h->device));
+    tls_pool_stream = h->stream;
     return NDT_OK;
   }
   const int n = usable_devices();
@@ -279,6 +328,7 @@ ndt_status ensure_device(ndt_context* h) {
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->cu_count = prop.multiProcessorCount;
   h->device_ready = true;
+  tls_pool_stream = h->stream;
   return NDT_OK;
 }
 
@@ -374,10 +424,9 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   HIP_TRY(totals.reserve(4));
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
   HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
-  unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  const size_t n_leaves = tot[1];
+  // the leaf count stays on the device (the kernels read it there): leaf arrays are sized for the
+  // worst case and the host learns the totals once, at the end, instead of in the middle
+  const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));
   HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
@@ -387,7 +436,9 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-  HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
+  HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   *n_out = tot[0];
   return NDT_OK;
@@ -455,9 +506,8 @@ ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, st));
   HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
   unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  const size_t n_leaves = tot[1];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));  // read after the final synchronise
+  const size_t n_leaves = std::min<size_t>(c->n, static_cast<size_t>(scan_cells));  // upper bound; the count stays on the device
   HIP_TRY(lut.reserve(static_cast<size_t>(scan_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
@@ -471,7 +521,7 @@ ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   HIP_TRY(hipMemcpy2DAsync(starts.data(), sizeof(unsigned), cell_count.p, static_cast<size_t>(geo.n_cells) * sizeof(unsigned),
                            sizeof(unsigned), n_scans + 1, hipMemcpyDeviceToHost, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-  HIP_TRY(ndt::launch_sort_gather(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p, st));
+  HIP_TRY(ndt::launch_sort_gather(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p, st, totals.p));
   HIP_TRY(hipStreamSynchronize(st));
   for (size_t k = 0; k < n_scans; k++) {
     c->scan_starts[k] = starts[k];
@@ -566,37 +616,49 @@ ndt_status build_grid(ndt_context* h) {
   // ---- scan
   const int n_tiles = ndt::scan_tiles(geo.n_cells);
   HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
-  HIP_TRY(totals.reserve(4));
+  HIP_TRY(g->counts.reserve(4));  // [points binned, occupied voxels, candidate voxels (>= min_pts), valid voxels]
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, st));
-  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
-  unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  g->n_sorted = tot[0];
-  g->n_leaves = tot[1];
-  g->n_cand = tot[2];
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, g->counts.p, st));
+  // The counts stay on the device: the later kernels read the voxel count there, the arrays are sized
+  // for the worst case, and the host fetches the four numbers only if somebody asks (grid_counts()).
+  // Two host round trips (~30 us each) less per target; nothing below waits for the GPU.
+  const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
+  const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
   HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.n_cells)));
-  HIP_TRY(g->leaf_cell.reserve(g->n_leaves));
-  HIP_TRY(g->leaf_start.reserve(g->n_leaves));
-  HIP_TRY(g->leaf_count.reserve(g->n_leaves));
-  HIP_TRY(g->leaf_rec.reserve(g->n_leaves));
+  HIP_TRY(g->leaf_cell.reserve(max_leaves));
+  HIP_TRY(g->leaf_start.reserve(max_leaves));
+  HIP_TRY(g->leaf_count.reserve(max_leaves));
+  HIP_TRY(g->leaf_rec.reserve(max_leaves));
   HIP_TRY(g->sorted_idx.reserve(n));
-  HIP_TRY(g->recs.reserve(g->n_cand));
+  HIP_TRY(g->recs.reserve(max_cand));
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->lut.p, g->leaf_cell.p,
                                  g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
   // ---- scatter + finalize
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
-  HIP_TRY(hipMemsetAsync(totals.p, 0, sizeof(unsigned), st));
+  HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, sizeof(unsigned), st));
   ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
-                               static_cast<int>(g->n_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
-                               g->lut.p, totals.p, nodump, st));
-  unsigned nv = 0;
-  HIP_TRY(hipMemcpyAsync(&nv, totals.p, sizeof(nv), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  g->n_valid = nv;
+                               static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
+                               g->lut.p, g->counts.p + 3, nodump, st, g->counts.p));
+  // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
+  // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
+  g->counts_known = false;
   g->empty = false;
   h->grid = g;
+  return NDT_OK;
+}
+
+// occupied / candidate / valid voxel counts of a built grid (fetched from the device on first use)
+ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
+  if (g->counts_known || g->empty) return NDT_OK;
+  unsigned c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(c, g->counts.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  g->n_sorted = c[0];
+  g->n_leaves = c[1];
+  g->n_cand = c[2];
+  g->n_valid = c[3];
+  g->counts_known = true;
   return NDT_OK;
 }
 
@@ -949,6 +1011,10 @@ ndt_status ndt_create(int device, ndt_handle* out) {
 
 ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
   if (!src || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (src->device_ready) {  // the shared grid / clouds may still be under construction on the source's stream
+    HIP_TRY(hipSetDevice(src->device));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+  }
   ndt_context* h = new ndt_context();
   h->device = src->device;
   h->resolution = src->resolution;
@@ -1190,6 +1256,8 @@ ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness
   *fitness = std::numeric_limits<double>::max();  // nr == 0 in the reference
   DeviceGrid* g = h->grid.get();
   const int n = static_cast<int>(h->source->n);
+  s = grid_counts(h, g);
+  if (s) return s;
   if (n == 0 || g->empty || g->n_sorted == 0) return NDT_OK;
   {
     std::lock_guard<std::mutex> lock(g->fit_mu);
@@ -1282,10 +1350,7 @@ static ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n
   HIP_TRY(totals.reserve(4));
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
   HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
-  unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  const size_t n_leaves = tot[1];
+  const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));  // upper bound; the count stays on the device
   HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
@@ -1295,9 +1360,11 @@ static ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st));
+  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
-  *n_out = n_leaves;
+  *n_out = tot[1];
   return NDT_OK;
 }
 
@@ -1662,6 +1729,11 @@ ndt_status ndt_eval_hessian_f64(ndt_handle h, const double* p, double* H) {
 
 ndt_status ndt_grid_size(ndt_handle h, size_t* n_leaves, size_t* n_valid) {
   if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  if (!h->grid->empty) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = grid_counts(h, h->grid.get());
+    if (s) return s;
+  }
   if (n_leaves) *n_leaves = h->grid->n_leaves;
   if (n_valid) *n_valid = h->grid->n_valid;
   return NDT_OK;
@@ -1683,6 +1755,11 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
                          double* evals) {
   if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
   DeviceGrid* g = h->grid.get();
+  if (!g->empty) {
+    ndt_status sc = ensure_device(h);
+    if (!sc) sc = grid_counts(h, g);
+    if (sc) return sc;
+  }
   const size_t V = g->n_leaves;
   if (V == 0) return NDT_OK;
   ndt_status s = ensure_device(h);

@@ -380,9 +380,10 @@ __device__ __forceinline__ void sort_segment(int* seg, int cnt) {
 // hence deterministic) and gather the points, so that consecutive lanes of K2 touch the same or
 // adjacent target voxels (coalesced LUT probes and record gathers).
 __global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                        const int* __restrict__ leaf_count, int n_leaves,
+                                                        const int* __restrict__ leaf_count, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                         int* __restrict__ sorted_idx, float4* __restrict__ out) {
   const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
   if (o >= n_leaves) return;
   const unsigned start = leaf_start[o];
   const int cnt = leaf_count[o];
@@ -399,9 +400,10 @@ __global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict
 // are enumerated in cell order, so the output is in ascending voxel-index order like PCL's.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_voxel_centroids(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                            const int* __restrict__ leaf_count, int n_leaves,
+                                                            const int* __restrict__ leaf_count, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                             int* __restrict__ sorted_idx, float4* __restrict__ out) {
   const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
   if (o >= n_leaves) return;
   const unsigned start = leaf_start[o];
   const int cnt = leaf_count[o];
@@ -427,11 +429,12 @@ __global__ __launch_bounds__(kBlock) void k_voxel_centroids(const float4* __rest
 __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ pts, const int* __restrict__ leaf_cell,
                                                      const unsigned* __restrict__ leaf_start,
                                                      const int* __restrict__ leaf_count,
-                                                     const int* __restrict__ leaf_rec, int n_leaves,
+                                                     const int* __restrict__ leaf_rec, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
                                                      VoxelRec* __restrict__ recs, int* __restrict__ lut,
                                                      unsigned* __restrict__ n_valid, FinalizeDump dump) {
   const int o = blockIdx.x * kBlock + threadIdx.x;
+  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
   if (o >= n_leaves) return;
   const unsigned start = leaf_start[o];
   const int cnt = leaf_count[o];
@@ -947,10 +950,11 @@ hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
                            int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
-                           FinalizeDump dump, hipStream_t stream) {
+                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals) {
+  // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
   if (n_leaves == 0) return hipSuccess;
   hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
-                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
+                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
                      d_n_valid, dump);
   return hipGetLastError();
 }
@@ -961,10 +965,10 @@ hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream)
 }
 
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                              int* sorted_idx, float4* out, hipStream_t stream) {
+                              int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
   if (n_leaves == 0) return hipSuccess;
   hipLaunchKernelGGL(k_sort_gather, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
-                     leaf_count, n_leaves, sorted_idx, out);
+                     leaf_count, n_leaves, d_totals, sorted_idx, out);
   return hipGetLastError();
 }
 
@@ -975,10 +979,10 @@ hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& 
 }
 
 hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                                  int* sorted_idx, float4* out, hipStream_t stream) {
+                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
   if (n_leaves == 0) return hipSuccess;
   hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
-                     leaf_count, n_leaves, sorted_idx, out);
+                     leaf_count, n_leaves, d_totals, sorted_idx, out);
   return hipGetLastError();
 }
 
