@@ -621,3 +621,30 @@ def test_multiresolution_pyramid_matches_oracle(mods):
         assert g.getFinalNumIteration() == r["iterations"]
         guess_g, guess_o = T, r["T"]
     assert rot_err(T, T_gt) < 2e-3 and trans_err(T, T_gt) < 3e-2
+
+
+def test_server_with_several_points_per_thread(mods):
+    """Above 131 072 source points the evaluation server's threads walk more than one point each
+    (its grid is capped at one block per CU); the launch path covers the same scan with a different
+    partition.  Same registration either way, and the oracle's."""
+    ndt, po, clouds = mods
+    tgt = clouds.target_surfaces(600000, extent=70.0, n_boxes=40)
+    src = clouds.source_from_target(tgt, 300000)
+    res = {}
+    for persistent in (True, False):
+        g = ndt.NormalDistributionsTransform()
+        g.setTransformationEpsilon(1e-4)
+        g.setEvaluationPath(persistent)
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+        g.align()
+        res[persistent] = (g.getFinalTransformation().copy(), g.getFinalNumIteration(), g.stats()["mean_neighbors"])
+    a, b = res[True], res[False]
+    assert a[1] == b[1] and a[2] == b[2]
+    assert rot_err(a[0], b[0]) < 1e-6 and trans_err(a[0], b[0]) < 1e-5  # partitions differ: sums agree to rounding
+    o = po.OracleNDT(num_threads=8, trans_eps=1e-4)
+    o.set_target(tgt)
+    o.set_source(src)
+    r = o.align()
+    assert a[1] == r["iterations"]
+    assert rot_err(a[0], r["T"]) < ROT_TOL and trans_err(a[0], r["T"]) < TRANS_TOL
