@@ -444,9 +444,9 @@ int VoxelGrid::neighbors(const Pt& p, SearchMethod m, const Leaf** out, float ra
           if (!inside) continue;
           size_t key = 0;
           for (int k = 0; k < 3; k++) key += static_cast<size_t>(q[k] - min_b[k]) * divb_mul[k];
-          auto it = leaves.find(key);
-          if (it == leaves.end() || !it->second.in_centroids) continue;
-          const Leaf& lf = it->second;
+          const Leaf* lp = find_leaf(key);
+          if (!lp || !lp->in_centroids) continue;
+          const Leaf& lf = *lp;
           const float dx = p.x - lf.centroid[0], dy = p.y - lf.centroid[1], dz = p.z - lf.centroid[2];
           float d = 0.0f;
           d += dx * dx;
@@ -495,8 +495,8 @@ int VoxelGrid::neighbors(const Pt& p, SearchMethod m, const Leaf** out, float ra
     if (!inside) continue;
     int key = 0;
     for (int k = 0; k < 3; k++) key += (ijk[k] + rel[ni][k] - min_b[k]) * divb_mul[k];
-    auto it = leaves.find(static_cast<size_t>(key));
-    if (it != leaves.end() && it->second.nr_points >= min_points_per_voxel) out[n++] = &it->second;
+    const Leaf* lp = find_leaf(static_cast<size_t>(key));
+    if (lp && lp->nr_points >= min_points_per_voxel) out[n++] = lp;
   }
   return n;
 }
@@ -505,11 +505,23 @@ int VoxelGrid::neighbors(const Pt& p, SearchMethod m, const Leaf** out, float ra
 // NDT  (ndt_omp.h, ndt_omp_impl.hpp)
 // ===========================================================================
 
+void VoxelGrid::build_dense() {
+  dense.clear();
+  if (leaves.empty() || overflow) return;
+  const size_t n_cells = static_cast<size_t>(div_b[0]) * div_b[1] * div_b[2];
+  if (n_cells > (size_t(1) << 28)) return;  // keep the map for absurdly sparse grids
+  dense.assign(n_cells, nullptr);
+  for (const auto& kv : leaves)
+    if (kv.first < n_cells) dense[kv.first] = &kv.second;
+}
+
 void NDT::set_target(const std::vector<Pt>& t, bool is_dense) {
   target = t;
   target_dense = is_dense;
   grid.set_leaf_size(resolution);  // init(), ndt_omp.h:276-283
   grid.build(target, target_dense);
+  grid.dense.clear();
+  if (optimised) grid.build_dense();
 }
 
 void NDT::set_resolution(float r) {  // ndt_omp.h:132-142 (tests input_, the SOURCE)
@@ -518,6 +530,8 @@ void NDT::set_resolution(float r) {  // ndt_omp.h:132-142 (tests input_, the SOU
     if (!source.empty()) {
       grid.set_leaf_size(resolution);
       grid.build(target, target_dense);
+      grid.dense.clear();
+      if (optimised) grid.build_dense();
     }
   }
 }
@@ -680,6 +694,43 @@ double NDT::compute_derivatives(double g[6], double H[36], const std::vector<Pt>
   for (int i = 0; i < 36; i++) H[i] = 0;
   double score = 0;
 
+  if (optimised) {  // "optimised CPU" baseline: same arithmetic per neighbour, no per-point result arrays
+    compute_angle_derivatives(p);
+    long long nn_total = 0;
+    const int nthreads = std::max(1, num_threads);
+#pragma omp parallel num_threads(nthreads)
+    {
+      double s_loc = 0, g_loc[6] = {0, 0, 0, 0, 0, 0}, H_loc[36];
+      long long nn_loc = 0;
+      for (int k = 0; k < 36; k++) H_loc[k] = 0;
+#pragma omp for schedule(static)
+      for (size_t idx = 0; idx < N; idx++) {
+        const Pt x_trans_pt = trans_cloud[idx];
+        const Leaf* nb[27];
+        const int n_nb = grid.neighbors(x_trans_pt, search_method, nb, resolution);
+        if (n_nb == 0) continue;
+        const double x[3] = {source[idx].x, source[idx].y, source[idx].z};
+        PointDerivF d;
+        point_derivatives_f32(j_ang, h_ang, x, d);  // once per point
+        for (int ni = 0; ni < n_nb; ni++) {
+          double x_trans[3] = {x_trans_pt.x, x_trans_pt.y, x_trans_pt.z};
+          for (int k = 0; k < 3; k++) x_trans[k] -= nb[ni]->mean[k];
+          s_loc += update_derivatives(g_loc, H_loc, d, x_trans, nb[ni]->icov, gauss_d1, gauss_d2, compute_hessian);
+        }
+        nn_loc += n_nb;
+      }
+#pragma omp critical
+      {
+        score += s_loc;
+        for (int k = 0; k < 6; k++) g[k] += g_loc[k];
+        for (int k = 0; k < 36; k++) H[k] += H_loc[k];
+        nn_total += nn_loc;
+      }
+    }
+    mean_neighbors = N ? static_cast<double>(nn_total) / N : 0.0;
+    return score;
+  }
+
   std::vector<double> scores(N);
   std::vector<double> grads(N * 6);
   std::vector<double> hess(N * 36);
@@ -732,6 +783,14 @@ void NDT::compute_hessian(double H[36], const std::vector<Pt>& trans_cloud) {
   n_hess++;
   for (int i = 0; i < 36; i++) H[i] = 0;
   const size_t N = source.size();
+  // serial in the reference (and here by default: one thread, same summation order); the optimised
+  // baseline spreads the points over the threads
+  const int nthreads = optimised ? std::max(1, num_threads) : 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+  double Hl[36];
+  for (int i = 0; i < 36; i++) Hl[i] = 0;
+#pragma omp for schedule(static)
   for (size_t idx = 0; idx < N; idx++) {
     const Pt x_trans_pt = trans_cloud[idx];
     const Leaf* nb[27];
@@ -780,10 +839,13 @@ void NDT::compute_hessian(double H[36], const std::vector<Pt>& trans_cloud) {
           double Jj[3] = {J[0][j], J[1][j], J[2][j]}, CJj[3], Hb[3] = {HE[i][0][j], HE[i][1][j], HE[i][2][j]}, CHb[3];
           matvec(Jj, CJj);
           matvec(Hb, CHb);
-          H[i * 6 + j] += e_x_cov_x * (-gauss_d2 * dot3(xt, cov_dxd_pi) * dot3(xt, CJj) + dot3(xt, CHb) + dot3(Jj, cov_dxd_pi));
+          Hl[i * 6 + j] += e_x_cov_x * (-gauss_d2 * dot3(xt, cov_dxd_pi) * dot3(xt, CJj) + dot3(xt, CHb) + dot3(Jj, cov_dxd_pi));
         }
       }
     }
+  }
+#pragma omp critical
+  for (int i = 0; i < 36; i++) H[i] += Hl[i];
   }
 }
 

@@ -46,6 +46,9 @@ void oracle_set_params(void* h, float resolution, double step_size, double outli
   n->num_threads = num_threads;
 }
 
+// 0 = structurally faithful (default), 1 = the "optimised CPU" variant (timing baseline only)
+void oracle_set_optimised(void* h, int on) { static_cast<NDT*>(h)->optimised = on != 0; }
+
 void oracle_set_grid_params(void* h, int min_points_per_voxel, double eig_ratio) {
   NDT* n = static_cast<NDT*>(h);
   n->grid.min_points_per_voxel = min_points_per_voxel;

@@ -36,6 +36,7 @@ def lib():
         L.oracle_destroy.argtypes = [vp]
         L.oracle_set_params.argtypes = [vp, C.c_float, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
         L.oracle_set_grid_params.argtypes = [vp, C.c_int, C.c_double]
+        L.oracle_set_optimised.argtypes = [vp, C.c_int]
         L.oracle_set_target.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.c_int]
         L.oracle_set_source.argtypes = [vp, fp, C.c_size_t, C.c_size_t]
         L.oracle_align.argtypes = [vp, fp, fp, ip, ip, dp, fp, ip, ip]
@@ -82,9 +83,12 @@ class OracleNDT:
     """Mirrors pclomp::NormalDistributionsTransform's call surface (ndt_omp.h)."""
 
     def __init__(self, resolution=1.0, step_size=0.1, outlier_ratio=0.55, trans_eps=0.1, max_iter=35,
-                 search_method=DIRECT7, num_threads=1, min_points_per_voxel=6, eig_ratio=0.01):
+                 search_method=DIRECT7, num_threads=1, min_points_per_voxel=6, eig_ratio=0.01, optimised=False):
         self.L = lib()
         self.h = C.c_void_p(self.L.oracle_create())
+        # optimised=True: the "optimised CPU" timing baseline (dense voxel lookup, per-thread accumulators,
+        # parallel f64 Hessian); set before set_target.  Parity tests use the faithful default.
+        self.L.oracle_set_optimised(self.h, int(optimised))
         self.params = dict(resolution=resolution, step_size=step_size, outlier_ratio=outlier_ratio,
                            trans_eps=trans_eps, max_iter=max_iter, search_method=search_method,
                            num_threads=num_threads)

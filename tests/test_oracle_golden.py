@@ -234,3 +234,25 @@ def test_voxel_grid_filter_restatement():
     far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
     out, ov = po.voxel_grid_filter(far, 0.01)
     assert ov and np.array_equal(out, far)
+
+
+def test_optimised_cpu_variant_is_the_same_algorithm(pair):
+    """bench.py's second CPU baseline (dense voxel lookup, per-thread accumulators, parallel f64
+    Hessian) must be the same computation as the faithful oracle: identical neighbour sets, sums equal
+    to rounding, identical registration path."""
+    t, s = pair
+    for method in (po.DIRECT7, po.DIRECT1, po.DIRECT26, po.KDTREE):
+        a = po.OracleNDT(search_method=method, num_threads=4)
+        b = po.OracleNDT(search_method=method, num_threads=4, optimised=True)
+        for o in (a, b):
+            o.set_target(t)
+            o.set_source(s)
+        p = np.array([0.3, -0.2, 0.1, 0.01, -0.02, 0.03])
+        sa, ga, Ha, na = a.eval(p)
+        sb, gb, Hb, nb = b.eval(p)
+        assert na == nb
+        assert sb == pytest.approx(sa, rel=1e-12) and np.allclose(gb, ga, rtol=1e-10, atol=1e-9) and np.allclose(Hb, Ha, rtol=1e-10, atol=1e-8)
+        assert np.allclose(b.hessian_f64(p), a.hessian_f64(p), rtol=1e-10, atol=1e-8)
+        ra, rb = a.align(), b.align()
+        assert ra["iterations"] == rb["iterations"] and ra["n_evals"] == rb["n_evals"]
+        assert rot_err(ra["T"], rb["T"]) < 1e-7 and trans_err(ra["T"], rb["T"]) < 1e-6
