@@ -75,3 +75,31 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     moved = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)].astype(np.float32), T3.astype(np.float32))[:, :3]
     d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
     assert float(rows["fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_align_app_reproduces_readme_table(built_lib, pair, golden, tmp_path):
+    """apps/align.cpp -- the reference's benchmark program (ndt_omp/apps/align.cpp) over the C-ABI:
+    PCD files in, VoxelGrid, three search methods, fitness out.  On the bundled pair it prints the
+    fitness values of the reference's README (ndt_omp/README.md:13-46)."""
+    from toyslam_amd import ndt
+    t, s = pair  # the pair after align.cpp's 0.1 m down-sample (committed fixture)
+    tp, sp = str(tmp_path / "target.pcd"), str(tmp_path / "source.pcd")
+    ndt.pcd_write_xyz(tp, t)
+    ndt.pcd_write_xyz(sp, s)
+    exe = str(tmp_path / "align")
+    libdir = os.path.join(ROOT, "toyslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "align.cpp"),
+                           "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([exe, tp, sp, "0"], text=True)
+    blocks = out.split("--- ndt_mi355 (")[1:]
+    assert [b.split(")")[0] for b in blocks] == ["KDTREE", "DIRECT7", "DIRECT1"]
+    for b in blocks:
+        name = b.split(")")[0]
+        fields = {ln.split(":")[0].strip(): ln.split(":", 1)[1].strip() for ln in b.splitlines() if ":" in ln}
+        assert float(fields["fitness"]) == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        assert fields["converged"].startswith("1")
+        assert float(fields["single"].split("[")[0]) > 0 and float(fields["10times"].split("[")[0]) > 0
+    # with the down-sample step (idempotent on an already filtered cloud up to the order of the points)
+    out2 = subprocess.check_output([exe, tp, sp, "0.1"], text=True)
+    assert "after the 0.10 m voxel grid" in out2
