@@ -498,6 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
   double icov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double evals[3] = {0, 0, 0};
   int nr_points = cnt;
+  bool is_valid = false;
 
   if (cnt >= min_pts) {
     // :329-330
@@ -546,11 +547,16 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
       recs[r] = rec;
       if (nr_points >= min_pts) {
         lut[leaf_cell[o]] = r;
-        atomicAdd(n_valid, 1u);
+        is_valid = true;
       } else {
         lut[leaf_cell[o]] = r | kLutRejected;
       }
     }
+  }
+  {  // one counter update per wave instead of ~10^5 atomics on one word
+    const unsigned long long vm = __ballot(is_valid);
+    if (vm != 0 && (threadIdx.x & (kWave - 1)) == static_cast<unsigned>(__ffsll(static_cast<long long>(vm)) - 1))
+      atomicAdd(n_valid, static_cast<unsigned>(__popcll(vm)));
   }
   if (dump.nr_points) {
     dump.nr_points[o] = nr_points;
