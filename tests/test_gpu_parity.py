@@ -5,6 +5,8 @@ Tolerances (north_star): final transform within 1e-4 on rotation entries and 1e-
 Per-evaluation sums are compared far tighter: the f32 per-neighbour math is the same formulae with
 FMA contraction on the GPU (<= 1e-6 relative on the f64 sums); integer/index work is bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -38,6 +40,19 @@ def make_pair(mods, t, s, **kw):
     g.setInputSource(s)
     o.set_source(s)
     return g, o
+
+
+def launch_path_is_default():
+    """False under the development switches that give the launch-per-evaluation path another thread
+    partition / operation order than the evaluation server (results then agree to rounding only)."""
+    e = os.environ
+    return e.get("NDT_K2_FUSED", "1") != "0" and e.get("NDT_SPIN_WAIT", "1") != "0" and e.get("NDT_K2_VARIANT", "0") == "0"
+
+
+def same_transform(a, b):
+    if launch_path_is_default():
+        return np.array_equal(a, b)
+    return rot_err(a, b) < 1e-6 and trans_err(a, b) < 1e-5
 
 
 def close_sums(a, b, rel=2e-6):
@@ -323,6 +338,9 @@ def test_persistent_server_equals_launch_per_evaluation(mods, pair, method):
         res[persistent] = (g.getFinalTransformation().copy(), g.getFinalNumIteration(), g.getTransformationProbability(),
                            g.stats(), np.asarray(out).copy())
     a, b = res[True], res[False]
+    if not launch_path_is_default():
+        assert same_transform(a[0], b[0])
+        return
     assert np.array_equal(a[0], b[0])
     assert a[1] == b[1] and a[2] == b[2]
     assert a[3]["n_evals"] == b[3]["n_evals"] and a[3]["n_hessian_recomputes"] == b[3]["n_hessian_recomputes"]
@@ -351,13 +369,16 @@ def test_profiled_align_is_the_same_align(mods, pair):
     assert np.array_equal(g.getFinalTransformation(), T0) and g.getFinalNumIteration() == it0
     assert n0 + n1 == st0["n_evals"] and n2 == st0["n_hessian_recomputes"] and n0 >= 1 and ms0 > 0
     # mode 2: the persistent kernel of the registration between one event pair
+    if os.environ.get("NDT_K2_VARIANT", "0") != "0":
+        return  # validation builds of the body exist for the launch path only
+    g.setEvaluationPath(True)  # (whatever NDT_PERSISTENT says)
     g.profile(2)
     g.profile_read(3)
     g.align()
     g.align()
     n3, ms3 = g.profile_read(3)
     g.profile(0)
-    assert np.array_equal(g.getFinalTransformation(), T0) and n3 == 2 and 0 < ms3 < 1e3
+    assert same_transform(g.getFinalTransformation(), T0) and n3 == 2 and 0 < ms3 < 1e3
 
 
 def test_point_stride_32_and_clone(mods, pair):
