@@ -669,3 +669,41 @@ def test_server_with_several_points_per_thread(mods):
     r = o.align()
     assert a[1] == r["iterations"]
     assert rot_err(a[0], r["T"]) < ROT_TOL and trans_err(a[0], r["T"]) < TRANS_TOL
+
+
+def test_concurrent_handles_share_one_gpu(mods, pair):
+    """Four host threads, four handles, one GPU: the persistent evaluation servers take turns (each
+    needs all its blocks resident), every registration still returns its own bit-identical result."""
+    import threading
+    ndt, po, clouds = mods
+    t, s = pair
+    tgt = clouds.target_uniform(300000, half=(30.0, 30.0, 5.0))
+    src = clouds.source_from_target(tgt, 120000)
+
+    def make(big):
+        g = ndt.NormalDistributionsTransform()
+        if big:
+            g.setInputTarget(tgt)
+            g.setInputSource(src)
+        else:
+            g.setInputTarget(t)
+            g.setInputSource(s)
+        g.align()
+        return g, g.getFinalTransformation().copy(), g.getFinalNumIteration()
+
+    handles = [make(True), make(False), make(True), make(False)]
+    bad = []
+
+    def work(g, T0, it0, reps):
+        for _ in range(reps):
+            g.align()
+            if not (np.array_equal(g.getFinalTransformation(), T0) and g.getFinalNumIteration() == it0):
+                bad.append(1)
+
+    threads = [threading.Thread(target=work, args=(g, T0, it0, 60 if i % 2 == 0 else 300)) for i, (g, T0, it0) in enumerate(handles)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a registration did not return"
+    assert not bad

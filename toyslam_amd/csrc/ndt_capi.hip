@@ -833,7 +833,21 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   return NDT_OK;
 }
 
-// ---- persistent evaluation server (see ndt_kernels.hip) -----------------------------------------
+// ---- persistent evaluation server (see ndt_latency.hip) -----------------------------------------
+// One server per device at a time inside this process: a server needs ALL its blocks resident to
+// finish a round, and two of them launched from different host threads could each hold part of the
+// CUs and wait for the rest (they would recover through their time-outs, ~100 ms later).  Handles
+// therefore take turns at registration granularity.  (Across processes the time-out path remains.)
+std::mutex& server_device_mutex(int device) {
+  static std::mutex m[64];
+  return m[device & 63];
+}
+void server_mark(ndt_context* h, bool running) {
+  if (running && !h->server_running) server_device_mutex(h->device).lock();
+  if (!running && h->server_running) server_device_mutex(h->device).unlock();
+  h->server_running = running;
+}
+
 bool server_enabled() {
   static const bool on = [] { const char* v = getenv("NDT_PERSISTENT"); return v ? atoi(v) != 0 : true; }();
   return on;
@@ -842,13 +856,19 @@ bool server_enabled() {
 ndt_status server_stop(ndt_context* h) {
   if (!h->server_running) return NDT_OK;
   ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdExit, nullptr, nullptr);
-  h->server_running = false;
+  server_mark(h, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return NDT_OK;
 }
 
 ndt_status server_start(ndt_context* h) {
   if (h->server_running) return NDT_OK;
+  server_mark(h, true);  // takes this device's turn BEFORE anything is launched
+  struct Undo {
+    ndt_context* c;
+    bool armed = true;
+    ~Undo() { if (armed) server_mark(c, false); }
+  } undo{h};
   const int n = h->source->k2_n();
   const size_t mb_bytes = ndt::server_mailbox_bytes();
   if (!h->server_host_mbs) {
@@ -882,7 +902,7 @@ ndt_status server_start(ndt_context* h) {
                                   h->partials.p, h->server_counter.p, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
                                   h->server_want_dbg ? h->server_dbg.p : nullptr));
-  h->server_running = true;
+  undo.armed = false;
   return NDT_OK;
 }
 
@@ -892,7 +912,7 @@ void server_finish(ndt_context* h, const float* T_colmajor) {
   float T12[12];
   colmajor_to_T12(T_colmajor, T12);
   ndt::server_post(h->server_host_mb, ++h->eval_seq, ndt::kServerCmdTransformExit, T12, nullptr);
-  h->server_running = false;
+  server_mark(h, false);
 }
 
 // one evaluation through the running server; *served = false means the server had given up
@@ -914,7 +934,7 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
     if ((++spins & 0x3FFF) == 0) {
       if (ndt::server_dead_word(h->server_host_mb) != 0 || hipStreamQuery(h->stream) != hipErrorNotReady) {
         // the server left (idle time-out or error): drain and let the caller relaunch
-        h->server_running = false;
+        server_mark(h, false);
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (pub_ready(h->host_pub, seq)) break;
         ndt::server_reset_mailbox(h->server_host_mb);
