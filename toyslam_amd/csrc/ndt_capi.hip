@@ -612,7 +612,7 @@ ndt_status build_grid(ndt_context* h) {
     return fail(NDT_ERR_GRID_OVERFLOW, "voxel grid too large");
 
   // ---- count
-  DevBuf<unsigned> cell_count, block_sums, totals, rank;
+  DevBuf<unsigned> cell_count, block_sums, rank;
   DevBuf<int> key;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
