@@ -320,6 +320,12 @@ class NormalDistributionsTransform:
         check(self._L.ndt_eval_hessian_f64(self._h, _d(p), _d(H)))
         return H.reshape(6, 6)
 
+    def grid_counts(self):
+        """Occupied / valid voxel counts of the target grid."""
+        nl, nv = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.ndt_grid_size(self._h, C.byref(nl), C.byref(nv)))
+        return dict(n_leaves=nl.value, n_valid=nv.value)
+
     def grid(self):
         nl, nv = C.c_size_t(0), C.c_size_t(0)
         check(self._L.ndt_grid_size(self._h, C.byref(nl), C.byref(nv)))
