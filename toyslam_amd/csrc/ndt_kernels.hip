@@ -291,15 +291,21 @@ __device__ void eig3_jacobi(const double A_in[3][3], double w[3], double V[3][3]
   for (int sweep = 0; sweep < 50; sweep++) {
     const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
     const double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-    if (off <= 1e-300 || off <= dia * 1e-18) break;
+    // Jacobi converges quadratically and the eigenvalue error is O(off^2 / gap): at off <= eps/2 * dia
+    // another sweep cannot change a bit of the result that is consumed
+    if (off <= 1e-300 || off <= dia * 1e-16) break;
 #pragma unroll
     for (int pq = 0; pq < 3; pq++) {
       const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
       const double apq = A[p][q];
       if (apq == 0.0) continue;
-      const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-      const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      // tan of the rotation angle, the root of t^2 + 2 theta t - 1 = 0 that is smaller in magnitude,
+      // written without forming theta = d / (2 apq):  t = 2 apq / (d + sign(d) sqrt(d^2 + 4 apq^2))
+      // (one division and two square roots per rotation instead of three and two: the f64 division
+      // chains are what this one-thread-per-voxel kernel waits for)
+      const double d = A[q][q] - A[p][p], b2 = 2.0 * apq;
+      const double t = b2 / (d + copysign(sqrt(d * d + b2 * b2), d));
+      const double c = rsqrt(t * t + 1.0), s = t * c;
       for (int k = 0; k < 3; k++) {
         const double akp = A[k][p], akq = A[k][q];
         A[k][p] = c * akp - s * akq;
