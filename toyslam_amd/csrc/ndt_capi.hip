@@ -163,6 +163,10 @@ struct DeviceCloud {
   DevBuf<float4> pts;     // caller's order (align's output cloud keeps it)
   DevBuf<float4> sorted;  // lattice-cell order, what the derivative kernels read
   size_t n = 0;
+  // bounding boxes computed during the upload (k_repack_bbox): [0] over the non-NaN points (the
+  // is_dense rule of getMinMax3D), [1] over the finite points (!is_dense); min > max = no such point
+  float bb_min[2][3] = {{FLT_MAX, FLT_MAX, FLT_MAX}, {FLT_MAX, FLT_MAX, FLT_MAX}};
+  float bb_max[2][3] = {{-FLT_MAX, -FLT_MAX, -FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
   size_t n_sorted = 0;    // finite points only
   std::vector<size_t> scan_counts;  // batch uploads: finite points of each scan ...
   std::vector<size_t> scan_starts;  // ... and where its ordered segment starts in `sorted`
@@ -224,6 +228,7 @@ struct ndt_context {
   DevBuf<float4> out_cloud;
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
+  float* bbox_rows = nullptr;     // pinned, per-block bounding-box rows of the last upload (k_repack_bbox)
   double* host_pub = nullptr;     // pinned, tagged publication row of the single-scan paths (ndt_kernels.hip publish_row_tagged)
   size_t host_result_rows = 0;
   unsigned long long eval_seq = 0;
@@ -274,6 +279,7 @@ struct ndt_context {
     release_buffers();
     if (host_result) (void)hipHostFree(host_result);
     if (host_pub) (void)hipHostFree(host_pub);
+    if (bbox_rows) (void)hipHostFree(bbox_rows);
     if (server_host_mbs) (void)hipHostFree(server_host_mbs);
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -365,10 +371,56 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
       HIP_TRY(hipMemcpyAsync(h->staging.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
       d_src = h->staging.p;
     }
-    HIP_TRY(ndt::launch_repack(d_src, n, stride, c->pts.p, h->stream));
+    // repack and bounding boxes in one pass; the per-block rows come back behind the synchronisation
+    // the upload needs anyway (the caller's buffer must be free to go when this returns)
+    const int nb = static_cast<int>(std::min<size_t>(1024, (n + 255) / 256));
+    if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
+    // the kernel stores its per-block rows straight into pinned host memory (no D2H copy to queue)
+    HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, c->pts.p, h->bbox_rows, nb, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    const float* mm = h->bbox_rows;
+    for (int b = 0; b < nb; b++)
+      for (int v = 0; v < 2; v++)
+        for (int k = 0; k < 3; k++) {
+          c->bb_min[v][k] = std::min(c->bb_min[v][k], mm[b * 12 + v * 6 + k]);
+          c->bb_max[v][k] = std::max(c->bb_max[v][k], mm[b * 12 + v * 6 + 3 + k]);
+        }
   }
   out = c;
+  return NDT_OK;
+}
+
+// bounding box of a dense float4 device cloud: taken from the upload when the cloud came through
+// upload_cloud (no kernel, no wait), else computed here (one kernel + one host round trip)
+struct BBox {
+  float mn[3], mx[3];
+};
+BBox bbox_of(const DeviceCloud& c, int dense) {
+  BBox b;
+  const int v = dense ? 0 : 1;
+  for (int k = 0; k < 3; k++) {
+    b.mn[k] = c.bb_min[v][k];
+    b.mx[k] = c.bb_max[v][k];
+  }
+  return b;
+}
+ndt_status bbox_compute(ndt_context* h, const float4* d_pts, int n, int dense, BBox& out) {
+  const int nb = std::min(1024, (n + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(d_pts, n, dense, d_mm.p, nb, h->stream));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 3; k++) {
+    out.mn[k] = FLT_MAX;
+    out.mx[k] = -FLT_MAX;
+  }
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      out.mn[k] = std::min(out.mn[k], mm[b * 6 + k]);
+      out.mx[k] = std::max(out.mx[k], mm[b * 6 + 3 + k]);
+    }
   return NDT_OK;
 }
 
@@ -376,24 +428,17 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
 // laid over the range's own bounding box (x fastest), stable inside a cell.  Rigid transforms
 // preserve locality, so whatever the pose, consecutive lanes of the derivative kernels land in
 // the same or adjacent target voxels.  Only the order of the f64 summation changes.
-ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitch, float4* d_out, size_t* n_out) {
+ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitch, float4* d_out, size_t* n_out,
+                       const BBox* known_bbox = nullptr) {
   *n_out = 0;
   if (n == 0) return NDT_OK;
   hipStream_t st = h->stream;
   const int ni = static_cast<int>(n);
-  const int nb = std::min(1024, (ni + 255) / 256);
-  DevBuf<float> d_mm;
-  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
-  HIP_TRY(ndt::launch_bbox(d_pts, ni, 0, d_mm.p, nb, st));
-  std::vector<float> mm(static_cast<size_t>(nb) * 6);
-  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < 3; k++) {
-      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
-      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
-    }
+  BBox bb;
+  if (known_bbox) bb = *known_bbox;
+  else { ndt_status sb = bbox_compute(h, d_pts, ni, 0, bb); if (sb) return sb; }
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
   if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point
   ndt::GridGeom geo{};
   for (;; pitch *= 2.0f) {
@@ -452,19 +497,9 @@ ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   const int ni = static_cast<int>(c->n);
   c->scan_counts.assign(n_scans, 0);
   c->scan_starts.assign(n_scans + 1, 0);
-  const int nb = std::min(1024, (ni + 255) / 256);
-  DevBuf<float> d_mm;
-  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
-  HIP_TRY(ndt::launch_bbox(c->pts.p, ni, 0, d_mm.p, nb, st));
-  std::vector<float> mm(static_cast<size_t>(nb) * 6);
-  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < 3; k++) {
-      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
-      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
-    }
+  const BBox bb = bbox_of(*c, 0);  // from the upload
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
   if (!(min_p[0] <= max_p[0])) return NDT_OK;
   ndt::GridGeom geo{};
   for (float pitch = h->resolution;; pitch *= 2.0f) {
@@ -545,7 +580,8 @@ ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   HIP_TRY(c->sorted.reserve(c->n));
   if (!offsets) {
     size_t got = 0;
-    ndt_status s = order_range(h, c->pts.p, c->n, h->resolution, c->sorted.p, &got);
+    const BBox bb = bbox_of(*c, 0);
+    ndt_status s = order_range(h, c->pts.p, c->n, h->resolution, c->sorted.p, &got, &bb);
     if (s) return s;
     c->n_sorted = got;
   } else {
@@ -575,19 +611,9 @@ ndt_status build_grid(ndt_context* h) {
   }
   hipStream_t st = h->stream;
   // ---- bbox
-  const int nb = std::min(1024, (n + 255) / 256);
-  DevBuf<float> d_mm;
-  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
-  HIP_TRY(ndt::launch_bbox(h->target->pts.p, n, h->target_dense, d_mm.p, nb, st));
-  std::vector<float> mm(static_cast<size_t>(nb) * 6);
-  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < 3; k++) {
-      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
-      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
-    }
+  const BBox bb = bbox_of(*h->target, h->target_dense);  // computed during the upload: no kernel, no wait
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
   if (!(min_p[0] <= max_p[0])) {  // no finite point at all
     h->grid = g;
     return NDT_OK;
@@ -1320,26 +1346,18 @@ ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness
 // per occupied voxel in ascending voxel-index order; *overflow = the leaf is too small for the
 // bounding box and, as PCL does, the input was copied through.  Synchronises h->stream.
 static ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
-                                      size_t* n_out, bool* overflow) {
+                                      size_t* n_out, bool* overflow, const BBox* known_bbox = nullptr) {
   *n_out = 0;
   *overflow = false;
   if (n == 0) return NDT_OK;
   hipStream_t st = h->stream;
   const int ni = static_cast<int>(n);
   // bbox -> geometry, exactly as VoxelGrid::applyFilter
-  const int nb = std::min(1024, (ni + 255) / 256);
-  DevBuf<float> d_mm;
-  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
-  HIP_TRY(ndt::launch_bbox(d_in, ni, is_dense, d_mm.p, nb, st));
-  std::vector<float> mm(static_cast<size_t>(nb) * 6);
-  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < 3; k++) {
-      min_p[k] = std::min(min_p[k], mm[b * 6 + k]);
-      max_p[k] = std::max(max_p[k], mm[b * 6 + 3 + k]);
-    }
+  BBox bb;
+  if (known_bbox) bb = *known_bbox;
+  else { ndt_status sb = bbox_compute(h, d_in, ni, is_dense, bb); if (sb) return sb; }
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
   if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point: empty output
   ndt::GridGeom geo{};
   long long d[3];
@@ -1410,7 +1428,8 @@ static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, siz
   }
   size_t n_written = 0;
   bool overflow = false;
-  s = voxel_filter_device(h, c->pts.p, n, is_dense, leaf, d_out, &n_written, &overflow);
+  const BBox bb = bbox_of(*c, is_dense);
+  s = voxel_filter_device(h, c->pts.p, n, is_dense, leaf, d_out, &n_written, &overflow, &bb);
   if (s) return s;
   if (!on_device && n_written) {
     if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");

@@ -83,6 +83,44 @@ __global__ __launch_bounds__(kBlock) void k_bbox(const float4* __restrict__ pts,
   }
 }
 
+// repack + both bounding boxes in one pass over the upload: block_minmax[block][12] =
+// {min xyz, max xyz} over the points that are not NaN (what getMinMax3D sees for an is_dense cloud) and
+// {min xyz, max xyz} over the finite points (the !is_dense rule).  The host reduces the per-block rows
+// behind the synchronisation the upload needs anyway, so no consumer launches k_bbox or waits again.
+__global__ __launch_bounds__(kBlock) void k_repack_bbox(const unsigned char* __restrict__ src, size_t n, size_t stride,
+                                                        float4* __restrict__ dst, float* __restrict__ block_minmax) {
+  float mn[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+  float mx[6] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float* p = reinterpret_cast<const float*>(src + i * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    dst[i] = make_float4(x, y, z, 1.0f);
+    mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);  // fminf / fmaxf drop NaN operands
+    mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+    mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+    if (finite3(x, y, z)) {
+      mn[3] = fminf(mn[3], x); mx[3] = fmaxf(mx[3], x);
+      mn[4] = fminf(mn[4], y); mx[4] = fmaxf(mx[4], y);
+      mn[5] = fminf(mn[5], z); mx[5] = fmaxf(mx[5], z);
+    }
+  }
+  __shared__ float s[kBlock / kWave][12];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+    const int base = (k < 3) ? 0 : 6, c = k % 3;
+    if (lane == 0) { s[wave][base + c] = a; s[wave][base + 3 + c] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const bool is_min = (threadIdx.x % 6) < 3;
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v = is_min ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+    block_minmax[blockIdx.x * 12 + threadIdx.x] = v;
+  }
+}
+
 // linear voxel index of a target point while BUILDING the grid:
 // floor(x * inv_leaf) - float(min_b), _impl.hpp:218-223 (f32, trap 2)
 __device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, float z) {
@@ -918,6 +956,14 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_repack, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream,
                      static_cast<const unsigned char*>(d_src), n, stride_bytes, d_dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
+                              int n_blocks, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
+                     stride_bytes, d_dst, d_block_minmax);
   return hipGetLastError();
 }
 

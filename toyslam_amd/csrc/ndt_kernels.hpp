@@ -77,6 +77,9 @@ constexpr int kNumAcc = 29;
 hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream);
 
 struct GridBuildScratch;  // opaque, owned by the grid
+// repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
+hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
+                              int n_blocks, hipStream_t stream);
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
 hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
                         unsigned* d_cell_count, hipStream_t stream);
