@@ -707,3 +707,74 @@ def test_concurrent_handles_share_one_gpu(mods, pair):
         th.join(timeout=120)
     assert not any(th.is_alive() for th in threads), "a registration did not return"
     assert not bad
+
+
+# ------------------------------------------------------------------ HBM-resident entry points
+def test_device_resident_entry_points_equal_host_ones(mods, pair):
+    """Every *_device entry point (clouds handed over as device pointers: prefilter, target, source,
+    map update, batch) must do exactly what its host-buffer twin does."""
+    import ctypes as C
+    ndt, po, clouds = mods
+    t, s = pair
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    held = []
+
+    def to_device(a):  # (N, 4) float32 -> device pointer
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), max(a.nbytes, 16)) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        held.append(p)
+        return p.value
+
+    def from_device(ptr, n):
+        out = np.zeros((n, 4), np.float32)
+        assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    try:
+        t4 = np.c_[t, np.ones(len(t), np.float32)]
+        s4 = np.c_[s, np.ones(len(s), np.float32)]
+        dt, ds = to_device(t4), to_device(s4)
+        gh = ndt.NormalDistributionsTransform()   # host twin
+        gd = ndt.NormalDistributionsTransform()   # device twin
+        # N1
+        ref = gh.voxelGridFilter(t, 0.5)
+        dout = to_device(np.zeros((len(t), 4), np.float32))
+        m = gd.voxelGridFilterDevice(dt, len(t), 16, 0.5, dout)
+        assert m == len(ref) and np.array_equal(from_device(dout, m)[:, :3], ref)
+        # target / source / align
+        gh.setInputTarget(t)
+        gh.setInputSource(s)
+        gd.setInputTargetDevice(dt, len(t), 16)
+        gd.setInputSourceDevice(ds, len(s), 16)
+        out_h = gh.align(n_out=len(s))
+        gd.align()
+        assert np.array_equal(gd.getFinalTransformation(), gh.getFinalTransformation())
+        ptr, n = gd.output_device()
+        assert n == len(s) and np.array_equal(from_device(ptr, n), out_h)
+        # the aligned cloud, still on the device, as the next step's input: N2 ...
+        T = gd.getFinalTransformation()
+        gh.mapUpdate(t, None, 0.5)
+        gh.mapUpdate(s, T, 0.5)
+        gd.mapUpdateDevice(dt, len(t), 16, None, 0.5)
+        gd.mapUpdateDevice(ds, len(s), 16, T, 0.5)
+        assert gd.mapSize() == gh.mapSize() and np.array_equal(gd.mapGet(), gh.mapGet())
+        # ... and as a new source (its records are float4, stride 16)
+        gd.setInputSourceDevice(ptr, n, 16)
+        gh.setInputSource(out_h[:, :3])
+        gd.align()
+        gh.align()
+        assert np.array_equal(gd.getFinalTransformation(), gh.getFinalTransformation())
+        # batch
+        offs = np.array([0, len(s) // 2, len(s)], dtype=np.uintp)
+        rh = gh.alignBatch(clouds=[s[:len(s) // 2], s[len(s) // 2:]])
+        rd = gd.alignBatch(device_ptr=ds, offsets=offs, stride_bytes=16)
+        for a, b in zip(rh["T"], rd["T"]):
+            assert np.array_equal(a, b)
+    finally:
+        for p in held:
+            hip.hipFree(p)
