@@ -179,3 +179,27 @@ def test_reference_fixture(ndt):
     py, names = clouds.read_pcd(REF_PCD)
     assert names[:3] == ["x", "y", "z"] and got.shape == (69088, 3) and dense
     assert np.array_equal(got, py[:, :3])
+
+
+REF_PCD2 = "/root/reference/ndt_omp/data/251371071.pcd"
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_PCD) and os.path.exists(REF_PCD2)), reason="reference tree not mounted")
+def test_committed_pair_is_the_reference_pair_after_align_cpp_downsample(ndt, pair):
+    """tests/golden/pair_0p1.npz (what every parity test registers) is the reference's bundled PCD pair
+    after apps/align.cpp's 0.1 m VoxelGrid (align.cpp:36-69: argv[1] = target = 251370668, argv[2] =
+    source = 251371071): rebuilt here from the raw files through the library's PCD reader and the
+    oracle's VoxelGrid restatement."""
+    from oracle import pyoracle as po
+    from toyslam_amd import clouds
+    t, s = pair
+    for path, fixture in ((REF_PCD, t), (REF_PCD2, s)):
+        raw, dense = ndt.pcd_read_xyz(path)
+        assert dense
+        # the generator (oracle/gen_golden.py) used the numpy down-sample: f64 centroid sums
+        assert np.array_equal(clouds.voxel_downsample(raw, 0.1), fixture)
+        # [PCL]'s own f32 centroid accumulation (the oracle's restatement, what N1 reproduces on the
+        # GPU) gives the same voxels in the same order; coordinates agree to the last f32 bit or two
+        down, overflow = po.voxel_grid_filter(raw, 0.1)
+        assert not overflow and down.shape == fixture.shape
+        assert np.abs(down - fixture).max() <= 2e-5
