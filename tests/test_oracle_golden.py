@@ -1,5 +1,7 @@
 """CPU: the oracle against its committed golden vectors and against the only
 known answers in the reference tree (README fitness, ndt_omp/README.md:23-46)."""
+import os
+
 import numpy as np
 import pytest
 from scipy.spatial import cKDTree
@@ -256,3 +258,22 @@ def test_optimised_cpu_variant_is_the_same_algorithm(pair):
         ra, rb = a.align(), b.align()
         assert ra["iterations"] == rb["iterations"] and ra["n_evals"] == rb["n_evals"]
         assert rot_err(ra["T"], rb["T"]) < 1e-7 and trans_err(ra["T"], rb["T"]) < 1e-6
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/ndt_omp/data/251370668.pcd"), reason="reference tree not mounted")
+@pytest.mark.parametrize("name", ["DIRECT7", "DIRECT1", "KDTREE"])
+def test_readme_fitness_from_the_raw_pcd_files(built_lib, golden, name):
+    """The whole of apps/align.cpp from the reference's own data files: PCD read (the library's reader),
+    0.1 m VoxelGrid with PCL's f32 centroid accumulation (the oracle's restatement), NDT at the class
+    defaults, getFitnessScore -- the README's printed values (ndt_omp/README.md:13-46)."""
+    from toyslam_amd import ndt
+    t, _ = ndt.pcd_read_xyz("/root/reference/ndt_omp/data/251370668.pcd")
+    s, _ = ndt.pcd_read_xyz("/root/reference/ndt_omp/data/251371071.pcd")
+    t = po.voxel_grid_filter(t, 0.1)[0]
+    s = po.voxel_grid_filter(s, 0.1)[0]
+    o = po.OracleNDT(resolution=1.0, search_method=METHODS[name], num_threads=4)
+    o.set_target(t)
+    o.set_source(s)
+    r = o.align()
+    assert r["converged"]
+    assert pcl_fitness(t, s, r["T"]) == pytest.approx(golden["readme_fitness"][name], abs=2e-6)
