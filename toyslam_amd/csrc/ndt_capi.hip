@@ -1526,20 +1526,32 @@ void ndt_host_chain_pose(const float* pose, const float* transform, float* out) 
 ndt_status ndt_pcd_read_header(const char* path, size_t* n_points, int* n_fields, int* data_kind) {
   if (!path) return fail(NDT_ERR_INVALID, "null path");
   std::string err;
-  if (ndt::pcd_read_header(path, n_points, n_fields, data_kind, err)) return fail(NDT_ERR_INVALID, err);
+  try {
+    if (ndt::pcd_read_header(path, n_points, n_fields, data_kind, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {  // nothing C++ crosses the C boundary
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
   return NDT_OK;
 }
 ndt_status ndt_pcd_read_xyz(const char* path, void* out, size_t capacity_points, size_t stride_bytes, size_t* n_points,
                             int* is_dense) {
   if (!path || (capacity_points && !out) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
   std::string err;
-  if (ndt::pcd_read_xyz(path, out, capacity_points, stride_bytes, n_points, is_dense, err)) return fail(NDT_ERR_INVALID, err);
+  try {
+    if (ndt::pcd_read_xyz(path, out, capacity_points, stride_bytes, n_points, is_dense, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
   return NDT_OK;
 }
 ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t stride_bytes, int binary) {
   if (!path || (n && !pts) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
   std::string err;
-  if (ndt::pcd_write_xyz(path, pts, n, stride_bytes, binary, err)) return fail(NDT_ERR_INVALID, err);
+  try {
+    if (ndt::pcd_write_xyz(path, pts, n, stride_bytes, binary, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
   return NDT_OK;
 }
 

@@ -32,6 +32,7 @@ struct Header {
   int data = -1;  // 0 ascii, 1 binary, 2 binary_compressed
   size_t record = 0;
   long body_offset = 0;
+  size_t body_bytes = 0;  // bytes of the file after the header
 };
 
 std::vector<std::string> split(const std::string& s) {
@@ -110,12 +111,20 @@ std::string parse_header(FILE* f, Header& h) {
   if (!h.have_points) h.points = h.width * h.height;
   size_t off = 0;
   for (Field& fd : h.fields) {
-    if (fd.size <= 0 || fd.size > 8 || fd.count < 0) return "bad SIZE / COUNT";
+    if (fd.size <= 0 || fd.size > 8 || fd.count < 0 || fd.count > (1 << 20)) return "bad SIZE / COUNT";
     fd.offset = off;
     off += static_cast<size_t>(fd.size) * fd.count;
   }
+  if (off == 0 || off > (size_t(1) << 24)) return "bad record size";
   h.record = off;
   h.body_offset = std::ftell(f);
+  // what is left of the file bounds what the header may promise (no allocation on a lying header)
+  if (std::fseek(f, 0, SEEK_END) != 0) return "cannot seek";
+  h.body_bytes = static_cast<size_t>(std::ftell(f) - h.body_offset);
+  if (std::fseek(f, h.body_offset, SEEK_SET) != 0) return "cannot seek";
+  if (h.data == 1 && h.points > h.body_bytes / h.record) return "truncated binary body";
+  if (h.data == 0 && h.points > h.body_bytes) return "fewer ascii records than POINTS";
+  if (h.data == 2 && h.points > (size_t(1) << 40) / h.record) return "implausible POINTS";
   return "";
 }
 
@@ -199,6 +208,11 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
   if (!err.empty()) { std::fclose(f); err = std::string(path) + ": " + err; return 2; }
   const int ix = find_field(h, "x"), iy = find_field(h, "y"), iz = find_field(h, "z");
   if (ix < 0 || iy < 0 || iz < 0) { std::fclose(f); err = std::string(path) + ": no x / y / z fields"; return 2; }
+  if (h.fields[ix].count < 1 || h.fields[iy].count < 1 || h.fields[iz].count < 1) {
+    std::fclose(f);
+    err = std::string(path) + ": x / y / z with COUNT 0";
+    return 2;
+  }
   if (n_points) *n_points = h.points;
   if (h.points > capacity) { std::fclose(f); err = "output buffer too small"; return 3; }
   unsigned char* o = static_cast<unsigned char*>(out);
@@ -244,6 +258,7 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
       uint32_t sizes[2];
       if (std::fread(sizes, 4, 2, f) != 2) { rc = 2; err = std::string(path) + ": truncated compressed header"; }
       if (!rc && sizes[1] != raw_bytes) { rc = 2; err = std::string(path) + ": uncompressed size does not match the header"; }
+      if (!rc && sizes[0] > h.body_bytes) { rc = 2; err = std::string(path) + ": truncated compressed body"; }
       std::vector<unsigned char> comp;
       if (!rc) {
         comp.resize(sizes[0]);
