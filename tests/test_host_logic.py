@@ -182,3 +182,19 @@ def test_quadratic_bowl_converges(ndt):
     r = ndt.host_run_driver(evaluator, 1, trans_eps=1e-6, max_iter=50, step_size=0.1)
     assert r["converged"]
     assert np.abs(r["T"] - po.pose_to_matrix(p_star)).max() < 1e-5
+
+
+def test_driver_state_machine_under_sanitizers(tmp_path):
+    """tests/driver_fuzz.cpp: the Newton / More-Thuente state machine fed random, singular, zero and
+    non-finite evaluation results, built with ASan + UBSan (CPU build only): every run terminates within
+    max_iterations + 2 passes and a bounded number of evaluations, without undefined behaviour."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "driver_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I" + os.path.join(root, "toyslam_amd", "csrc"),
+                           os.path.join(root, "tests", "driver_fuzz.cpp"), os.path.join(root, "toyslam_amd", "csrc", "ndt_driver.cpp"),
+                           "-o", exe])
+    out = subprocess.run([exe, "5000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no crash" in out.stdout
