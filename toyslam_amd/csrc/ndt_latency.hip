@@ -33,11 +33,20 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   __shared__ double lds[kWaves * 32];
   __shared__ double lds2[kParts * kEvalStride];
   __shared__ int s_last;
+  // The 81 parameter words go to LDS first: read from the kernel arguments they occupy ~90 SGPRs,
+  // which spill to VGPR lanes (v_readlane / v_writelane made up ~20 % of this kernel's VALU count).
+  __shared__ EvalParams sP;
+  {
+    const int* sp = reinterpret_cast<const int*>(&P);
+    int* dp = reinterpret_cast<int*>(&sP);
+    for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += TPB) dp[t] = sp[t];
+  }
+  __syncthreads();
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, P, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
