@@ -670,9 +670,14 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
     else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
     block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
   } else {
-    if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, P, first, stride, acc);
-    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, P, first, stride, acc);
-    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, P, first, stride, acc);
+    // parameters through LDS here too: as kernel arguments they overflow the SGPR file
+    const int* sp = reinterpret_cast<const int*>(&P);
+    int* dp = reinterpret_cast<int*>(&sP);
+    for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
+    __syncthreads();
+    if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, first, stride, acc);
+    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, sP, first, stride, acc);
+    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, sP, first, stride, acc);
     block_reduce_store<kNumAcc>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
   }
 }
@@ -696,6 +701,12 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     __syncthreads();
     src += dsc->offset;
     n = dsc->count;
+    prm = &sP;
+  } else {
+    const int* sp = reinterpret_cast<const int*>(&P);
+    int* dp = reinterpret_cast<int*>(&sP);
+    for (int t = threadIdx.x; t < static_cast<int>(sizeof(Hess64Params) / 4); t += kBlock) dp[t] = sp[t];
+    __syncthreads();
     prm = &sP;
   }
   double* out = partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride;
