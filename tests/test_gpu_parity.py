@@ -436,7 +436,13 @@ def test_edge_cases(mods, pair):
     o = po.OracleNDT()
     o.set_target(t)
     o.set_source(np.delete(bad, 3, axis=0))
-    assert g.eval(np.zeros(6))[0] == pytest.approx(o.eval(np.zeros(6))[0], rel=1e-6)
+    rg, ro = g.eval(np.zeros(6)), o.eval(np.zeros(6))
+    assert rg[0] == pytest.approx(ro[0], rel=1e-6)
+    assert close_sums(rg[1], ro[1]) and close_sums(rg[2], ro[2])  # gradient and Hessian too: no 0 x NaN leak
+    assert np.isfinite(g.hessian_f64(np.zeros(6))).all()
+    g.align()
+    ra = o.align()
+    assert g.getFinalNumIteration() == ra["iterations"] and g.hasConverged() == ra["converged"]
     g.setNeighborhoodSearchMethod(7)                           # unknown value: the reference's `default:` = DIRECT7
     g.setInputSource(s)
     o.set_source(s)
@@ -778,3 +784,29 @@ def test_device_resident_entry_points_equal_host_ones(mods, pair):
     finally:
         for p in held:
             hip.hipFree(p)
+
+
+@pytest.mark.parametrize("method", ["DIRECT7", "DIRECT26", "KDTREE"])
+def test_ragged_batch_equals_individual(mods, pair, method):
+    """A lock-step batch of very different scans -- empty, a handful of points, NaN points, far outside
+    the target, big -- in every search mode: each member gets the registration it would get alone."""
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(17)
+    nanny = s[:3000].copy()
+    nanny[::7] = np.nan
+    scans = [s[:2000], np.zeros((0, 3), np.float32), s[2000:2007], nanny, (s[:500] + 500.0).astype(np.float32),
+             s, clouds.apply_T(np.linalg.inv(clouds.random_T(rng, 0.3, 1.0)), s[1::2].copy())]
+    g = ndt.NormalDistributionsTransform()
+    g.setNeighborhoodSearchMethod(getattr(po, method))
+    g.setTransformationEpsilon(0.01)
+    g.setMaximumIterations(30)
+    g.setInputTarget(t)
+    res = g.alignBatch(scans)
+    for k, scan in enumerate(scans):
+        g.setInputSource(scan)
+        g.align()
+        Ts = g.getFinalTransformation()
+        # (a 7-point scan is an ill-conditioned problem: last-ulp differences of the sums are amplified)
+        assert rot_err(res["T"][k], Ts) < 1e-5 and trans_err(res["T"][k], Ts) < 1e-5, "scan %d" % k
+        assert res["iterations"][k] == g.getFinalNumIteration() and bool(res["converged"][k]) == g.hasConverged(), "scan %d" % k

@@ -183,6 +183,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __
 
 constexpr int kLutRejected = 0x40000000;  // LUT flag: voxel has a record but nr_points == -1
 
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
 // ---------------------------------------------------------------------------
 // K2  derivatives
 // ---------------------------------------------------------------------------
@@ -481,6 +483,10 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
     if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[1] = stamp(); }
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
+    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
+    // would poison the per-point finish even though every neighbour term is rejected.
+    if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
@@ -537,6 +543,10 @@ __device__ __forceinline__ void derivatives_body_split7(const float4* __restrict
     const float4 pt = src[t >> 3];
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
+    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
+    // would poison the per-point finish even though every neighbour term is rejected.
+    if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
@@ -562,6 +572,10 @@ __device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ s
     const float4 pt = src[i];
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
+    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
+    // would poison the per-point finish even though every neighbour term is rejected.
+    if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
@@ -646,6 +660,10 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
     const float4 pt = src[i];
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
+    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
+    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
+    // would poison the per-point finish even though every neighbour term is rejected.
+    if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;

@@ -42,7 +42,6 @@ __global__ __launch_bounds__(kBlock) void k_selftest_reduce(double* __restrict__
   block_reduce_store<kNumAcc>(acc, out + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
 }
 
-__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
 // ---------------------------------------------------------------------------
 // repack: arbitrary-stride xyz records -> dense float4 (x,y,z,1)
