@@ -1,0 +1,41 @@
+"""Randomised differential test (development aid): random resolutions, search methods, step sizes, outlier
+ratios, stopping rules, cloud subsets with NaN / inf points and random guesses -- GPU registration against
+the oracle.  A mismatch is printed; per-evaluation agreement decides whether it is a bug or a line search
+that rounding sent down another path (ill-posed cases).   fuzz_align.py [seed] [cases]"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from toyslam_amd import clouds, ndt
+from oracle import pyoracle as po
+d = np.load("tests/golden/pair_0p1.npz"); t, s = d["target"], d["source"]
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+methods = [po.KDTREE, po.DIRECT26, po.DIRECT7, po.DIRECT1]
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    res = float(rng.choice([0.5, 0.8, 1.0, 1.5, 2.0, 3.0]))
+    m = int(rng.choice(methods))
+    kw = dict(resolution=res, search_method=m, step_size=float(rng.choice([0.05, 0.1, 0.3])), outlier_ratio=float(rng.choice([0.3, 0.55, 0.8])),
+              trans_eps=float(rng.choice([0.1, 0.01, 1e-3])), max_iter=int(rng.choice([5, 20, 35])))
+    nt = int(rng.integers(2000, len(t))); ns = int(rng.integers(50, len(s)))
+    tt = t[rng.choice(len(t), nt, replace=False)].copy(); ss = s[rng.choice(len(s), ns, replace=False)].copy()
+    dense_t = True
+    if rng.random() < 0.3:
+        tt[rng.choice(nt, 5, replace=False)] = np.nan; dense_t = False
+    if rng.random() < 0.3:
+        ss[rng.choice(ns, 3, replace=False), int(rng.integers(0, 3))] = np.inf if rng.random() < 0.5 else np.nan
+    guess = None if rng.random() < 0.5 else clouds.random_T(rng, 0.3, 2.0).astype(np.float32)
+    g = ndt.NormalDistributionsTransform(); o = po.OracleNDT(num_threads=8, **kw)
+    g.setResolution(res); g.setNeighborhoodSearchMethod(m); g.setStepSize(kw["step_size"]); g.setOutlierRatio(kw["outlier_ratio"])
+    g.setTransformationEpsilon(kw["trans_eps"]); g.setMaximumIterations(kw["max_iter"])
+    g.setInputTarget(tt, is_dense=dense_t); o.set_target(tt, is_dense=dense_t)
+    g.setInputSource(ss); o.set_source(ss)
+    g.align(guess); r = o.align(guess)
+    T = g.getFinalTransformation()
+    ok_T = np.abs(T[:3, :3] - r["T"][:3, :3]).max() < 1e-4 and np.abs(T[:3, 3] - r["T"][:3, 3]).max() < 1e-3
+    ok_it = g.getFinalNumIteration() == r["iterations"] and g.hasConverged() == r["converged"]
+    if not (ok_T and ok_it):
+        bad += 1
+        print("MISMATCH case", case, kw, "nt", nt, "ns", ns, "dense_t", dense_t, "guess", guess is not None,
+              "it gpu/oracle", g.getFinalNumIteration(), r["iterations"], "conv", g.hasConverged(), r["converged"],
+              "dR", float(np.abs(T[:3, :3] - r["T"][:3, :3]).max()), "dt", float(np.abs(T[:3, 3] - r["T"][:3, 3]).max()))
+print("fuzz done, mismatches:", bad)

@@ -45,10 +45,14 @@ void solve6(const double H[36], const double b[6], double x[6]) {
   }
   // Fast path.  JacobiSVD::solve returns the minimum-norm least-squares solution, which for a matrix
   // of full numerical rank IS H^-1 b.  Gaussian elimination with complete pivoting both computes that
-  // and certifies the rank: with every pivot above 1e-8 of the largest, no singular value can be
-  // anywhere near Eigen's rank threshold (6 eps s_max), so the SVD would have kept all six.  Anything
-  // less clear-cut (near-singular, rank-deficient, zero) takes the SVD below.  ~0.2 us against ~5 us,
-  // once per Newton iteration on the registration's serial path.
+  // and certifies the conditioning: it is used only when every pivot is above 1e-5 of the largest, so
+  // that (a) no singular value can be anywhere near Eigen's rank threshold (6 eps s_max) and (b) the
+  // elimination and the SVD agree to ~1e-10 relative -- on worse-conditioned Hessians (registrations
+  // started far off with DIRECT26, say) the two backward-stable answers differ by cond * eps, enough
+  // to send the line search down another path than the reference's, so those take the SVD below, as
+  // do rank-deficient and zero matrices.  ~0.2 us against ~5 us, once per Newton iteration on the
+  // registration's serial path.
+  constexpr double kPivotFloor = 1e-5;
   {
     double m[6][7];
     for (int r = 0; r < 6; r++) {
@@ -70,7 +74,7 @@ void solve6(const double H[36], const double b[6], double x[6]) {
           }
       p_max = std::max(p_max, best);
       p_min = std::min(p_min, best);
-      if (!(best > 1e-8 * p_max) || !(best > std::numeric_limits<double>::min())) {
+      if (!(best > kPivotFloor * p_max) || !(best > std::numeric_limits<double>::min())) {
         ok = false;
         break;
       }
@@ -87,7 +91,7 @@ void solve6(const double H[36], const double b[6], double x[6]) {
         for (int c = k + 1; c < 7; c++) m[r][c] -= f * m[k][c];
       }
     }
-    if (ok && p_min > 1e-8 * p_max) {
+    if (ok && p_min > kPivotFloor * p_max) {
       double y[6];
       for (int k = 5; k >= 0; k--) {
         double acc = m[k][6];
