@@ -1,0 +1,107 @@
+"""Randomised check of the target voxel grid (K1), the VoxelGrid prefilter (N1) and the map update (N2)
+against the oracle (development aid): random cloud shapes (uniform, clusters with thousands of points
+per voxel, thin sheets, big offsets), NaN points, resolutions, min_points_per_voxel, eigenvalue ratios,
+input strides.   fuzz_grid.py [seed] [cases]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle as po  # noqa: E402
+from toyslam_amd import clouds, ndt  # noqa: E402
+
+
+def cloud(rng, n, extent):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        c = rng.uniform(-extent, extent, (n, 3))
+    elif kind == 1:
+        ctr = rng.uniform(-extent, extent, (max(1, n // 3000), 3))
+        c = ctr[rng.integers(0, len(ctr), n)] + rng.normal(0, extent * 0.003, (n, 3))
+    elif kind == 2:
+        c = rng.uniform(-extent, extent, (n, 3)) * [1, 1, 1e-4]
+    else:  # a line: degenerate covariances
+        c = np.outer(rng.uniform(-extent, extent, n), [1.0, 0.5, 0.1]) + rng.normal(0, 1e-5, (n, 3))
+    return (c + rng.uniform(-3000, 3000, 3) * (rng.random() < 0.3)).astype(np.float32)
+
+
+def main():
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    bad = 0
+    for case in range(n_cases):
+        n = int(rng.integers(1, 60000))
+        extent = float(rng.choice([1.0, 15.0, 120.0]))
+        c = cloud(rng, n, extent)
+        dense = True
+        if rng.random() < 0.3:
+            c[rng.choice(n, min(4, n), replace=False), int(rng.integers(0, 3))] = np.nan
+            dense = False
+        cols = int(rng.choice([3, 4, 8]))
+        wide = np.zeros((n, cols), np.float32)
+        wide[:, :3] = c
+        res = float(rng.choice([0.1, 0.5, 1.0, 4.0])) * max(extent / 30.0, 0.05)
+        min_pts = int(rng.choice([3, 6, 10]))
+        eig = float(rng.choice([0.01, 0.1, 1e-4]))
+        # ---- K1
+        g = ndt.NormalDistributionsTransform()
+        g.setResolution(res)
+        g.setMinPointPerVoxel(min_pts)
+        g.setCovEigValueInflationRatio(eig)
+        o = po.OracleNDT(resolution=res, min_points_per_voxel=min_pts, eig_ratio=eig)
+        try:
+            g.setInputTarget(wide, is_dense=dense)
+            gpu_overflow = False
+        except ndt.NdtError:
+            gpu_overflow = True
+        ov = o.set_target(c, is_dense=dense)
+        why = None
+        if gpu_overflow != bool(ov):
+            why = "overflow flag"
+        elif not gpu_overflow:
+            a, b = g.grid(), o.grid()
+            if not (np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["n"], b["n"])):
+                why = "indices / counts"
+            elif not np.array_equal(a["mean"], b["mean"]):
+                why = "means not bit-exact (max %.3g)" % np.abs(a["mean"] - b["mean"]).max()
+            else:
+                ok = b["n"] >= min_pts
+                for k in ("cov", "icov", "evals"):
+                    x, y = a[k][ok], b[k][ok]
+                    fin = np.isfinite(y)
+                    if not np.array_equal(fin, np.isfinite(x)):
+                        why = k + " finiteness"
+                    elif fin.any():
+                        scale = np.abs(y[fin]).max()
+                        if np.abs(x[fin] - y[fin]).max() > 1e-8 * scale:
+                            why = "%s differs (rel %.3g)" % (k, np.abs(x[fin] - y[fin]).max() / scale)
+        if why:
+            bad += 1
+            print("MISMATCH K1 case", case, "n", n, "extent", extent, "res", res, "min_pts", min_pts, "eig", eig, "dense", dense, ":", why)
+        # ---- N1 / N2
+        leaf = float(rng.choice([0.05, 0.3, 1.0])) * max(extent / 30.0, 0.05)
+        ref, ov = po.voxel_grid_filter(c, leaf, is_dense=dense)
+        try:
+            got = g.voxelGridFilter(wide, leaf, is_dense=dense)
+            gov = False
+        except ndt.NdtError:
+            gov = True
+        if gov != ov or (not gov and not np.array_equal(got, ref)):
+            bad += 1
+            print("MISMATCH N1 case", case, "n", n, "leaf", leaf, "overflow gpu/oracle", gov, ov)
+        if not ov and dense:
+            T = clouds.random_T(rng, extent * 0.05, 10.0).astype(np.float32)
+            g.mapClear()
+            g.mapUpdate(wide, None, leaf)
+            nm, mov = g.mapUpdate(wide[: max(1, n // 2)], T, leaf)
+            moved = po.transform_cloud(np.c_[c[: max(1, n // 2)], np.ones(max(1, n // 2), np.float32)], T)[:, :3]
+            ref2, ov2 = po.voxel_grid_filter(np.concatenate([ref, moved]), leaf)
+            if mov != ov2 or (not mov and not np.array_equal(g.mapGet(), ref2)):
+                bad += 1
+                print("MISMATCH N2 case", case, "n", n, "leaf", leaf, mov, ov2)
+    print("grid fuzz done, mismatches:", bad)
+
+
+if __name__ == "__main__":
+    main()

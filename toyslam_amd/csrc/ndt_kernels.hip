@@ -319,6 +319,7 @@ struct Sym3 {
 // Eigen::SelfAdjointEigenSolver<Matrix3d> (_impl.hpp:275,333-335): only the
 // eigenvalues and V*diag*V^-1 are consumed, both solver-independent to O(eps).
 __device__ void eig3_jacobi(const double A_in[3][3], double w[3], double V[3][3]) {
+#pragma clang fp contract(off)
   double A[3][3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
@@ -377,6 +378,7 @@ __device__ void eig3_jacobi(const double A_in[3][3], double w[3], double V[3][3]
 
 // Matrix3d::inverse() as Eigen evaluates it (cofactors, multiply by 1/det)
 __device__ void inv3_cofactor(const double a[3][3], double r[3][3]) {
+#pragma clang fp contract(off)
   auto cof = [&](int i, int j) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     return a[i1][j1] * a[i2][j2] - a[i1][j2] * a[i2][j1];
@@ -476,6 +478,12 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
                                                      VoxelRec* __restrict__ recs, int* __restrict__ lut,
                                                      unsigned* __restrict__ n_valid, FinalizeDump dump) {
+  // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
+  // covariance formula (_impl.hpp:329-330) cancels catastrophically when the coordinates are large
+  // against the voxel size (sum of squares ~ n x^2 against a spread of millimetres), so a single fused
+  // multiply-add in the sums shows up in the 7th digit of cov / icov.  With it off, the f64 sums and
+  // the covariance are bit-identical to the reference's sequential pass.
+#pragma clang fp contract(off)
   const int o = blockIdx.x * kBlock + threadIdx.x;
   const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
   if (o >= n_leaves) return;
