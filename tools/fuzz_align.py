@@ -29,6 +29,21 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     g.setTransformationEpsilon(kw["trans_eps"]); g.setMaximumIterations(kw["max_iter"])
     g.setInputTarget(tt, is_dense=dense_t); o.set_target(tt, is_dense=dense_t)
     g.setInputSource(ss); o.set_source(ss)
+    # per-evaluation agreement at the start pose: sums, neighbour counts, f64 Hessian, calculateScore
+    p0 = np.zeros(6) if guess is None else ndt.host_matrix_to_pose(guess)
+    rg, ro = g.eval(p0, True), o.eval(p0, True)
+    def rel(a, b):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    ev_bad = rg[3] != ro[3] or rel(rg[0], ro[0]) > 2e-6 or rel(rg[1], ro[1]) > 2e-6 or rel(rg[2], ro[2]) > 2e-6
+    hg, ho = g.hessian_f64(p0), o.hessian_f64(p0)
+    ev_bad = ev_bad or (np.isfinite(ho).all() and rel(hg, ho) > 2e-6) or (np.isfinite(hg).all() != np.isfinite(ho).all())
+    fin = ss[np.isfinite(ss).all(axis=1)]
+    cg, co = g.calculateScore(fin), o.calculate_score(fin)
+    ev_bad = ev_bad or not (cg == co or abs(cg - co) <= 1e-6 * abs(co) or (cg != cg and co != co))
+    if ev_bad:
+        bad += 1
+        print("EVAL MISMATCH case", case, kw, "nn", rg[3], ro[3], "score", rel(rg[0], ro[0]), "g", rel(rg[1], ro[1]), "H", rel(rg[2], ro[2]), "h64", rel(hg, ho), "calc", cg, co)
     g.align(guess); r = o.align(guess)
     T = g.getFinalTransformation()
     ok_T = np.abs(T[:3, :3] - r["T"][:3, :3]).max() < 1e-4 and np.abs(T[:3, 3] - r["T"][:3, 3]).max() < 1e-3
