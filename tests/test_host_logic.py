@@ -103,7 +103,7 @@ def test_matrix_to_pose(ndt):
         T = po.pose_to_matrix(p)
         q = ndt.host_matrix_to_pose(T)
         qo = np.r_[T[:3, 3].astype(np.float64), po.euler_from_matrix(T).astype(np.float64)]
-        assert np.allclose(q, qo, atol=2e-6)
+        assert np.array_equal(q, qo)  # same neutral choice for rotation(): the correctly rounded polar factor
         # Eigen's eulerAngles(0,1,2) returns roll in [0, pi]; the pose must map back to the same matrix
         assert -1e-6 <= q[3] <= np.pi + 1e-6
         assert np.abs(ndt.host_pose_to_matrix(q) - T).max() < 5e-6
@@ -198,3 +198,38 @@ def test_driver_state_machine_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "5000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "no crash" in out.stdout
+
+
+def test_product_driver_equals_oracle_driver_randomised(ndt, pair):
+    """tools/fuzz_driver.py, short: random resolutions, search methods, step sizes, outlier ratios, stopping
+    rules (incl. epsilon 0 = forced passes), cloud subsets and far guesses -- the product driver fed the
+    oracle's evaluations reproduces the oracle's registration bit for bit, evaluation for evaluation."""
+    from toyslam_amd import clouds
+    t, s = pair
+    rng = np.random.default_rng(5)
+    for case in range(25):
+        kw = dict(resolution=float(rng.choice([0.5, 1.0, 2.0, 3.0])), search_method=int(rng.choice([po.KDTREE, po.DIRECT26, po.DIRECT7, po.DIRECT1])),
+                  step_size=float(rng.choice([0.05, 0.1, 0.3])), outlier_ratio=float(rng.choice([0.3, 0.55, 0.8])),
+                  trans_eps=float(rng.choice([0.1, 0.01, 1e-3, 1e-9, 0.0])), max_iter=int(rng.choice([0, 3, 12, 35])))
+        tt = t[rng.choice(len(t), int(rng.integers(1500, 6000)), replace=False)]
+        ss = s[rng.choice(len(s), int(rng.integers(30, 2000)), replace=False)]
+        guess = None if rng.random() < 0.4 else clouds.random_T(rng, 0.4, 3.0).astype(np.float32)
+        o = po.OracleNDT(num_threads=4, **kw)
+        o.set_target(tt)
+        o.set_source(ss)
+        ref = o.align(guess)
+        s4 = np.c_[ss, np.ones(len(ss), np.float32)]
+
+        def evaluator(kind, T, p):
+            tc = po.transform_cloud(s4, T)
+            if kind == 2:
+                o.eval(p, False, tc)
+                return 0.0, np.zeros(6), o.hessian_f64(p)
+            sc, g, H, _ = o.eval(p, kind == 0, tc)
+            return sc, g, H
+
+        got = ndt.host_run_driver(evaluator, len(ss), guess=guess, resolution=kw["resolution"], step_size=kw["step_size"],
+                                  outlier_ratio=kw["outlier_ratio"], trans_eps=kw["trans_eps"], max_iter=kw["max_iter"])
+        for k in ("converged", "iterations", "n_evals", "n_hessian_recomputes"):
+            assert got[k] == ref[k], (case, k)
+        assert np.array_equal(got["T"], ref["T"]), case

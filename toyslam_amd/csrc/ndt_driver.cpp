@@ -201,49 +201,37 @@ void pose_to_matrix(const double p[6], float T[16]) {
 // part (Eigen Transform.h computeRotationScaling, f32 JacobiSVD); then
 // MatrixBase::eulerAngles(0,1,2) (Eigen 3.3.7 EulerAngles.h).
 void matrix_to_pose(const float T[16], double p[6]) {
-  // f32 one-sided Jacobi on the 3x3 linear part
-  float a[3][3], v[3][3];  // columns
-  for (int c = 0; c < 3; c++)
-    for (int r = 0; r < 3; r++) {
-      a[c][r] = T[c * 4 + r];
-      v[c][r] = (r == c) ? 1.f : 0.f;
-    }
-  for (int sweep = 0; sweep < 30; sweep++) {
-    int n_rot = 0;
-    for (int i = 0; i < 2; i++)
-      for (int j = i + 1; j < 3; j++) {
-        float aii = 0, ajj = 0, aij = 0;
-        for (int k = 0; k < 3; k++) {
-          aii += a[i][k] * a[i][k];
-          ajj += a[j][k] * a[j][k];
-          aij += a[i][k] * a[j][k];
-        }
-        if (aij == 0.f || std::fabs(aij) <= 2.0f * std::numeric_limits<float>::epsilon() * std::sqrt(aii * ajj)) continue;
-        n_rot++;
-        const float tau = (ajj - aii) / (2.0f * aij);
-        const float t = std::copysign(1.0f, tau) / (std::fabs(tau) + std::sqrt(1.0f + tau * tau));
-        const float cs = 1.0f / std::sqrt(1.0f + t * t), sn = cs * t;
-        for (int k = 0; k < 3; k++) {
-          const float ai = a[i][k], aj = a[j][k];
-          a[i][k] = cs * ai - sn * aj;
-          a[j][k] = sn * ai + cs * aj;
-          const float vi = v[i][k], vj = v[j][k];
-          v[i][k] = cs * vi - sn * vj;
-          v[j][k] = sn * vi + cs * vj;
-        }
+  // rotation(): the orthogonal polar factor of the linear part.  Eigen gets it from an f32 JacobiSVD
+  // (U V^T), i.e. the exact factor plus a few ulps of that solver's own rounding noise, which cannot be
+  // restated without Eigen.  The neutral choice is the correctly rounded factor: Newton's polar
+  // iteration X <- (X + X^-T) / 2 in f64 (quadratically convergent, exact fixed point for an
+  // orthonormal input such as Identity), rounded to f32.
+  double X[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) X[r][c] = T[c * 4 + r];
+  for (int it = 0; it < 30; it++) {
+    const double c00 = X[1][1] * X[2][2] - X[1][2] * X[2][1], c01 = X[1][2] * X[2][0] - X[1][0] * X[2][2],
+                 c02 = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+    const double det = (X[0][0] * c00 + X[0][1] * c01) + X[0][2] * c02;
+    if (!(std::fabs(det) > 0.0)) break;  // singular linear part: leave it as it is
+    const double inv = 1.0 / det;
+    // cofactor matrix / det = X^-T
+    const double XiT[3][3] = {
+        {c00 * inv, c01 * inv, c02 * inv},
+        {(X[0][2] * X[2][1] - X[0][1] * X[2][2]) * inv, (X[0][0] * X[2][2] - X[0][2] * X[2][0]) * inv, (X[0][1] * X[2][0] - X[0][0] * X[2][1]) * inv},
+        {(X[0][1] * X[1][2] - X[0][2] * X[1][1]) * inv, (X[0][2] * X[1][0] - X[0][0] * X[1][2]) * inv, (X[0][0] * X[1][1] - X[0][1] * X[1][0]) * inv}};
+    double diff = 0.0;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        const double y = 0.5 * (X[r][c] + XiT[r][c]);
+        diff = std::max(diff, std::fabs(y - X[r][c]));
+        X[r][c] = y;
       }
-    if (!n_rot) break;
+    if (diff < 1e-15) break;
   }
   float R[3][3];
-  {
-    float u[3][3];
-    for (int j = 0; j < 3; j++) {
-      float nrm = std::sqrt(a[j][0] * a[j][0] + a[j][1] * a[j][1] + a[j][2] * a[j][2]);
-      for (int k = 0; k < 3; k++) u[j][k] = nrm > 0 ? a[j][k] / nrm : v[j][k];
-    }
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) R[r][c] = (u[0][r] * v[0][c] + u[1][r] * v[1][c]) + u[2][r] * v[2][c];
-  }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) R[r][c] = static_cast<float>(X[r][c]);
   // eulerAngles(0,1,2): odd = 0, i = 0, j = 1, k = 2
   const float pi_f = static_cast<float>(3.141592653589793238462643383279502884L);
   float e0 = std::atan2(R[1][2], R[2][2]), e1;
