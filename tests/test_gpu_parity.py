@@ -181,6 +181,25 @@ def test_eval_with_guess_matrix(mods, pair):
     assert sg == pytest.approx(so, rel=1e-6) and close_sums(gg, go) and close_sums(Hg, Ho)
 
 
+def test_calculate_score_with_non_finite_points(mods, pair):
+    """NaN / inf / absurdly far points have no neighbourhood in the reference and add nothing."""
+    ndt, po, _ = mods
+    t, s = pair
+    c = s[:2000].copy()
+    c[5] = np.nan
+    c[7, 1] = np.inf
+    c[9] = 1e30
+    for m in (po.DIRECT7, po.KDTREE, po.DIRECT26, po.DIRECT1):
+        g = ndt.NormalDistributionsTransform()
+        g.setNeighborhoodSearchMethod(m)
+        g.setInputTarget(t)
+        g.setInputSource(s[:10])
+        o = po.OracleNDT(search_method=m)
+        o.set_target(t)
+        o.set_source(s[:10])
+        assert g.calculateScore(c) == pytest.approx(o.calculate_score(c), rel=1e-6)
+
+
 def test_calculate_score(mods, pair, golden):
     ndt, po, _ = mods
     t, s = pair

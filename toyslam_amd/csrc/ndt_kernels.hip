@@ -913,6 +913,7 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
   double acc[1] = {0.0};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 pt = cloud[i];
+    if (!finite3(pt.x, pt.y, pt.z)) continue;  // no neighbourhood in the reference (garbage voxel index): adds nothing
     int vi, vj, vk;
     search_ijk(gv.g, pt.x, pt.y, pt.z, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
