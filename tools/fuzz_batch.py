@@ -1,0 +1,53 @@
+"""Randomised check of the lock-step batch (development aid): random batches of ragged scans (empty, tiny,
+NaN points, far away, large), random guesses, every search mode -- each member must get the registration
+it gets alone (same iteration count, transform equal to rounding).   fuzz_batch.py [seed] [cases]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toyslam_amd import clouds, ndt  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    world = clouds.target_surfaces(300000, extent=50.0, n_boxes=30)
+    bad = members = 0
+    for case in range(n_cases):
+        tt = world[rng.choice(len(world), int(rng.integers(3000, 150000)), replace=False)]
+        g = ndt.NormalDistributionsTransform()
+        g.setResolution(float(rng.choice([0.5, 1.0, 2.0])))
+        g.setNeighborhoodSearchMethod(int(rng.choice([ndt.KDTREE, ndt.DIRECT26, ndt.DIRECT7, ndt.DIRECT1])))
+        g.setTransformationEpsilon(float(rng.choice([0.1, 0.01, 1e-3])))
+        g.setMaximumIterations(int(rng.choice([3, 15, 35])))
+        g.setInputTarget(tt)
+        scans, guesses = [], []
+        for k in range(int(rng.integers(1, 12))):
+            kind = rng.integers(0, 6)
+            n = 0 if kind == 0 else int(rng.integers(1, 20)) if kind == 1 else int(rng.integers(20, 30000))
+            sc = clouds.apply_T(np.linalg.inv(clouds.random_T(rng, 0.4, 2.0)), world[rng.choice(len(world), n, replace=False)]) if n else np.zeros((0, 3), np.float32)
+            if kind == 2 and n > 10:
+                sc[rng.choice(n, 3, replace=False)] = np.nan
+            if kind == 3:
+                sc = (sc + 1000.0).astype(np.float32)
+            scans.append(sc.astype(np.float32))
+            guesses.append(np.eye(4, dtype=np.float32) if rng.random() < 0.5 else clouds.random_T(rng, 0.2, 1.0).astype(np.float32))
+        res = g.alignBatch(scans, guesses)
+        for k, sc in enumerate(scans):
+            g.setInputSource(sc)
+            g.align(guesses[k])
+            T = g.getFinalTransformation()
+            members += 1
+            same = (np.abs(res["T"][k] - T).max() < 2e-5 and res["iterations"][k] == g.getFinalNumIteration() and
+                    bool(res["converged"][k]) == g.hasConverged())
+            if not same:
+                bad += 1
+                print("MISMATCH case", case, "member", k, "n", len(sc), "it", res["iterations"][k], g.getFinalNumIteration(), "dT",
+                      float(np.nanmax(np.abs(res["T"][k] - T))))
+    print("batch fuzz: %d members, %d mismatches" % (members, bad))
+
+
+if __name__ == "__main__":
+    main()
