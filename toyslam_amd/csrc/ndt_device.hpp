@@ -185,6 +185,17 @@ constexpr int kLutRejected = 0x40000000;  // LUT flag: voxel has a record but nr
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
+// XCD-aware work assignment for the latency kernels.  Workgroups are dispatched round-robin over the 8
+// XCDs (block b runs on XCD b % 8), each XCD has its own L2, and the source scan is in lattice-cell
+// order: giving XCD x the x-th contiguous eighth of the scan keeps every L2 working on one compact
+// region of the target's voxel records instead of all eight caching the whole map.  Returns the chunk
+// (of `TPB` consecutive points) that block b of nb works on; a permutation of 0..nb-1 whatever the
+// real block -> XCD placement is, so only speed depends on it.
+__device__ __forceinline__ int xcd_chunk(int b, int nb) {
+  const int x = b & 7, q = nb >> 3, r = nb & 7;
+  return x * q + min(x, r) + (b >> 3);
+}
+
 // ---------------------------------------------------------------------------
 // K2  derivatives
 // ---------------------------------------------------------------------------

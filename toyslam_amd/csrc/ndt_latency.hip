@@ -45,8 +45,10 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, blockIdx.x * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  // XCD-aware first tile (see xcd_chunk); larger scans continue grid-strided, which balances uneven
+  // neighbour counts better than one contiguous range per block (measured: -8 % at 2M points)
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x, gridDim.x * TPB, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
@@ -288,19 +290,21 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
     double acc[kNumAcc];
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    const int first = blockIdx.x * kServerTPB + tid, stride = gridDim.x * kServerTPB;
+    // XCD-aware first tile (see xcd_chunk); larger scans continue grid-strided (better balance)
+    const int first = xcd_chunk(blockIdx.x, gridDim.x) * kServerTPB + tid, stride = gridDim.x * kServerTPB;
+    const int limit = n;
     if (kind == 2) {
       // rare round (at most one per Newton iteration): keep its loop invariants from being hoisted
       // into registers the hot rounds need (the opaque copy of `first` pins them inside the branch)
       int first64 = first;
       asm volatile("" : "+v"(first64));
-      hessian64_body<NNB, true>(src, n, gv, sP64, first64, stride, acc);
+      hessian64_body<NNB, true>(src, limit, gv, sP64, first64, stride, acc);
     } else if (NNB == 27) {
-      if (kind == 0) derivatives_body_kd<true>(src, n, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body_kd<false>(src, n, gv, sP, first, stride, acc);
+      if (kind == 0) derivatives_body_kd<true>(src, limit, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body_kd<false>(src, limit, gv, sP, first, stride, acc);
     } else {
-      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, n, gv, sP, first, stride, acc);
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, limit, gv, sP, first, stride, acc);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, limit, gv, sP, first, stride, acc);
     }
     if (fine && tid == 0) fine[1] = __builtin_amdgcn_s_memrealtime();
     const double tot = wave_fold<kNumAcc>(acc);
