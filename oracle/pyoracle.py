@@ -16,7 +16,8 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("ndt_oracle.cpp", "oracle_capi.cpp", "ndt_oracle.hpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ndt_oracle.cpp", "oracle_capi.cpp", "ndt_oracle.hpp", "gicp_oracle.cpp", "gicp_oracle_capi.cpp",
+                                           "gicp_oracle.hpp", "Makefile")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
@@ -57,6 +58,18 @@ def lib():
         L.oracle_transform_cloud.argtypes = [fp, C.c_size_t, fp, fp]
         L.oracle_voxel_grid_filter.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, fp, ip]
         L.oracle_voxel_grid_filter.restype = C.c_size_t
+        L.gicp_oracle_create.restype = vp
+        L.gicp_oracle_destroy.argtypes = [vp]
+        L.gicp_oracle_set_params.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.gicp_oracle_set_target.argtypes = [vp, fp, C.c_size_t, C.c_size_t]
+        L.gicp_oracle_set_source.argtypes = [vp, fp, C.c_size_t, C.c_size_t]
+        L.gicp_oracle_covariances.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, dp]
+        L.gicp_oracle_knn.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, ip, fp]
+        L.gicp_oracle_align.argtypes = [vp, fp, fp, ip, ip, fp]
+        L.gicp_oracle_prepare.argtypes = [vp, fp]
+        L.gicp_oracle_correspond.argtypes = [vp, fp, ip, fp]
+        L.gicp_oracle_functor.argtypes = [vp, C.c_int, dp, dp, dp]
+        L.gicp_oracle_apply_state.argtypes = [dp, fp]
         _lib = L
     return _lib
 
@@ -233,3 +246,85 @@ def voxel_grid_filter(pts, leaf, is_dense=True):
     ov = C.c_int(0)
     n = lib().oracle_voxel_grid_filter(_f(a), a.shape[0], a.shape[1], int(is_dense), float(leaf), _f(out), C.byref(ov))
     return out[:n, :3].copy(), bool(ov.value)
+
+
+class OracleGICP:
+    """oracle::GICP (pclomp::GeneralizedIterativeClosestPoint restated on the CPU)."""
+
+    def __init__(self, k=20, gicp_epsilon=1e-3, rotation_epsilon=2e-3, transformation_epsilon=5e-4,
+                 corr_dist_threshold=5.0, max_iterations=200, max_inner_iterations=20):
+        self._L = lib()
+        self._h = self._L.gicp_oracle_create()
+        self._L.gicp_oracle_set_params(self._h, k, gicp_epsilon, rotation_epsilon, transformation_epsilon,
+                                       corr_dist_threshold, max_iterations, max_inner_iterations)
+        self.k, self.eps = k, gicp_epsilon
+        self.ns = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.gicp_oracle_destroy(self._h)
+            self._h = None
+
+    def setInputTarget(self, pts):
+        pts = _xyz(pts)
+        self._L.gicp_oracle_set_target(self._h, _f(pts), pts.shape[0], pts.shape[1])
+
+    def setInputSource(self, pts):
+        pts = _xyz(pts)
+        self.ns = pts.shape[0]
+        self._L.gicp_oracle_set_source(self._h, _f(pts), pts.shape[0], pts.shape[1])
+
+    def align(self, guess=None, want_cloud=False):
+        g = None if guess is None else np.asfortranarray(guess, dtype=np.float32)
+        T = np.zeros((4, 4), dtype=np.float32, order="F")
+        conv = C.c_int(0)
+        stats = np.zeros(5, dtype=np.int32)
+        out = np.zeros((self.ns, 4), dtype=np.float32) if want_cloud else None
+        self._L.gicp_oracle_align(self._h, None if g is None else _f(g), _f(T), C.byref(conv), _i(stats),
+                                  None if out is None else _f(out))
+        res = {"T": np.array(T), "converged": bool(conv.value), "iterations": int(stats[0]), "n_f": int(stats[1]),
+               "n_df": int(stats[2]), "n_fdf": int(stats[3]), "correspondences": int(stats[4])}
+        if want_cloud:
+            res["cloud"] = out
+        return res
+
+    def prepare(self, guess=None):
+        g = np.asfortranarray(np.eye(4) if guess is None else guess, dtype=np.float32)
+        return bool(self._L.gicp_oracle_prepare(self._h, _f(g)))
+
+    def correspond(self, transformation):
+        t = np.asfortranarray(transformation, dtype=np.float32)
+        idx = np.zeros(self.ns, dtype=np.int32)
+        maha = np.zeros((self.ns, 9), dtype=np.float32)
+        m = self._L.gicp_oracle_correspond(self._h, _f(t), _i(idx), _f(maha))
+        return m, idx, maha
+
+    def functor(self, mode, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        f = C.c_double(0.0)
+        g = np.zeros(6)
+        self._L.gicp_oracle_functor(self._h, mode, _d(x), C.byref(f), _d(g))
+        return f.value, g
+
+
+def gicp_covariances(pts, k=20, eps=1e-3):
+    pts = _xyz(pts)
+    out = np.zeros((pts.shape[0], 3, 3))
+    ok = lib().gicp_oracle_covariances(_f(pts), pts.shape[0], pts.shape[1], k, eps, _d(out))
+    return out if ok else None
+
+
+def gicp_knn(cloud, query, k):
+    cloud = np.ascontiguousarray(np.c_[_xyz(cloud)[:, :3], np.ones(len(cloud), np.float32)], dtype=np.float32)
+    query = np.ascontiguousarray(np.c_[_xyz(query)[:, :3], np.ones(len(query), np.float32)], dtype=np.float32)
+    idx = np.zeros((len(query), k), dtype=np.int32)
+    d2 = np.zeros((len(query), k), dtype=np.float32)
+    lib().gicp_oracle_knn(_f(cloud), len(cloud), _f(query), len(query), k, _i(idx), _f(d2))
+    return idx, d2
+
+
+def gicp_apply_state(x):
+    T = np.zeros((4, 4), dtype=np.float32, order="F")
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib().gicp_oracle_apply_state(_d(x), _f(T))
+    return np.array(T)

@@ -102,6 +102,25 @@ SIGNATURES = {
     "ndt_host_gauss": (None, [C.c_float, C.c_double, dp]),
     "ndt_host_run_driver": (C.c_int, [EVAL_CB, vp, C.c_size_t, fp, C.c_float, C.c_double, C.c_double, C.c_double,
                                       C.c_int, fp, ip, ip, dp, ip, ip]),
+    # GICP row (include/gicp_mi355.h)
+    "gicp_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "gicp_destroy": (None, [vp]),
+    "gicp_set_correspondence_randomness": (C.c_int, [vp, C.c_int]),
+    "gicp_set_rotation_epsilon": (C.c_int, [vp, C.c_double]),
+    "gicp_set_maximum_optimizer_iterations": (C.c_int, [vp, C.c_int]),
+    "gicp_set_transformation_epsilon": (C.c_int, [vp, C.c_double]),
+    "gicp_set_maximum_iterations": (C.c_int, [vp, C.c_int]),
+    "gicp_set_max_correspondence_distance": (C.c_int, [vp, C.c_double]),
+    "gicp_set_input_target": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "gicp_set_input_source": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "gicp_align": (C.c_int, [vp, fp, fp, ip, ip, vp]),
+    "gicp_get_result": (C.c_int, [vp, fp, ip, ip]),
+    "gicp_get_fitness_score": (C.c_int, [vp, C.c_double, dp]),
+    "gicp_get_stats": (C.c_int, [vp, ip, ip, ip, ip]),
+    "gicp_covariances": (C.c_int, [vp, C.c_int, dp, ip, fp]),
+    "gicp_step_correspond": (C.c_int, [vp, fp, fp, ip, fp, ip]),
+    "gicp_step_functor": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+    "gicp_host_apply_state": (None, [dp, fp]),
 }
 
 

@@ -1,0 +1,466 @@
+// gicp_capi.inl -- C-ABI glue of the GICP row (include/gicp_mi355.h).  Textually part of ndt_capi.hip
+// (included at its end): it reuses that unit's device pool, cloud upload and K1 grid build -- the
+// voxel index K1 produces over a cloud is the search structure of GICP's nearest-neighbour queries.
+//
+// A gicp_context owns two ndt_contexts used purely as index holders: `tgt` (the GICP target as its
+// target cloud + grid) and `src` (the GICP *source* as ITS target cloud + grid, for the source's own
+// k-NN covariances).  All GICP kernels run on tgt's stream.
+
+namespace {
+
+struct GicpDevice;
+
+}  // namespace
+
+struct gicp_context {
+  ndt_context tgt, src;
+  gicp::Params prm;
+  bool have_tgt = false, have_src = false;
+  bool have_cov_tgt = false, have_cov_src = false;
+  DevBuf<double> cov_tgt, cov_src;  // [n][6]
+  DevBuf<float4> output;            // the source moved by the guess
+  DevBuf<int> corr;
+  DevBuf<float> maha;
+  DevBuf<double> partials;
+  DevBuf<unsigned> counter;
+  DevBuf<float4> out_cloud;
+  DevBuf<int> nn_idx;
+  DevBuf<float> nn_d2;
+  double* host_pub = nullptr;  // pinned tagged publication row
+  unsigned long long seq = 0;
+  float guess_rm[16];          // guess of the current align / step, row-major
+  bool step_ready = false;
+  // results
+  float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // column-major
+  int converged = 0, nr_iterations = 0, n_f = 0, n_df = 0, n_fdf = 0, correspondences = 0;
+
+  ~gicp_context() {
+    if (tgt.device_ready) {
+      (void)hipSetDevice(tgt.device);
+      (void)hipStreamSynchronize(tgt.stream);
+      tls_pool_stream = tgt.stream;
+    }
+    cov_tgt.release(); cov_src.release(); output.release(); corr.release(); maha.release(); partials.release();
+    counter.release(); out_cloud.release(); nn_idx.release(); nn_d2.release();
+    if (host_pub) (void)hipHostFree(host_pub);
+  }
+};
+
+namespace {
+
+constexpr double kGicpPointsPerCell = 6.0;           // what the index leaf size aims for
+constexpr long long kGicpMaxCells = 1ll << 26;       // dense cell table budget (256 MB of int)
+
+// Builds the voxel index of a host cloud on `c`: finite check, upload, leaf size from the cloud's own
+// density (volume guess first, then corrected once from the measured points per occupied cell --
+// scans are surfaces, so occupancy grows with the square of the leaf).
+ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t stride) {
+  if (!pts || n == 0) return fail(NDT_ERR_INVALID, "invalid or empty point cloud dataset given");
+  if (stride < 12 || stride % 4) return fail(NDT_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  const unsigned char* base = static_cast<const unsigned char*>(pts);
+  for (size_t i = 0; i < n; i++) {
+    float p[3];
+    std::memcpy(p, base + i * stride, sizeof(p));
+    if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])))
+      return fail(NDT_ERR_INVALID, "GICP needs finite points (point " + std::to_string(i) + " is not)");
+    for (int k = 0; k < 3; k++) {
+      mn[k] = std::min(mn[k], static_cast<double>(p[k]));
+      mx[k] = std::max(mx[k], static_cast<double>(p[k]));
+    }
+  }
+  ndt_status s = ensure_device(c);
+  if (s) return s;
+  c->target_dense = 1;
+  c->min_pts = 1;
+  s = upload_cloud(c, pts, n, stride, false, c->target);
+  if (s) return s;
+  double ext[3], vol = 1.0, ext_max = 0.0;
+  for (int k = 0; k < 3; k++) {
+    ext[k] = std::max(mx[k] - mn[k], 1e-3);
+    vol *= ext[k];
+    ext_max = std::max(ext_max, ext[k]);
+  }
+  auto clamp_leaf = [&](double leaf) {
+    leaf = std::max(leaf, 1e-4);
+    for (int it = 0; it < 64; it++) {  // keep the dense cell table within budget
+      const double cells = (ext[0] / leaf + 2) * (ext[1] / leaf + 2) * (ext[2] / leaf + 2);
+      if (cells <= static_cast<double>(kGicpMaxCells)) break;
+      leaf *= 1.26;
+    }
+    return static_cast<float>(leaf);
+  };
+  float leaf = clamp_leaf(std::cbrt(vol * kGicpPointsPerCell / static_cast<double>(n)));
+  for (int pass = 0; pass < 3; pass++) {
+    c->resolution = leaf;
+    s = build_grid(c);
+    if (s) return s;
+    s = grid_counts(c, c->grid.get());
+    if (s) return s;
+    const double per_cell = static_cast<double>(n) / static_cast<double>(std::max<size_t>(c->grid->n_leaves, 1));
+    if (per_cell <= 2.0 * kGicpPointsPerCell) break;
+    const float next = clamp_leaf(static_cast<double>(leaf) * std::sqrt(kGicpPointsPerCell / per_cell));
+    if (!(next < 0.9f * leaf)) break;
+    leaf = next;
+  }
+  return ensure_cell2leaf(c, c->grid.get());
+}
+
+gicp::PointIndex gicp_index_of(const ndt_context* c) {
+  const DeviceGrid* g = c->grid.get();
+  gicp::PointIndex ix;
+  ix.pts = c->target->pts.p;
+  ix.n = static_cast<int>(c->target->n);
+  ix.geom = g->geom;
+  ix.cell2leaf = g->cell2leaf.p;
+  ix.leaf_start = g->leaf_start.p;
+  ix.leaf_count = g->leaf_count.p;
+  ix.sorted_idx = g->sorted_idx.p;
+  ix.n_sorted = static_cast<int>(g->n_sorted);
+  ix.slack = index_slack(g);
+  return ix;
+}
+
+void rowmajor_from_colmajor(const float* cm, float* rm) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) rm[r * 4 + c] = cm ? cm[c * 4 + r] : (r == c ? 1.0f : 0.0f);
+}
+void colmajor_from_rowmajor(const float* rm, float* cm) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) cm[c * 4 + r] = rm[r * 4 + c];
+}
+
+ndt_status gicp_ready(gicp_context* h) {
+  if (!h->have_tgt) return fail(NDT_ERR_NO_INPUT, "no target cloud set");
+  if (!h->have_src) return fail(NDT_ERR_NO_INPUT, "no source cloud set");
+  ndt_status s = ensure_device(&h->tgt);  // current device + this thread's pool stream
+  if (s) return s;
+  if (!h->host_pub) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_pub), ndt::kPublishSlots * sizeof(double), hipHostMallocDefault));
+    std::memset(h->host_pub, 0, ndt::kPublishSlots * sizeof(double));
+  }
+  if (!h->counter.p) {
+    HIP_TRY(h->counter.reserve(1));
+    HIP_TRY(hipMemsetAsync(h->counter.p, 0, sizeof(unsigned), h->tgt.stream));
+  }
+  return NDT_OK;
+}
+
+// computeCovariances of one cloud (lazily, gicp_omp_impl.hpp:385-397)
+ndt_status gicp_cloud_covariances(gicp_context* h, int which, bool want_neighbors) {
+  ndt_context* c = which == 0 ? &h->tgt : &h->src;
+  DevBuf<double>& cov = which == 0 ? h->cov_tgt : h->cov_src;
+  bool& have = which == 0 ? h->have_cov_tgt : h->have_cov_src;
+  if (have && !want_neighbors) return NDT_OK;
+  const size_t n = c->target->n;
+  const int k = h->prm.k_correspondences;
+  if (k > static_cast<int>(n))  // :53-57: PCL_ERROR and return, the covariances stay empty
+    return fail(NDT_ERR_INVALID, "number of points in cloud (" + std::to_string(n) + ") is less than k_correspondences_ (" +
+                                     std::to_string(k) + ")");
+  HIP_TRY(cov.reserve(n * 6));
+  if (want_neighbors) {
+    HIP_TRY(h->nn_idx.reserve(n * static_cast<size_t>(k)));
+    HIP_TRY(h->nn_d2.reserve(n * static_cast<size_t>(k)));
+  }
+  HIP_TRY(gicp::launch_knn_covariances(gicp_index_of(c), k, h->prm.gicp_epsilon, cov.p, want_neighbors ? h->nn_idx.p : nullptr,
+                                       want_neighbors ? h->nn_d2.p : nullptr, h->tgt.stream));
+  have = true;
+  return NDT_OK;
+}
+
+// covariances of both clouds + the guess-moved source (:385-403)
+ndt_status gicp_prepare(gicp_context* h, const float* guess_cm) {
+  ndt_status s = gicp_ready(h);
+  if (s) return s;
+  s = gicp_cloud_covariances(h, 0, false);
+  if (s) return s;
+  s = gicp_cloud_covariances(h, 1, false);
+  if (s) return s;
+  const size_t n = h->src.target->n;
+  rowmajor_from_colmajor(guess_cm, h->guess_rm);
+  HIP_TRY(h->output.reserve(n));
+  HIP_TRY(h->corr.reserve(n));
+  HIP_TRY(h->maha.reserve(n * 9));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(gicp::kFunctorMaxBlocks) * ndt::kEvalStride));
+  // pcl::transformPointCloud(output, output, guess), :403
+  HIP_TRY(ndt::launch_transform(h->src.target->pts.p, static_cast<int>(n), h->guess_rm, h->output.p, h->tgt.stream));
+  return NDT_OK;
+}
+
+struct GicpDevice : gicp::Backend {
+  gicp_context* h;
+  std::string error;
+  explicit GicpDevice(gicp_context* ctx) : h(ctx) {}
+
+  bool correspond(const float transformation[16], const double R[9]) override {
+    gicp::Rot3d rot;
+    for (int i = 0; i < 9; i++) rot.m[i] = R[i];
+    const double thr = h->prm.corr_dist_threshold * h->prm.corr_dist_threshold;  // :401
+    const hipError_t e = gicp::launch_correspond(h->output.p, static_cast<int>(h->src.target->n), transformation, rot,
+                                                 gicp_index_of(&h->tgt), h->cov_src.p, h->cov_tgt.p, thr, h->corr.p, h->maha.p,
+                                                 h->tgt.stream);
+    if (e != hipSuccess) {
+      error = std::string("correspondence kernel: ") + hipGetErrorString(e);
+      return false;
+    }
+    return true;
+  }
+
+  bool sums(int mode, const float T[16], gicp::FunctorSums& out) override {
+    const int n = static_cast<int>(h->src.target->n);
+    const unsigned long long seq = ++h->seq;
+    const hipError_t e = gicp::launch_functor(mode, h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, T,
+                                              gicp::functor_blocks(n), h->partials.p, h->counter.p, h->host_pub, seq, h->tgt.stream);
+    if (e != hipSuccess) {
+      error = std::string("functor kernel: ") + hipGetErrorString(e);
+      return false;
+    }
+    // the row arrives as 64 self-validating words; poll, and look at the stream now and then so that a
+    // failed launch cannot hang the caller
+    for (unsigned long long spins = 1; !pub_ready(h->host_pub, seq); spins++) {
+      if ((spins & 0xfffff) == 0) {
+        const hipError_t q = hipStreamQuery(h->tgt.stream);
+        if (q == hipSuccess) {
+          if (pub_ready(h->host_pub, seq)) break;
+          error = "functor kernel finished without publishing its result";
+          return false;
+        }
+        if (q != hipErrorNotReady) {
+          error = std::string("functor kernel: ") + hipGetErrorString(q);
+          return false;
+        }
+      }
+    }
+    double row[ndt::kEvalStride];
+    pub_gather(h->host_pub, row);
+    out.f = row[0];
+    for (int i = 0; i < 3; i++) out.g[i] = row[1 + i];
+    for (int i = 0; i < 9; i++) out.R[i] = row[4 + i];
+    out.m = row[13];
+    return true;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+ndt_status gicp_create(int device, gicp_handle* out) {
+  if (!out || device < 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  gicp_context* h = new gicp_context();
+  h->tgt.device = device;
+  h->src.device = device;
+  *out = h;
+  return NDT_OK;
+}
+
+void gicp_destroy(gicp_handle h) {
+  if (!h) return;
+  for (ndt_context* c : {&h->tgt, &h->src})
+    if (c->device_ready) {
+      (void)hipSetDevice(c->device);
+      (void)hipStreamSynchronize(c->stream);
+    }
+  delete h;
+}
+
+ndt_status gicp_set_correspondence_randomness(gicp_handle h, int k) {
+  if (!h || k < 1 || k > gicp::kMaxK) return fail(NDT_ERR_INVALID, "k_correspondences must be in [1, 64]");
+  if (k != h->prm.k_correspondences) h->have_cov_tgt = h->have_cov_src = false;
+  h->prm.k_correspondences = k;
+  return NDT_OK;
+}
+ndt_status gicp_set_rotation_epsilon(gicp_handle h, double eps) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->prm.rotation_epsilon = eps;
+  return NDT_OK;
+}
+ndt_status gicp_set_maximum_optimizer_iterations(gicp_handle h, int n) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->prm.max_inner_iterations = n;
+  return NDT_OK;
+}
+ndt_status gicp_set_transformation_epsilon(gicp_handle h, double eps) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->prm.transformation_epsilon = eps;
+  return NDT_OK;
+}
+ndt_status gicp_set_maximum_iterations(gicp_handle h, int n) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->prm.max_iterations = n;
+  return NDT_OK;
+}
+ndt_status gicp_set_max_correspondence_distance(gicp_handle h, double d) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->prm.corr_dist_threshold = d;
+  return NDT_OK;
+}
+
+ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_t stride_bytes) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->have_tgt = false;
+  h->have_cov_tgt = false;  // target_covariances_.reset()
+  h->step_ready = false;
+  if (h->tgt.device_ready) {  // kernels of an earlier align may still read the old index
+    HIP_TRY(hipSetDevice(h->tgt.device));
+    HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+  }
+  const ndt_status s = gicp_build_index(&h->tgt, pts, n, stride_bytes);
+  if (s) return s;
+  h->have_tgt = true;
+  return NDT_OK;
+}
+
+ndt_status gicp_set_input_source(gicp_handle h, const void* pts, size_t n, size_t stride_bytes) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  h->have_src = false;
+  h->have_cov_src = false;  // input_covariances_.reset()
+  h->step_ready = false;
+  if (h->tgt.device_ready) {
+    HIP_TRY(hipSetDevice(h->tgt.device));
+    HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+  }
+  const ndt_status s = gicp_build_index(&h->src, pts, n, stride_bytes);
+  if (s) return s;
+  HIP_TRY(hipStreamSynchronize(h->src.stream));  // the index is read from tgt's stream from here on
+  h->have_src = true;
+  return NDT_OK;
+}
+
+ndt_status gicp_align(gicp_handle h, const float* guess, float* final_T, int* converged, int* n_iterations, void* out_cloud) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  ndt_status s = gicp_prepare(h, guess);
+  if (s) return s;
+  h->step_ready = false;
+  GicpDevice dev(h);
+  const gicp::Result r = gicp::run(h->prm, h->guess_rm, dev);
+  if (r.backend_failed || !dev.error.empty()) return fail(NDT_ERR_HIP, dev.error.empty() ? "device failure" : dev.error);
+  colmajor_from_rowmajor(r.final_T, h->final_T);
+  h->converged = r.converged ? 1 : 0;
+  h->nr_iterations = r.nr_iterations;
+  h->n_f = r.n_f;
+  h->n_df = r.n_df;
+  h->n_fdf = r.n_fdf;
+  h->correspondences = r.correspondences;
+  if (final_T) std::memcpy(final_T, h->final_T, sizeof(h->final_T));
+  if (converged) *converged = h->converged;
+  if (n_iterations) *n_iterations = h->nr_iterations;
+  if (out_cloud) {  // pcl::transformPointCloud(*input_, output, final_transformation_), :513-516
+    const size_t n = h->src.target->n;
+    HIP_TRY(h->out_cloud.reserve(n));
+    HIP_TRY(ndt::launch_transform(h->src.target->pts.p, static_cast<int>(n), r.final_T, h->out_cloud.p, h->tgt.stream));
+    HIP_TRY(hipMemcpyAsync(out_cloud, h->out_cloud.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->tgt.stream));
+    HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+  }
+  return NDT_OK;
+}
+
+ndt_status gicp_get_result(gicp_handle h, float* final_T, int* converged, int* n_iterations) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  if (final_T) std::memcpy(final_T, h->final_T, sizeof(h->final_T));
+  if (converged) *converged = h->converged;
+  if (n_iterations) *n_iterations = h->nr_iterations;
+  return NDT_OK;
+}
+
+ndt_status gicp_get_fitness_score(gicp_handle h, double max_range, double* fitness) {
+  if (!h || !fitness) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = gicp_ready(h);
+  if (s) return s;
+  return fitness_impl(&h->tgt, h->src.target->pts.p, static_cast<int>(h->src.target->n), h->final_T, max_range, fitness);
+}
+
+ndt_status gicp_get_stats(gicp_handle h, int* n_f, int* n_df, int* n_fdf, int* correspondences) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  if (n_f) *n_f = h->n_f;
+  if (n_df) *n_df = h->n_df;
+  if (n_fdf) *n_fdf = h->n_fdf;
+  if (correspondences) *correspondences = h->correspondences;
+  return NDT_OK;
+}
+
+ndt_status gicp_covariances(gicp_handle h, int which, double* cov, int* nn_idx, float* nn_d2) {
+  if (!h || !cov || which < 0 || which > 1) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!(which == 0 ? h->have_tgt : h->have_src)) return fail(NDT_ERR_NO_INPUT, "cloud not set");
+  ndt_status s = ensure_device(&h->tgt);
+  if (s) return s;
+  const bool want_nn = nn_idx && nn_d2;
+  s = gicp_cloud_covariances(h, which, want_nn);
+  if (s) return s;
+  ndt_context* c = which == 0 ? &h->tgt : &h->src;
+  const size_t n = c->target->n;
+  std::vector<double> c6(n * 6);
+  HIP_TRY(hipMemcpyAsync(c6.data(), (which == 0 ? h->cov_tgt : h->cov_src).p, n * 6 * sizeof(double), hipMemcpyDeviceToHost, h->tgt.stream));
+  if (want_nn) {
+    const size_t k = static_cast<size_t>(h->prm.k_correspondences);
+    HIP_TRY(hipMemcpyAsync(nn_idx, h->nn_idx.p, n * k * sizeof(int), hipMemcpyDeviceToHost, h->tgt.stream));
+    HIP_TRY(hipMemcpyAsync(nn_d2, h->nn_d2.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->tgt.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+  for (size_t i = 0; i < n; i++) {
+    const double* s6 = &c6[i * 6];
+    double* o = cov + i * 9;
+    o[0] = s6[0]; o[1] = s6[1]; o[2] = s6[2];
+    o[3] = s6[1]; o[4] = s6[3]; o[5] = s6[4];
+    o[6] = s6[2]; o[7] = s6[4]; o[8] = s6[5];
+  }
+  return NDT_OK;
+}
+
+ndt_status gicp_step_correspond(gicp_handle h, const float* guess, const float* transformation, int* corr, float* maha,
+                                int* n_correspondences) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  ndt_status s = gicp_prepare(h, guess);
+  if (s) return s;
+  float T[16];
+  rowmajor_from_colmajor(transformation, T);
+  double R[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; k++) acc += static_cast<double>(T[i * 4 + k]) * static_cast<double>(h->guess_rm[k * 4 + j]);
+      R[i * 3 + j] = acc;
+    }
+  GicpDevice dev(h);
+  if (!dev.correspond(T, R)) return fail(NDT_ERR_HIP, dev.error);
+  const size_t n = h->src.target->n;
+  std::vector<int> c(n);
+  HIP_TRY(hipMemcpyAsync(c.data(), h->corr.p, n * sizeof(int), hipMemcpyDeviceToHost, h->tgt.stream));
+  if (maha) HIP_TRY(hipMemcpyAsync(maha, h->maha.p, n * 9 * sizeof(float), hipMemcpyDeviceToHost, h->tgt.stream));
+  HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+  int m = 0;
+  for (size_t i = 0; i < n; i++) m += c[i] >= 0;
+  if (corr) std::memcpy(corr, c.data(), n * sizeof(int));
+  if (n_correspondences) *n_correspondences = m;
+  h->step_ready = true;
+  return NDT_OK;
+}
+
+ndt_status gicp_step_functor(gicp_handle h, int mode, const double* x, double* f, double* g) {
+  if (!h || !x || mode < 0 || mode > 2) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h->step_ready) return fail(NDT_ERR_NO_INPUT, "gicp_step_correspond has not run");
+  ndt_status s = gicp_ready(h);
+  if (s) return s;
+  GicpDevice dev(h);
+  float T[16];
+  gicp::apply_state(x, T);
+  gicp::FunctorSums sums;
+  if (!dev.sums(mode, T, sums)) return fail(NDT_ERR_HIP, dev.error);
+  const int m = static_cast<int>(sums.m);
+  if (mode != 1 && f) *f = sums.f / static_cast<double>(m);
+  if (mode != 0 && g) {
+    for (int i = 0; i < 3; i++) g[i] = sums.g[i] * (2.0 / m);
+    double R[9];
+    for (int i = 0; i < 9; i++) R[i] = sums.R[i] * (2.0 / m);
+    gicp::rotation_gradient(x, R, g);
+  }
+  return NDT_OK;
+}
+
+void gicp_host_apply_state(const double* x, float* T) {
+  float rm[16];
+  gicp::apply_state(x, rm);
+  colmajor_from_rowmajor(rm, T);
+}
+
+}  // extern "C"

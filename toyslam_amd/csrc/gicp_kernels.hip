@@ -1,0 +1,364 @@
+// gicp_kernels.hip -- HIP kernels of the GICP row, gfx950 / wave64 only.
+//
+//   k_knn_covariances  computeCovariances (gicp_omp_impl.hpp:48-116): exact k nearest neighbours of
+//                      every point of a cloud among the cloud itself, the f64 covariance of those k
+//                      points, its eigenvectors, and the regularised covariance (1, 1, epsilon).
+//   k_correspond       per outer iteration (:419-456): nearest target point of every transformed
+//                      source point, distance gate, Mahalanobis matrix (R C1 R^T + C2)^-1.
+//   k_functor          the BFGS objective / gradient sums (:241-368), one fused launch per evaluation.
+//
+// All three are gather kernels over point sets that sit in L2 at the reference's sizes (tens of
+// thousands of points after the 0.1 m prefilter, apps/align.cpp:60-69); nothing here is
+// GEMM-shaped.  Nearest-neighbour search: the target's counting-sort voxel index (K1), cubic
+// shells of cells around the query until the k-th best distance cannot be beaten by any unvisited
+// shell -- exact, and with (distance, index) ordering deterministic.
+#include "gicp_kernels.hpp"
+
+#include "ndt_device.hpp"
+
+namespace gicp {
+
+using namespace ndt;
+
+namespace {
+
+constexpr int kKnnBlock = 64;   // one wave per block: the candidate lists take k * 512 B of LDS
+constexpr int kKnnMaxRing = 8;  // beyond this many shells: one scan over all points
+
+// [Eigen] Matrix4f * Vector4f (column by column): row r = ((T_r0 x + T_r1 y) + T_r2 z) + T_r3 * 1
+__device__ __forceinline__ void matvec_eigen(const float* T12, float x, float y, float z, float& ox, float& oy, float& oz) {
+#pragma clang fp contract(off)
+  ox = ((T12[0] * x + T12[1] * y) + T12[2] * z) + T12[3] * 1.0f;
+  oy = ((T12[4] * x + T12[5] * y) + T12[6] * z) + T12[7] * 1.0f;
+  oz = ((T12[8] * x + T12[9] * y) + T12[10] * z) + T12[11] * 1.0f;
+}
+
+__device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, float z, int& ci, int& cj, int& ck) {
+  search_ijk(g, x, y, z, ci, cj, ck);
+  ci = max(g.min_b[0], min(g.max_b[0], ci)) - g.min_b[0];  // nearest grid cell when outside the bounding box
+  cj = max(g.min_b[1], min(g.max_b[1], cj)) - g.min_b[1];
+  ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
+}
+
+// visits the occupied cells of shell r around (ci, cj, ck)
+template <class F>
+__device__ __forceinline__ void for_shell(const PointIndex& ix, int ci, int cj, int ck, int r, F&& visit) {
+  const GridGeom& g = ix.geom;
+  for (int dz = -r; dz <= r; dz++) {
+    const int z = ck + dz;
+    if (z < 0 || z >= g.div_b[2]) continue;
+    for (int dy = -r; dy <= r; dy++) {
+      const int y = cj + dy;
+      if (y < 0 || y >= g.div_b[1]) continue;
+      const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+      const int step = face ? 1 : max(2 * r, 1);  // interior rows of the shell: only dx = -r and dx = +r
+      for (int dx = -r; dx <= r; dx += step) {
+        const int x = ci + dx;
+        if (x < 0 || x >= g.div_b[0]) continue;
+        const int lf = ix.cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+        if (lf >= 0) visit(lf);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, int k, double gicp_epsilon,
+                                                               double* __restrict__ cov6, int* __restrict__ nn_idx,
+                                                               float* __restrict__ nn_d2) {
+#pragma clang fp contract(off)
+  extern __shared__ unsigned char knn_lds[];
+  float* sd = reinterpret_cast<float*>(knn_lds);         // [k][64] distances, ascending per lane
+  int* si = reinterpret_cast<int*>(sd + k * kKnnBlock);  // [k][64] point indices
+  const int lane = threadIdx.x;
+  const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
+  const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
+  for (int i = blockIdx.x * kKnnBlock + lane; i < ix.n; i += gridDim.x * kKnnBlock) {
+    const float4 q = ix.pts[i];
+    int cnt = 0;
+    float worst = INFINITY;
+    int worst_i = 0x7fffffff;
+    auto consider = [&](int idx) {
+      const float4 t = ix.pts[idx];
+      const float d = dist2_f32(q.x, q.y, q.z, t.x, t.y, t.z);
+      if (cnt == k && (d > worst || (d == worst && idx > worst_i))) return;
+      int j = (cnt < k) ? cnt++ : k - 1;
+      while (j > 0) {
+        const float pd = sd[(j - 1) * kKnnBlock + lane];
+        const int pi = si[(j - 1) * kKnnBlock + lane];
+        if (pd < d || (pd == d && pi < idx)) break;
+        sd[j * kKnnBlock + lane] = pd;
+        si[j * kKnnBlock + lane] = pi;
+        j--;
+      }
+      sd[j * kKnnBlock + lane] = d;
+      si[j * kKnnBlock + lane] = idx;
+      if (cnt == k) {
+        worst = sd[(k - 1) * kKnnBlock + lane];
+        worst_i = si[(k - 1) * kKnnBlock + lane];
+      }
+    };
+    int ci, cj, ck;
+    query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck);
+    bool done = false;
+    for (int r = 0; r <= kKnnMaxRing && !done; r++) {
+      for_shell(ix, ci, cj, ck, r, [&](int lf) {
+        const unsigned s0 = ix.leaf_start[lf];
+        const int c = ix.leaf_count[lf];
+        for (int p = 0; p < c; p++) consider(ix.sorted_idx[s0 + p]);
+      });
+      // every unvisited point is at least r cells (less the index-rounding slack) away; strict, so a
+      // tie at the k-th distance with a lower index cannot be missed
+      const float reach = static_cast<float>(r) * leaf - ix.slack;
+      if ((cnt == k && reach > 0.0f && worst < reach * reach) || r >= r_lim) done = true;
+    }
+    if (!done) {  // sparse neighbourhood: scan everything
+      cnt = 0;
+      worst = INFINITY;
+      worst_i = 0x7fffffff;
+      for (int p = 0; p < ix.n_sorted; p++) consider(ix.sorted_idx[p]);
+    }
+    if (nn_idx) {
+      for (int j = 0; j < k; j++) {
+        nn_idx[static_cast<size_t>(i) * k + j] = (j < cnt) ? si[j * kKnnBlock + lane] : -1;
+        nn_d2[static_cast<size_t>(i) * k + j] = (j < cnt) ? sd[j * kKnnBlock + lane] : INFINITY;
+      }
+    }
+    // :81-105  f32 products, f64 sums, neighbours in ascending distance
+    double mx = 0, my = 0, mz = 0, cxx = 0, cyx = 0, cyy = 0, czx = 0, czy = 0, czz = 0;
+    for (int j = 0; j < cnt; j++) {
+      const float4 t = ix.pts[si[j * kKnnBlock + lane]];
+      mx += static_cast<double>(t.x);
+      my += static_cast<double>(t.y);
+      mz += static_cast<double>(t.z);
+      cxx += static_cast<double>(t.x * t.x);
+      cyx += static_cast<double>(t.y * t.x);
+      cyy += static_cast<double>(t.y * t.y);
+      czx += static_cast<double>(t.z * t.x);
+      czy += static_cast<double>(t.z * t.y);
+      czz += static_cast<double>(t.z * t.z);
+    }
+    const double kd = static_cast<double>(k);
+    mx /= kd;
+    my /= kd;
+    mz /= kd;
+    double C[3][3];
+    C[0][0] = cxx / kd - mx * mx;
+    C[1][0] = cyx / kd - my * mx;
+    C[1][1] = cyy / kd - my * my;
+    C[2][0] = czx / kd - mz * mx;
+    C[2][1] = czy / kd - mz * my;
+    C[2][2] = czz / kd - mz * mz;
+    C[0][1] = C[1][0];
+    C[0][2] = C[2][0];
+    C[1][2] = C[2][1];
+    // :108-120  [Eigen] JacobiSVD of a symmetric matrix: U = eigenvectors ordered by |eigenvalue| descending
+    double w[3], V[3][3];
+    eig3_jacobi(C, w, V);
+    int o0 = 2, o1 = 1, o2 = 0;  // eig3_jacobi: ascending eigenvalues
+    if (fabs(w[o1]) > fabs(w[o0])) { const int t = o0; o0 = o1; o1 = t; }
+    if (fabs(w[o2]) > fabs(w[o1])) { const int t = o1; o1 = o2; o2 = t; }
+    if (fabs(w[o1]) > fabs(w[o0])) { const int t = o0; o0 = o1; o1 = t; }
+    double out[6];
+    int e = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) {
+        double s = (1.0 * V[a][o0]) * V[b][o0];
+        s += (1.0 * V[a][o1]) * V[b][o1];
+        s += (gicp_epsilon * V[a][o2]) * V[b][o2];
+        out[e++] = s;
+      }
+    for (int t = 0; t < 6; t++) cov6[static_cast<size_t>(i) * 6 + t] = out[t];
+  }
+}
+
+__device__ __forceinline__ void load_sym(const double* __restrict__ c6, double C[3][3]) {
+  C[0][0] = c6[0]; C[0][1] = c6[1]; C[0][2] = c6[2];
+  C[1][0] = c6[1]; C[1][1] = c6[3]; C[1][2] = c6[4];
+  C[2][0] = c6[2]; C[2][1] = c6[4]; C[2][2] = c6[5];
+}
+
+__global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict__ output, int n, EvalParams P, Rot3d R,
+                                                       PointIndex ix, const double* __restrict__ cov_src6,
+                                                       const double* __restrict__ cov_tgt6, double dist_threshold,
+                                                       int* __restrict__ corr, float* __restrict__ maha9) {
+#pragma clang fp contract(off)
+  const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
+  const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = output[i];
+    float qx, qy, qz;
+    matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
+    float best = INFINITY;
+    int best_i = -1;
+    auto consider = [&](int idx) {
+      const float4 t = ix.pts[idx];
+      const float d = dist2_f32(qx, qy, qz, t.x, t.y, t.z);
+      if (d < best || (d == best && idx < best_i)) {
+        best = d;
+        best_i = idx;
+      }
+    };
+    int ci, cj, ck;
+    query_cell(ix.geom, qx, qy, qz, ci, cj, ck);
+    bool done = false;
+    for (int r = 0; r <= kKnnMaxRing && !done; r++) {
+      for_shell(ix, ci, cj, ck, r, [&](int lf) {
+        const unsigned s0 = ix.leaf_start[lf];
+        const int c = ix.leaf_count[lf];
+        for (int q = 0; q < c; q++) consider(ix.sorted_idx[s0 + q]);
+      });
+      const float reach = static_cast<float>(r) * leaf - ix.slack;
+      if ((best_i >= 0 && reach > 0.0f && best < reach * reach) || r >= r_lim) done = true;
+    }
+    if (!done) {
+      best = INFINITY;
+      best_i = -1;
+      for (int q = 0; q < ix.n_sorted; q++) consider(ix.sorted_idx[q]);
+    }
+    int c_out = -1;
+    if (best_i >= 0 && static_cast<double>(best) < dist_threshold) {  // :436
+      double C1[3][3], C2[3][3], M[3][3], tmp[3][3], inv[3][3];
+      load_sym(cov_src6 + static_cast<size_t>(i) * 6, C1);
+      load_sym(cov_tgt6 + static_cast<size_t>(best_i) * 6, C2);
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) M[r][c] = (R.m[r * 3] * C1[0][c] + R.m[r * 3 + 1] * C1[1][c]) + R.m[r * 3 + 2] * C1[2][c];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+          tmp[r][c] = ((M[r][0] * R.m[c * 3] + M[r][1] * R.m[c * 3 + 1]) + M[r][2] * R.m[c * 3 + 2]) + C2[r][c];
+      inv3_cofactor(tmp, inv);
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) maha9[static_cast<size_t>(i) * 9 + r * 3 + c] = static_cast<float>(inv[r][c]);
+      c_out = best_i;
+    }
+    corr[i] = c_out;
+  }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(kBlock) void k_functor(const float4* __restrict__ output, int n, const float4* __restrict__ tgt,
+                                                    const int* __restrict__ corr, const float* __restrict__ maha9,
+                                                    EvalParams P, double* __restrict__ partials,
+                                                    unsigned* __restrict__ counter, double* __restrict__ out_row,
+                                                    unsigned long long seq) {
+#pragma clang fp contract(off)
+  constexpr int kWaves = kBlock / kWave, kParts = kBlock / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ double lds2[kParts * kEvalStride];
+  __shared__ int s_last;
+  double acc[kFunctorValues];
+#pragma unroll
+  for (int k = 0; k < kFunctorValues; k++) acc[k] = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int c = corr[i];
+    if (c < 0) continue;
+    const float4 ps = output[i];
+    const float4 pt = tgt[c];
+    const float* M = maha9 + static_cast<size_t>(i) * 9;
+    float px, py, pz;
+    matvec_eigen(P.T, ps.x, ps.y, ps.z, px, py, pz);
+    const float r0 = px - pt.x, r1 = py - pt.y, r2 = pz - pt.z;
+    if (F32) {  // operator(), :241-274
+      const float m0 = (M[0] * r0 + M[1] * r1) + M[2] * r2;
+      const float m1 = (M[3] * r0 + M[4] * r1) + M[5] * r2;
+      const float m2 = (M[6] * r0 + M[7] * r1) + M[8] * r2;
+      const float ret = (r0 * m0 + r2 * m2) + r1 * m1;  // [Eigen] 4-wide dot: (p0 + p2) + (p1 + p3)
+      acc[0] += static_cast<double>(ret);
+    } else {  // df / fdf, :277-368
+      const double d0 = static_cast<double>(r0), d1 = static_cast<double>(r1), d2 = static_cast<double>(r2);
+      const double t0 = (static_cast<double>(M[0]) * d0 + static_cast<double>(M[1]) * d1) + static_cast<double>(M[2]) * d2;
+      const double t1 = (static_cast<double>(M[3]) * d0 + static_cast<double>(M[4]) * d1) + static_cast<double>(M[5]) * d2;
+      const double t2 = (static_cast<double>(M[6]) * d0 + static_cast<double>(M[7]) * d1) + static_cast<double>(M[8]) * d2;
+      acc[0] += (d0 * t0 + d1 * t1) + d2 * t2;
+      acc[1] += t0;
+      acc[2] += t1;
+      acc[3] += t2;
+      const double sx = static_cast<double>(ps.x), sy = static_cast<double>(ps.y), sz = static_cast<double>(ps.z);
+      acc[4] += sx * t0;
+      acc[5] += sx * t1;
+      acc[6] += sx * t2;
+      acc[7] += sy * t0;
+      acc[8] += sy * t1;
+      acc[9] += sy * t2;
+      acc[10] += sz * t0;
+      acc[11] += sz * t1;
+      acc[12] += sz * t2;
+    }
+    acc[13] += 1.0;
+  }
+  // block row -> ticket -> fixed-order sum by the last block -> tagged publication (as k_derivatives_fused)
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const double tot = wave_fold<kFunctorValues>(acc);
+  if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+  __syncthreads();
+  if (wave == 0) {
+    if (lane < kEvalStride) {
+      double v = 0.0;
+      if (lane < kFunctorValues) {
+        v = lds[lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+      }
+      __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int k = threadIdx.x % kEvalStride, part = threadIdx.x / kEvalStride;
+  lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x < kEvalStride) {
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + threadIdx.x];
+    lds[threadIdx.x] = t;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  publish_row_tagged(out_row, lds, threadIdx.x, seq);
+}
+
+}  // namespace
+
+hipError_t launch_knn_covariances(const PointIndex& ix, int k, double gicp_epsilon, double* cov6, int* nn_idx, float* nn_d2,
+                                  hipStream_t stream) {
+  if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
+  const int blocks = max(1, min(8192, (ix.n + kKnnBlock - 1) / kKnnBlock));
+  const size_t lds = static_cast<size_t>(k) * kKnnBlock * 8;
+  hipLaunchKernelGGL(k_knn_covariances, dim3(blocks), dim3(kKnnBlock), lds, stream, ix, k, gicp_epsilon, cov6, nn_idx, nn_d2);
+  return hipGetLastError();
+}
+
+hipError_t launch_correspond(const float4* output, int n, const float* T12, const Rot3d& R, const PointIndex& tgt,
+                             const double* cov_src6, const double* cov_tgt6, double dist_threshold, int* corr, float* maha9,
+                             hipStream_t stream) {
+  EvalParams P{};
+  for (int i = 0; i < 12; i++) P.T[i] = T12[i];
+  const int blocks = max(1, min(4096, (n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_correspond, dim3(blocks), dim3(kBlock), 0, stream, output, n, P, R, tgt, cov_src6, cov_tgt6,
+                     dist_threshold, corr, maha9);
+  return hipGetLastError();
+}
+
+int functor_blocks(int n) { return max(1, min(kFunctorMaxBlocks, (n + kBlock - 1) / kBlock)); }
+
+hipError_t launch_functor(int mode, const float4* output, int n, const float4* tgt, const int* corr, const float* maha9,
+                          const float* T12, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                          unsigned long long seq, hipStream_t stream) {
+  EvalParams P{};
+  for (int i = 0; i < 12; i++) P.T[i] = T12[i];
+  if (mode == 0)
+    hipLaunchKernelGGL(k_functor<true>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials,
+                       counter, out_row, seq);
+  else
+    hipLaunchKernelGGL(k_functor<false>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials,
+                       counter, out_row, seq);
+  return hipGetLastError();
+}
+
+}  // namespace gicp

@@ -21,6 +21,9 @@
 #include <tuple>
 #include <vector>
 
+#include "gicp_driver.hpp"
+#include "gicp_kernels.hpp"
+#include "gicp_mi355.h"
 #include "ndt_driver.hpp"
 #include "ndt_kernels.hpp"
 #include "ndt_pcd.hpp"
@@ -1301,44 +1304,56 @@ ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t
 }
 
 // ---- N4: getFitnessScore ------------------------------------------------------
-ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness) {
-  if (!h || !fitness) return fail(NDT_ERR_INVALID, "bad arguments");
-  ndt_status s = check_ready(h);
-  if (s) return s;
-  *fitness = std::numeric_limits<double>::max();  // nr == 0 in the reference
-  DeviceGrid* g = h->grid.get();
-  const int n = static_cast<int>(h->source->n);
-  s = grid_counts(h, g);
-  if (s) return s;
-  if (n == 0 || g->empty || g->n_sorted == 0) return NDT_OK;
-  {
-    std::lock_guard<std::mutex> lock(g->fit_mu);
-    if (!g->have_cell2leaf) {
-      HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
-      HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
-      HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      g->have_cell2leaf = true;
-    }
+namespace {
+// cell -> occupied-cell ordinal table of a built grid (the nearest-neighbour searches walk it), built on first use
+ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g) {
+  std::lock_guard<std::mutex> lock(g->fit_mu);
+  if (!g->have_cell2leaf) {
+    HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
+    HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
+    HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    g->have_cell2leaf = true;
   }
-  s = ensure_host_rows(h, 1);
-  if (s) return s;
-  float T12[12];
-  colmajor_to_T12(h->final_T, T12);
-  // slack of the shell bound: the build-time and search-time cell indices of a coordinate can differ
-  // at cell borders by rounding (SURVEY 8a trap 2) -- a few ulps of the largest coordinate
+  return NDT_OK;
+}
+// slack of the shell bound: the build-time and search-time cell indices of a coordinate can differ
+// at cell borders by rounding (SURVEY 8a trap 2) -- a few ulps of the largest coordinate
+float index_slack(const DeviceGrid* g) {
   float max_abs = 0.f;
   for (int k = 0; k < 3; k++)
     max_abs = std::max(max_abs, std::max(std::fabs(g->geom.min_b[k] * g->geom.leaf[k]), std::fabs((g->geom.max_b[k] + 1) * g->geom.leaf[k])));
-  const float slack = 1e-3f * h->resolution + 4e-6f * max_abs;
+  return 1e-3f * g->resolution + 4e-6f * max_abs;
+}
+// [PCL] Registration::getFitnessScore of the dense device cloud d_src moved by T against h's target
+ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness) {
+  *fitness = std::numeric_limits<double>::max();  // nr == 0 in the reference
+  DeviceGrid* g = h->grid.get();
+  ndt_status s = grid_counts(h, g);
+  if (s) return s;
+  if (n == 0 || g->empty || g->n_sorted == 0) return NDT_OK;
+  s = ensure_cell2leaf(h, g);
+  if (s) return s;
+  s = ensure_host_rows(h, 1);
+  if (s) return s;
+  float T12[12];
+  colmajor_to_T12(T_colmajor, T12);
   const int nblk = std::max(1, std::min(2048, (n + 255) / 256));
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
-  HIP_TRY(ndt::launch_fitness(h->source->pts.p, n, T12, g->geom, g->cell2leaf.p, g->leaf_start.p, g->leaf_count.p, g->sorted_idx.p,
-                              static_cast<int>(g->n_sorted), g->target->pts.p, max_range, slack, nblk, h->partials.p, h->stream));
+  HIP_TRY(ndt::launch_fitness(d_src, n, T12, g->geom, g->cell2leaf.p, g->leaf_start.p, g->leaf_count.p, g->sorted_idx.p,
+                              static_cast<int>(g->n_sorted), g->target->pts.p, max_range, index_slack(g), nblk, h->partials.p, h->stream));
   HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->host_result[1] > 0) *fitness = h->host_result[0] / h->host_result[1];
   return NDT_OK;
+}
+}  // namespace
+
+ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness) {
+  if (!h || !fitness) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  return fitness_impl(h, h->source->pts.p, static_cast<int>(h->source->n), h->final_T, max_range, fitness);
 }
 
 // ---- N1: voxel-grid centroid down-sample -----------------------------------
@@ -2015,3 +2030,6 @@ ndt_status ndt_host_run_driver(ndt_eval_cb cb, void* user, size_t n_source, cons
 }
 
 }  // extern "C"
+
+// GICP row: shares this unit's pool, upload and grid build
+#include "gicp_capi.inl"

@@ -707,5 +707,93 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// small dense f64 algebra (grid finalize, GICP covariances / Mahalanobis matrices)
+// ---------------------------------------------------------------------------
+// 3x3 symmetric eigen-decomposition (cyclic Jacobi, f64); eigenvalues ascending
+// in w[], eigenvectors in the columns of V.  Stands in for
+// Eigen::SelfAdjointEigenSolver<Matrix3d> (_impl.hpp:275,333-335): only the
+// eigenvalues and V*diag*V^-1 are consumed, both solver-independent to O(eps).
+__device__ inline void eig3_jacobi(const double A_in[3][3], double w[3], double V[3][3]) {
+#pragma clang fp contract(off)
+  double A[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      A[i][j] = (i >= j) ? A_in[i][j] : A_in[j][i];  // lower triangle, like Eigen
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 50; sweep++) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    const double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+    // Jacobi converges quadratically and the eigenvalue error is O(off^2 / gap): at off <= eps/2 * dia
+    // another sweep cannot change a bit of the result that is consumed
+    if (off <= 1e-300 || off <= dia * 1e-16) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; pq++) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+      const double apq = A[p][q];
+      if (apq == 0.0) continue;
+      // tan of the rotation angle, the root of t^2 + 2 theta t - 1 = 0 that is smaller in magnitude,
+      // written without forming theta = d / (2 apq):  t = 2 apq / (d + sign(d) sqrt(d^2 + 4 apq^2))
+      // (one division and two square roots per rotation instead of three and two: the f64 division
+      // chains are what this one-thread-per-voxel kernel waits for)
+      const double d = A[q][q] - A[p][p], b2 = 2.0 * apq;
+      const double t = b2 / (d + copysign(sqrt(d * d + b2 * b2), d));
+      const double c = rsqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; k++) {
+        const double akp = A[k][p], akq = A[k][q];
+        A[k][p] = c * akp - s * akq;
+        A[k][q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; k++) {
+        const double apk = A[p][k], aqk = A[q][k];
+        A[p][k] = c * apk - s * aqk;
+        A[q][k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; k++) {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq;
+        V[k][q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  // sort ascending (3 elements)
+  double d[3] = {A[0][0], A[1][1], A[2][2]};
+  int o[3] = {0, 1, 2};
+  if (d[o[0]] > d[o[1]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  if (d[o[1]] > d[o[2]]) { int t = o[1]; o[1] = o[2]; o[2] = t; }
+  if (d[o[0]] > d[o[1]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  double Vs[3][3];
+  for (int j = 0; j < 3; j++) {
+    w[j] = d[o[j]];
+    for (int i = 0; i < 3; i++) Vs[i][j] = V[i][o[j]];
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) V[i][j] = Vs[i][j];
+}
+
+// Matrix3d::inverse() as Eigen evaluates it (cofactors, multiply by 1/det)
+__device__ inline void inv3_cofactor(const double a[3][3], double r[3][3]) {
+#pragma clang fp contract(off)
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return a[i1][j1] * a[i2][j2] - a[i1][j2] * a[i2][j1];
+  };
+  const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+  const double det = (c00 * a[0][0] + c10 * a[1][0]) + c20 * a[2][0];
+  const double invdet = 1.0 / det;
+  r[0][0] = c00 * invdet; r[0][1] = c10 * invdet; r[0][2] = c20 * invdet;
+  r[1][0] = cof(0, 1) * invdet; r[1][1] = cof(1, 1) * invdet; r[1][2] = cof(2, 1) * invdet;
+  r[2][0] = cof(0, 2) * invdet; r[2][1] = cof(1, 2) * invdet; r[2][2] = cof(2, 2) * invdet;
+}
+
+// [FLANN] L2_Simple<float>: f32, (dx*dx + dy*dy) + dz*dz, no contraction
+__device__ __forceinline__ float dist2_f32(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+
 }  // namespace
 }  // namespace ndt
