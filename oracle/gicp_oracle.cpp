@@ -243,26 +243,30 @@ inline void mat4f_vec(const float T[4][4], const Pt& p, float out[4]) {  // [Eig
 }
 }  // namespace
 
-double GICP::functor_f(const double x[6]) const {  // operator(), :241-274: f32 quadratic form, f64 sum
-  n_f++;
-  float T[4][4];
-  apply_state(x, T);
-  const int m = static_cast<int>(corr_src.size());
+static double functor_f_sum(const GICP& s, const float T[4][4]) {
+  const int m = static_cast<int>(s.corr_src.size());
   double f = 0.0;
   for (int i = 0; i < m; i++) {
-    const Pt& ps = (*opt_src)[corr_src[i]];
-    const Pt& pt = target[corr_tgt[i]];
+    const Pt& ps = (*s.opt_src)[s.corr_src[i]];
+    const Pt& pt = s.target[s.corr_tgt[i]];
     float pp[4];
     mat4f_vec(T, ps, pp);
     const float res[3] = {pp[0] - pt.x, pp[1] - pt.y, pp[2] - pt.z};  // 4th component 1 - 1 = 0
-    const std::array<float, 9>& M = mahalanobis[corr_src[i]];
+    const std::array<float, 9>& M = s.mahalanobis[s.corr_src[i]];
     float mr[3];
     for (int r = 0; r < 3; r++) mr[r] = (M[r * 3 + 0] * res[0] + M[r * 3 + 1] * res[1]) + M[r * 3 + 2] * res[2];
     // [Eigen] 4-wide dot: (p0 + p2) + (p1 + p3), p3 = 0
     const float ret = (res[0] * mr[0] + res[2] * mr[2]) + res[1] * mr[1];
     f += static_cast<double>(ret);
   }
-  return f / m;
+  return f;
+}
+
+double GICP::functor_f(const double x[6]) const {  // operator(), :241-274: f32 quadratic form, f64 sum
+  n_f++;
+  float T[4][4];
+  apply_state(x, T);
+  return functor_f_sum(*this, T) / static_cast<int>(corr_src.size());
 }
 
 namespace {
@@ -289,6 +293,22 @@ static void functor_sums(const GICP& s, const float T[4][4], Sums& acc) {
       acc.g[r] += temp[r];
       for (int c = 0; c < 3; c++) acc.R[r][c] += p3[r] * temp[c];
     }
+  }
+}
+
+void GICP::functor_raw(int mode, const float T[4][4], double out[14]) const {
+  for (int i = 0; i < 14; i++) out[i] = 0.0;
+  out[13] = static_cast<double>(corr_src.size());
+  if (mode == 0) {
+    out[0] = functor_f_sum(*this, T);
+    return;
+  }
+  Sums acc;
+  functor_sums(*this, T, acc);
+  out[0] = acc.f;
+  for (int r = 0; r < 3; r++) {
+    out[1 + r] = acc.g[r];
+    for (int c = 0; c < 3; c++) out[4 + r * 3 + c] = acc.R[r][c];
   }
 }
 

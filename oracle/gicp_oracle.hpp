@@ -70,6 +70,8 @@ class GICP {
   double functor_f(const double x[6]) const;
   void functor_df(const double x[6], double g[6]) const;
   void functor_fdf(const double x[6], double& f, double g[6]) const;
+  // the un-normalised sums behind them at a given T: out = f, g[3], R[9] row-major, count (mode 0: f32 form, f and count only)
+  void functor_raw(int mode, const float T[4][4], double out[14]) const;
 
   // applyState on the identity (:519-532), computeRDerivative (:119-178)
   static void apply_state(const double x[6], float T[4][4]);

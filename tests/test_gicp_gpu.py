@@ -1,0 +1,213 @@
+"""GPU parity tests of the GICP row: the HIP path behind include/gicp_mi355.h against the CPU oracle
+(oracle/gicp_oracle.cpp) on the same inputs.  Index work (neighbours, correspondences) must be identical; the f64
+covariances agree to rounding; transforms within BASELINE's tolerance (1e-4 rotation / 1e-3 m translation) -- in
+practice the whole registration follows the oracle's trajectory evaluation for evaluation."""
+import numpy as np
+import pytest
+
+from conftest import rot_err, trans_err
+from oracle import pyoracle as po
+from toyslam_amd import clouds
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def gmod():
+    import torch  # noqa: F401  the GPU runtime is initialised before the library
+    from toyslam_amd import gicp
+    return gicp
+
+
+@pytest.fixture(scope="module")
+def scene():
+    tgt = clouds.target_surfaces(20000)[:, :3].astype(np.float32)
+    src = clouds.source_from_target(tgt, 8000)[:, :3].astype(np.float32)
+    return tgt, src
+
+
+def both(gmod, tgt, src, **kw):
+    g = gmod.GeneralizedIterativeClosestPoint()
+    o = po.OracleGICP(**kw)
+    if "k" in kw:
+        g.setCorrespondenceRandomness(kw["k"])
+    if "rotation_epsilon" in kw:
+        g.setRotationEpsilon(kw["rotation_epsilon"])
+    if "transformation_epsilon" in kw:
+        g.setTransformationEpsilon(kw["transformation_epsilon"])
+    if "corr_dist_threshold" in kw:
+        g.setMaxCorrespondenceDistance(kw["corr_dist_threshold"])
+    if "max_iterations" in kw:
+        g.setMaximumIterations(kw["max_iterations"])
+    if "max_inner_iterations" in kw:
+        g.setMaximumOptimizerIterations(kw["max_inner_iterations"])
+    for x in (g, o):
+        x.setInputTarget(tgt)
+        x.setInputSource(src)
+    return g, o
+
+
+def test_neighbours_and_covariances(gmod, scene):
+    """computeCovariances (gicp_omp_impl.hpp:48-116): the 20 nearest neighbours of every point are the oracle's,
+    in the oracle's order with the oracle's f32 distances; covariances agree to f64 rounding."""
+    tgt, src = scene
+    g, _ = both(gmod, tgt, src)
+    for which, cloud in ((0, tgt), (1, src)):
+        cov, idx, d2 = g.covariances(which, neighbors=True)
+        oi, od = po.gicp_knn(cloud, cloud, 20)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+        assert np.abs(cov - po.gicp_covariances(cloud, 20, 1e-3)).max() < 1e-12
+        assert np.array_equal(cov, cov.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("k", [5, 33, 64])
+def test_other_neighbourhood_sizes(gmod, scene, k):
+    tgt, _ = scene
+    sub = tgt[:3000]
+    g = gmod.GeneralizedIterativeClosestPoint()
+    g.setCorrespondenceRandomness(k)
+    g.setInputTarget(sub)
+    cov, idx, d2 = g.covariances(0, neighbors=True)
+    oi, od = po.gicp_knn(sub, sub, k)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    assert np.abs(cov - po.gicp_covariances(sub, k, 1e-3)).max() < 1e-12
+
+
+def test_duplicate_points_and_sparse_outliers(gmod):
+    """ties are broken by index on both sides; isolated points far from everything (the exhaustive-scan path of the
+    shell search) still get their exact neighbours."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-3, 3, (1500, 3)).astype(np.float32)
+    cloud = np.concatenate([base, base[:300], base[:100], np.array([[400, 0, 0], [0, -350, 20], [90, 90, 90]], np.float32)])
+    g = gmod.GeneralizedIterativeClosestPoint()
+    g.setInputTarget(cloud)
+    cov, idx, d2 = g.covariances(0, neighbors=True)
+    oi, od = po.gicp_knn(cloud, cloud, 20)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od)
+    assert np.abs(cov - po.gicp_covariances(cloud, 20, 1e-3)).max() < 1e-9
+
+
+def test_correspondence_step(gmod, scene):
+    """one outer iteration's correspondence step (:405-456): same nearest target index for every source point, same
+    gate decisions, Mahalanobis matrices equal as f32 -- with a guess and a non-identity current transform."""
+    tgt, src = scene
+    guess = clouds.make_T([0.2, -0.1, 0.05], np.radians([0.3, -0.2, 0.6])).astype(np.float32)
+    cur = clouds.make_T([0.05, -0.05, 0.02], np.radians([0.1, 0.0, 0.2])).astype(np.float32)
+    for thr in (5.0, 0.15):
+        g, o = both(gmod, tgt, src, corr_dist_threshold=thr)
+        o.prepare(guess)
+        m_o, idx_o, maha_o = o.correspond(cur)
+        m_g, idx_g, maha_g = g.step_correspond(guess, cur)
+        assert m_o == m_g and np.array_equal(idx_o, idx_g)
+        if thr < 1:
+            assert 0 < m_g < len(src)
+        v = idx_o >= 0
+        assert np.abs(maha_o[v] - maha_g[v]).max() <= 1e-6 * np.abs(maha_o[v]).max()
+
+
+def test_functor_sums(gmod, scene):
+    """OptimizationFunctorWithIndices (:241-368): operator() (f32 form), df and fdf (f64) at several states."""
+    tgt, src = scene
+    g, o = both(gmod, tgt, src)
+    o.prepare()
+    o.correspond(np.eye(4))
+    g.step_correspond()
+    rng = np.random.default_rng(2)
+    for _ in range(6):
+        x = np.r_[rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.03, 0.03, 3)]
+        for mode in (0, 1, 2):
+            fo, go = o.functor(mode, x)
+            fg, gg = g.step_functor(mode, x)
+            if mode != 1:
+                assert abs(fo - fg) <= 1e-12 * abs(fo)
+            if mode != 0:
+                assert np.abs(go - gg).max() <= 1e-11 * np.abs(go).max()
+
+
+@pytest.mark.parametrize("case", ["identity", "guess", "k10", "tight_gate", "few_outer", "few_inner"])
+def test_align_matches_oracle(gmod, scene, case):
+    """computeTransformation (:372-517): final transform within tolerance of the oracle's, same convergence flag,
+    same number of outer iterations and of objective evaluations (the optimiser follows the same path)."""
+    tgt, src = scene
+    kw, guess = {}, None
+    if case == "guess":
+        guess = clouds.make_T([0.2, -0.1, 0.05], np.radians([0.3, -0.2, 0.6])).astype(np.float32)
+    if case == "k10":
+        kw = dict(k=10)
+    if case == "tight_gate":
+        kw = dict(corr_dist_threshold=0.3)
+    if case == "few_outer":
+        kw = dict(max_iterations=2)
+    if case == "few_inner":
+        kw = dict(max_inner_iterations=3)
+    g, o = both(gmod, tgt, src, **kw)
+    ro = o.align(guess, want_cloud=True)
+    cloud = g.align(guess, want_cloud=True)
+    T = g.getFinalTransformation()
+    assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL
+    assert g.hasConverged() == ro["converged"] and g.getFinalNumIteration() == ro["iterations"]
+    st = g.stats()
+    assert (st["n_f"], st["n_df"], st["n_fdf"]) == (ro["n_f"], ro["n_df"], ro["n_fdf"])
+    assert st["correspondences"] == ro["correspondences"]
+    assert np.abs(cloud - ro["cloud"]).max() < 2e-3
+    # the output cloud is the source moved by the final transform ([PCL] transformPointCloud)
+    src4 = np.c_[src, np.ones(len(src), np.float32)]
+    assert np.array_equal(cloud, po.transform_cloud(src4, T))
+
+
+def test_align_on_the_reference_pair(gmod, pair):
+    """the bundled scan pair after the 0.1 m prefilter, as ndt_omp/apps/align.cpp:80-86 runs pclomp::GICP on it."""
+    tgt, src = pair
+    g, o = both(gmod, tgt, src)
+    ro = o.align()
+    g.align()
+    T = g.getFinalTransformation()
+    assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL
+    assert g.hasConverged() and ro["converged"] and g.getFinalNumIteration() == ro["iterations"]
+    # getFitnessScore after align: mean squared nearest-neighbour distance, well under the NDT values of the README
+    from scipy.spatial import cKDTree
+    moved = clouds.apply_T(T, src)
+    want = float(np.mean(cKDTree(tgt.astype(np.float64)).query(moved.astype(np.float64))[0] ** 2))
+    assert abs(g.getFitnessScore() - want) < 1e-4 * want
+    assert g.getFitnessScore() < 0.25
+
+
+def test_too_few_correspondences_and_errors(gmod, scene):
+    tgt, src = scene
+    g, o = both(gmod, tgt, src + np.float32(0.37), corr_dist_threshold=1e-4)
+    guess = clouds.make_T([0.5, 0, 0], [0, 0, 0.1]).astype(np.float32)
+    ro = o.align(guess)
+    g.align(guess)
+    assert not g.hasConverged() and not ro["converged"] and g.getFinalNumIteration() == 0
+    assert np.array_equal(g.getFinalTransformation(), ro["T"]) and np.array_equal(ro["T"], guess)
+    from toyslam_amd import NdtError
+    h = gmod.GeneralizedIterativeClosestPoint()
+    with pytest.raises(NdtError):  # no inputs
+        h.align()
+    bad = tgt[:100].copy()
+    bad[7, 1] = np.nan
+    with pytest.raises(NdtError):  # non-finite input
+        h.setInputTarget(bad)
+    h.setInputTarget(tgt[:10])
+    h.setInputSource(src[:100])
+    with pytest.raises(NdtError):  # k_correspondences_ exceeds the target (:53-57)
+        h.align()
+    with pytest.raises(NdtError):
+        h.setCorrespondenceRandomness(65)
+
+
+def test_handles_are_independent_and_reusable(gmod, scene):
+    """new inputs on a used handle drop the cached covariances (gicp_omp.h:128-160); two handles do not interfere."""
+    tgt, src = scene
+    a, oa = both(gmod, tgt, src)
+    b, ob = both(gmod, tgt[::2], src[::3])
+    a.align()
+    b.align()
+    Ta, Tb = a.getFinalTransformation(), b.getFinalTransformation()
+    assert trans_err(Ta, oa.align()["T"]) < TRANS_TOL and trans_err(Tb, ob.align()["T"]) < TRANS_TOL
+    a.setInputSource(src[::3])
+    a.setInputTarget(tgt[::2])
+    a.align()
+    assert np.array_equal(a.getFinalTransformation(), Tb)

@@ -370,7 +370,10 @@ bool estimate(const Params& prm, Backend& dev, Result& stats, float transformati
   bfgs.init(x);
   if (!fn.ok()) return false;
   stats.correspondences = static_cast<int>(fn.count());
-  if (stats.correspondences < 4) return false;  // NotEnoughPointsException
+  if (stats.correspondences < 4) {  // NotEnoughPointsException: thrown before the reference evaluates anything
+    stats.n_fdf--;
+    return false;
+  }
   const double gradient_tol = 1e-2;
   int inner = 0;
   int result = kRunning;
