@@ -1,9 +1,9 @@
-// apps/align.cpp -- the NDT part of the reference's benchmark program (ndt_omp/apps/align.cpp) written
-// against the C-ABI alone (no PCL, no ROS): load two PCD files, 0.1 m VoxelGrid down-sample, then for
-// KDTREE / DIRECT7 / DIRECT1 at resolution 1.0 and class defaults: one registration timed, ten more
-// timed, and the fitness score -- the three numbers per method the reference prints and its README
-// tabulates (ndt_omp/README.md:13-46).  GICP, pcl::NDT and the visualiser of the original are not part
-// of the hot path and are not here.
+// apps/align.cpp -- the pclomp part of the reference's benchmark program (ndt_omp/apps/align.cpp) written
+// against the C-ABI alone (no PCL, no ROS): load two PCD files, 0.1 m VoxelGrid down-sample, then GICP at
+// class defaults (align.cpp:84-86) and NDT with KDTREE / DIRECT7 / DIRECT1 at resolution 1.0 (:88-105): one
+// registration timed, ten more timed, and the fitness score -- the three numbers per method the reference
+// prints and its README tabulates (ndt_omp/README.md:13-46).  The stock pcl::GICP / pcl::NDT runs and the
+// visualiser of the original are not here.
 //
 //   align target.pcd source.pcd [leaf_size (0.1; 0 = no down-sample)]
 #include <chrono>
@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "gicp_mi355.h"
 #include "ndt_mi355.h"
 
 #define CHECK(call)                                                          \
@@ -57,11 +58,41 @@ int main(int argc, char** argv) {
   std::vector<Pt> target, source;
   if (load(h, argv[1], leaf, target) || load(h, argv[2], leaf, source)) return 1;
 
-  CHECK(ndt_set_resolution(h, 1.0f));  // align.cpp:96
-  const struct { const char* name; int method; } methods[] = {{"KDTREE", NDT_KDTREE}, {"DIRECT7", NDT_DIRECT7}, {"DIRECT1", NDT_DIRECT1}};
   using clock = std::chrono::steady_clock;
   auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   std::vector<Pt> aligned(source.size() ? source.size() : 1);
+  {  // align.cpp:84-86
+    std::printf("--- gicp_mi355 ---\n");
+    gicp_handle g = nullptr;
+    CHECK(gicp_create(0, &g));
+    CHECK(gicp_set_input_target(g, target.data(), target.size(), sizeof(Pt)));
+    CHECK(gicp_set_input_source(g, source.data(), source.size(), sizeof(Pt)));
+    float T[16];
+    int converged = 0, iterations = 0;
+    const auto t1 = clock::now();
+    CHECK(gicp_align(g, nullptr, T, &converged, &iterations, aligned.data()));
+    const auto t2 = clock::now();
+    std::printf("single : %.3f[msec]\n", ms(t1, t2));
+    for (int i = 0; i < 10; i++) CHECK(gicp_align(g, nullptr, T, &converged, &iterations, aligned.data()));
+    const auto t3 = clock::now();
+    std::printf("10times: %.3f[msec]\n", ms(t2, t3));
+    double fitness = 0;
+    CHECK(gicp_get_fitness_score(g, DBL_MAX, &fitness));
+    std::printf("fitness: %.6g\n", fitness);
+    int n_f = 0, n_df = 0, n_fdf = 0, corr = 0;
+    CHECK(gicp_get_stats(g, &n_f, &n_df, &n_fdf, &corr));
+    std::printf("converged: %d  iterations: %d  objective evaluations: %d  correspondences: %d\n", converged, iterations,
+                n_f + n_df + n_fdf, corr);
+    std::printf("T:");
+    for (int r = 0; r < 4; r++) {
+      for (int c = 0; c < 4; c++) std::printf(" %.9g", T[c * 4 + r]);
+      std::printf(r < 3 ? " |" : "\n\n");
+    }
+    gicp_destroy(g);
+  }
+
+  CHECK(ndt_set_resolution(h, 1.0f));  // align.cpp:96
+  const struct { const char* name; int method; } methods[] = {{"KDTREE", NDT_KDTREE}, {"DIRECT7", NDT_DIRECT7}, {"DIRECT1", NDT_DIRECT1}};
   for (const auto& m : methods) {
     std::printf("--- ndt_mi355 (%s) ---\n", m.name);
     CHECK(ndt_set_neighborhood_search_method(h, m.method));

@@ -2,6 +2,7 @@
 // lidar_subscriber/src/ndt_omp_mapping_node.cpp:151-169, compiled against include/pclomp/ndt_omp.h
 // (with the PCL stand-ins of tests/pcl_stub) and linked to libndt_mi355.so.
 //   adapter_harness target.f32 n_target source.f32 n_source   (xyz float32 triples)
+#include <pclomp/gicp_omp.h>
 #include <pclomp/ndt_omp.h>
 
 #include <cstdio>
@@ -77,5 +78,17 @@ int main(int argc, char** argv) {
   std::printf("trans_probability %.12g\n", copy.getTransformationProbability());
   // ndt_rosbag_mapping_node.cpp:133 prints the fitness of the derived object
   std::printf("fitness %.12g\n", copy.getFitnessScore());
+
+  // apps/align.cpp:84-86 -- pclomp::GICP through the pcl::Registration base pointer
+  typedef pclomp::GeneralizedIterativeClosestPoint<PointT, PointT> GICP;
+  GICP::Ptr gicp_omp(new GICP());
+  pcl::Registration<PointT, PointT>::Ptr reg2 = gicp_omp;
+  reg2->setInputTarget(target);
+  reg2->setInputSource(source);
+  pcl::PointCloud<PointT>::Ptr aligned3(new pcl::PointCloud<PointT>());
+  reg2->align(*aligned3);
+  print("gicp_app", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
+  std::printf("gicp_aligned0 %.9g %.9g %.9g %.9g\n", aligned3->points[0].x, aligned3->points[0].y, aligned3->points[0].z, aligned3->points[0].pad);
+  std::printf("gicp_fitness %.12g\n", gicp_omp->getFitnessScore());
   return 0;
 }

@@ -3,7 +3,9 @@
 // compile- and run-checked here.  Written from the public API documentation, not from PCL source;
 // they are NOT part of the product and are never installed.
 #pragma once
+#include <cmath>
 #include <cstdio>
+#include <limits>
 #include <cstring>
 #include <memory>
 #include <string>

@@ -12,6 +12,17 @@ INC = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", 
 SRC = os.path.join(ROOT, "tests", "adapter_harness.cpp")
 
 
+def test_gicp_adapter_declares_reference_surface():
+    """public surface of pclomp::GeneralizedIterativeClosestPoint (gicp_omp.h:52-260) that its caller
+    (apps/align.cpp:84-86) and PCL-style user code touch."""
+    hdr = open(os.path.join(ROOT, "include", "pclomp", "gicp_omp.h")).read()
+    for name in ["class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<PointSource, PointTarget>",
+                 "setInputSource", "setInputTarget", "setRotationEpsilon", "getRotationEpsilon", "setCorrespondenceRandomness",
+                 "getCorrespondenceRandomness", "setMaximumOptimizerIterations", "getMaximumOptimizerIterations",
+                 "computeTransformation", "max_iterations_ = 200", "transformation_epsilon_ = 5e-4", "corr_dist_threshold_ = 5."]:
+        assert name in hdr, name
+
+
 def test_adapter_header_compiles():
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + INC + [SRC])
 
@@ -76,6 +87,20 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
     assert float(rows["fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-5)
 
+    # pclomp::GICP through the pcl::Registration pointer (apps/align.cpp:84-86)
+    og = po.OracleGICP()
+    og.setInputTarget(t)
+    og.setInputSource(s)
+    rg = og.align(want_cloud=True)
+    conv, _, Tg = parse("gicp_app")
+    assert conv == int(rg["converged"]) == 1
+    assert rot_err(Tg, rg["T"]) < 1e-4 and trans_err(Tg, rg["T"]) < 1e-3
+    g0 = np.array([float(x) for x in rows["gicp_aligned0"].split()])
+    assert g0[3] == 1.0 and np.allclose(g0[:3], rg["cloud"][0, :3], atol=1e-3)
+    moved = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)].astype(np.float32), Tg.astype(np.float32))[:, :3]
+    d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
+    assert float(rows["gicp_fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-4)
+
 
 @pytest.mark.gpu
 def test_align_app_reproduces_readme_table(built_lib, pair, golden, tmp_path):
@@ -92,6 +117,9 @@ def test_align_app_reproduces_readme_table(built_lib, pair, golden, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "align.cpp"),
                            "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([exe, tp, sp, "0"], text=True)
+    gblock = out.split("--- gicp_mi355 ---")[1].split("--- ndt_mi355 (")[0]
+    gf = {ln.split(":")[0].strip(): ln.split(":", 1)[1].strip() for ln in gblock.splitlines() if ":" in ln}
+    assert gf["converged"].startswith("1") and 0 < float(gf["fitness"]) < 0.25
     blocks = out.split("--- ndt_mi355 (")[1:]
     assert [b.split(")")[0] for b in blocks] == ["KDTREE", "DIRECT7", "DIRECT1"]
     for b in blocks:

@@ -1,0 +1,43 @@
+"""GICP row timings on the GPU: index build, covariances, steady-state align; optional oracle time beside it.
+usage: time_gicp.py [pair | N_TARGET N_SOURCE] [--oracle]"""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+from toyslam_amd import clouds, gicp
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+if not args or args[0] == "pair":
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pair_0p1.npz"))
+    tgt, src, name = d["target"], d["source"], "reference pair after the 0.1 m prefilter"
+else:
+    nt, ns = int(args[0]), int(args[1])
+    tgt = clouds.target_surfaces(nt)[:, :3].astype(np.float32)
+    src = clouds.source_from_target(tgt, ns)[:, :3].astype(np.float32)
+    name = "synthetic surfaces %d / %d" % (nt, ns)
+g = gicp.GeneralizedIterativeClosestPoint()
+g.setInputTarget(tgt[:64]); g.setInputSource(src[:64]); g.align()  # runtime warm-up
+def med(f, n=5):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+t_tgt = med(lambda: g.setInputTarget(tgt))
+t_src = med(lambda: g.setInputSource(src))
+def first():
+    g.setInputTarget(tgt); g.setInputSource(src); g.align()
+t_first = med(first, 3)
+t_align = med(lambda: g.align(), 7)
+st = g.stats()
+out = {"workload": name, "n_target": len(tgt), "n_source": len(src), "set_target_ms": t_tgt, "set_source_ms": t_src,
+       "first_align_incl_inputs_and_covariances_ms": t_first, "align_ms": t_align, "iterations": g.getFinalNumIteration(),
+       "evaluations": st["n_f"] + st["n_df"] + st["n_fdf"], "us_per_evaluation_incl_correspondence_steps": 1e3 * t_align / max(1, st["n_f"] + st["n_df"] + st["n_fdf"]),
+       "fitness": g.getFitnessScore()}
+if "--oracle" in sys.argv:
+    from oracle import pyoracle as po
+    o = po.OracleGICP(); o.setInputTarget(tgt); o.setInputSource(src)
+    t0 = time.perf_counter(); r = o.align(); out["oracle_first_align_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); r = o.align(); out["oracle_align_ms"] = (time.perf_counter() - t0) * 1e3
+    out["oracle_threads"] = os.cpu_count()
+    out["T_max_abs_diff_vs_oracle"] = float(np.abs(g.getFinalTransformation() - r["T"]).max())
+print(json.dumps(out))

@@ -22,8 +22,8 @@ using namespace ndt;
 
 namespace {
 
-constexpr int kKnnBlock = 64;   // one wave per block: the candidate lists take k * 512 B of LDS
-constexpr int kKnnMaxRing = 8;  // beyond this many shells: one scan over all points
+constexpr int kKnnBlock = 64;   // one wave = 8 query teams per block: the candidate lists take k * 544 B of LDS
+constexpr int kKnnMaxRing = 8;  // shells every query may try (see max_shells) before one scan over all points
 
 // [Eigen] Matrix4f * Vector4f (column by column): row r = ((T_r0 x + T_r1 y) + T_r2 z) + T_r3 * 1
 __device__ __forceinline__ void matvec_eigen(const float* T12, float x, float y, float z, float& ox, float& oy, float& oz) {
@@ -40,47 +40,152 @@ __device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, 
   ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
 }
 
-// visits the occupied cells of shell r around (ci, cj, ck)
+// Points in cell order (sorted_pts[q] = pts[sorted_idx[q]]): the candidates of a cell are consecutive
+// 16-byte records, so a scan issues several loads at once instead of chasing index -> point one
+// candidate at a time (with ~16k queries the chip is nearly empty and a query's time is its chain of
+// load latencies).
+__global__ __launch_bounds__(kBlock) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ sorted_idx,
+                                                          const unsigned* __restrict__ d_n_sorted, float4* __restrict__ out) {
+  const int n = static_cast<int>(*d_n_sorted);
+  for (int q = blockIdx.x * kBlock + threadIdx.x; q < n; q += gridDim.x * kBlock) out[q] = pts[sorted_idx[q]];
+}
+
+// ---------------------------------------------------------------------------
+// Team search.  A query is worked on by kTeam = 8 adjacent lanes: they look up the same cell and
+// stride over its points, each lane keeping its own best / its own sorted candidate list, and the
+// team combines them with three xor-shuffles.  With a thread per query the few 10^4 queries of a
+// down-sampled scan leave the chip almost empty and every query is one long chain of load
+// latencies (measured on the reference pair: 2 ms per correspondence step, 4 ms per covariance
+// pass); teams cut the chain eightfold and give the machine eight times the waves.
+// ---------------------------------------------------------------------------
+constexpr int kTeam = 8;
+
+// squared distances from (qx,qy,qz) to this lane's share of the `count` cell-ordered points starting at
+// `first` (positions sub, sub + 8, ...), two loads in flight; visit(d, position in the cell order)
 template <class F>
-__device__ __forceinline__ void for_shell(const PointIndex& ix, int ci, int cj, int ck, int r, F&& visit) {
+__device__ __forceinline__ void scan_run(const float4* __restrict__ sp, unsigned first, int count, int sub, float qx, float qy,
+                                         float qz, F&& visit) {
+  int p = sub;
+  for (; p + kTeam < count; p += 2 * kTeam) {
+    const float4 a = sp[first + p], b = sp[first + p + kTeam];
+    const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
+    visit(da, first + p);
+    visit(db, first + p + kTeam);
+  }
+  if (p < count) {
+    const float4 a = sp[first + p];
+    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), first + p);
+  }
+}
+
+// the exhaustive scan of a query without near neighbours: this lane's share of all points, four loads in flight
+template <class F>
+__device__ __forceinline__ void scan_all(const float4* __restrict__ sp, int count, int sub, float qx, float qy, float qz, F&& visit) {
+  int p = sub;
+  for (; p + 3 * kTeam < count; p += 4 * kTeam) {
+    const float4 a = sp[p], b = sp[p + kTeam], c = sp[p + 2 * kTeam], d = sp[p + 3 * kTeam];
+    const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
+    const float dc = dist2_f32(qx, qy, qz, c.x, c.y, c.z), dd = dist2_f32(qx, qy, qz, d.x, d.y, d.z);
+    visit(da, static_cast<unsigned>(p));
+    visit(db, static_cast<unsigned>(p + kTeam));
+    visit(dc, static_cast<unsigned>(p + 2 * kTeam));
+    visit(dd, static_cast<unsigned>(p + 3 * kTeam));
+  }
+  for (; p < count; p += kTeam) {
+    const float4 a = sp[p];
+    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), static_cast<unsigned>(p));
+  }
+}
+
+// lexicographic minimum of (d, idx) over the 8 lanes of a team
+__device__ __forceinline__ void team_min(float& d, int& idx) {
+#pragma unroll
+  for (int off = 1; off < kTeam; off <<= 1) {
+    const float od = __shfl_xor(d, off, kWave);
+    const int oi = __shfl_xor(idx, off, kWave);
+    if (od < d || (od == d && oi < idx)) {
+      d = od;
+      idx = oi;
+    }
+  }
+}
+__device__ __forceinline__ int team_sum(int v) {
+#pragma unroll
+  for (int off = 1; off < kTeam; off <<= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Shell r of cells around (ci, cj, ck), worked on by a team: the (2r+1)^2 rows of the shell are dealt out
+// to the eight lanes, each lane probes one cell of its row per step (face rows: every x; interior rows:
+// only x = -r and x = +r), and every occupied cell any lane finds is then scanned by the whole team.
+// consider(d, position) as in scan_run.  All control flow is uniform within the team.
+template <class F>
+__device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj, int ck, int r, int sub, float qx, float qy,
+                                           float qz, F&& consider) {
   const GridGeom& g = ix.geom;
-  for (int dz = -r; dz <= r; dz++) {
-    const int z = ck + dz;
-    if (z < 0 || z >= g.div_b[2]) continue;
-    for (int dy = -r; dy <= r; dy++) {
-      const int y = cj + dy;
-      if (y < 0 || y >= g.div_b[1]) continue;
-      const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-      const int step = face ? 1 : max(2 * r, 1);  // interior rows of the shell: only dx = -r and dx = +r
-      for (int dx = -r; dx <= r; dx += step) {
-        const int x = ci + dx;
-        if (x < 0 || x >= g.div_b[0]) continue;
-        const int lf = ix.cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
-        if (lf >= 0) visit(lf);
+  const int w = 2 * r + 1, rows = w * w;
+  const int team_base = (threadIdx.x & (kWave - 1)) & ~(kTeam - 1);
+  for (int row0 = 0; row0 < rows; row0 += kTeam) {
+    const int row = row0 + sub;
+    const int dz = row / w - r, dy = row % w - r;
+    const int z = ck + dz, y = cj + dy;
+    const bool row_ok = row < rows && z >= 0 && z < g.div_b[2] && y >= 0 && y < g.div_b[1];
+    if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
+    const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
+    const int nx = face ? w : 2;
+    for (int t = 0; t < w; t++) {
+      int lf = -1;
+      if (row_ok && t < nx) {
+        const int x = ci + (face ? t - r : (t == 0 ? -r : r));
+        if (x >= 0 && x < g.div_b[0]) lf = ix.cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+      }
+      unsigned first = 0;
+      int count = 0;
+      if (lf >= 0) {
+        first = ix.leaf_start[lf];
+        count = ix.leaf_count[lf];
+      }
+      unsigned found = static_cast<unsigned>((__ballot(lf >= 0) >> team_base) & 0xffull);
+      while (found) {
+        const int owner = __builtin_ctz(found);
+        found &= found - 1;
+        const unsigned fs = __shfl(first, team_base + owner, kWave);
+        const int fc = __shfl(count, team_base + owner, kWave);
+        scan_run(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
       }
     }
   }
+}
+
+// shells tried before a query falls back to one scan over all points: while probing the shells costs
+// less than that scan
+__device__ __forceinline__ int max_shells(const PointIndex& ix, int r_lim) {
+  const int by_cost = (static_cast<int>(cbrtf(static_cast<float>(ix.n_sorted))) - 1) / 2;  // (2r+1)^3 probes ~ n points
+  return min(r_lim, max(kKnnMaxRing, by_cost));
 }
 
 __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, int k, double gicp_epsilon,
                                                                double* __restrict__ cov6, int* __restrict__ nn_idx,
                                                                float* __restrict__ nn_d2) {
 #pragma clang fp contract(off)
+  constexpr int kTeams = kKnnBlock / kTeam;
   extern __shared__ unsigned char knn_lds[];
-  float* sd = reinterpret_cast<float*>(knn_lds);         // [k][64] distances, ascending per lane
-  int* si = reinterpret_cast<int*>(sd + k * kKnnBlock);  // [k][64] point indices
-  const int lane = threadIdx.x;
+  float* sd = reinterpret_cast<float*>(knn_lds);         // [k][64] this lane's candidates: distances, ascending
+  int* si = reinterpret_cast<int*>(sd + k * kKnnBlock);  // [k][64] and their point indices
+  int* merged = si + k * kKnnBlock;                      // [k][8]  the team's k nearest, in order
+  const int lane = threadIdx.x, sub = lane & (kTeam - 1), team = lane / kTeam;
   const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
-  for (int i = blockIdx.x * kKnnBlock + lane; i < ix.n; i += gridDim.x * kKnnBlock) {
+  const int r_max = max_shells(ix, r_lim);
+  for (int i = blockIdx.x * kTeams + team; i < ix.n; i += gridDim.x * kTeams) {  // i is uniform within a team
     const float4 q = ix.pts[i];
-    int cnt = 0;
+    int cnt = 0;  // this lane's list length
     float worst = INFINITY;
     int worst_i = 0x7fffffff;
-    auto consider = [&](int idx) {
-      const float4 t = ix.pts[idx];
-      const float d = dist2_f32(q.x, q.y, q.z, t.x, t.y, t.z);
-      if (cnt == k && (d > worst || (d == worst && idx > worst_i))) return;
+    auto consider = [&](float d, unsigned pos) {
+      if (cnt == k && d > worst) return;
+      const int idx = ix.sorted_idx[pos];
+      if (cnt == k && d == worst && idx > worst_i) return;
       int j = (cnt < k) ? cnt++ : k - 1;
       while (j > 0) {
         const float pd = sd[(j - 1) * kKnnBlock + lane];
@@ -100,33 +205,44 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
     int ci, cj, ck;
     query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck);
     bool done = false;
-    for (int r = 0; r <= kKnnMaxRing && !done; r++) {
-      for_shell(ix, ci, cj, ck, r, [&](int lf) {
-        const unsigned s0 = ix.leaf_start[lf];
-        const int c = ix.leaf_count[lf];
-        for (int p = 0; p < c; p++) consider(ix.sorted_idx[s0 + p]);
-      });
-      // every unvisited point is at least r cells (less the index-rounding slack) away; strict, so a
-      // tie at the k-th distance with a lower index cannot be missed
+    for (int r = 0; r <= r_max && !done; r++) {
+      team_shell(ix, ci, cj, ck, r, sub, q.x, q.y, q.z, consider);
+      // Every unvisited point is at least r cells (less the index-rounding slack) away.  Once k visited
+      // candidates lie strictly inside that reach no unvisited point can enter the k nearest: a candidate
+      // a lane has dropped was beaten by k better ones of the same lane, so counting the lists is enough.
       const float reach = static_cast<float>(r) * leaf - ix.slack;
-      if ((cnt == k && reach > 0.0f && worst < reach * reach) || r >= r_lim) done = true;
+      int inside = 0;
+      if (reach > 0.0f)
+        for (int j = 0; j < cnt && sd[j * kKnnBlock + lane] < reach * reach; j++) inside++;
+      if (team_sum(inside) >= k || r >= r_lim) done = true;
     }
-    if (!done) {  // sparse neighbourhood: scan everything
+    if (!done) {  // sparse neighbourhood: the team scans everything
       cnt = 0;
       worst = INFINITY;
       worst_i = 0x7fffffff;
-      for (int p = 0; p < ix.n_sorted; p++) consider(ix.sorted_idx[p]);
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, consider);
     }
-    if (nn_idx) {
-      for (int j = 0; j < k; j++) {
-        nn_idx[static_cast<size_t>(i) * k + j] = (j < cnt) ? si[j * kKnnBlock + lane] : -1;
-        nn_d2[static_cast<size_t>(i) * k + j] = (j < cnt) ? sd[j * kKnnBlock + lane] : INFINITY;
+    // k-way merge of the eight sorted lists: k rounds of "smallest head wins"
+    int head = 0;
+    for (int j = 0; j < k; j++) {
+      float d = (head < cnt) ? sd[head * kKnnBlock + lane] : INFINITY;
+      int idx = (head < cnt) ? si[head * kKnnBlock + lane] : 0x7fffffff;
+      const float my_d = d;
+      const int my_i = idx;
+      team_min(d, idx);
+      if (head < cnt && my_d == d && my_i == idx) head++;  // (distance, index) pairs are unique: one winner
+      if (sub == 0) {
+        merged[j * kTeams + team] = idx;
+        if (nn_idx) {
+          nn_idx[static_cast<size_t>(i) * k + j] = (idx == 0x7fffffff) ? -1 : idx;
+          nn_d2[static_cast<size_t>(i) * k + j] = d;
+        }
       }
     }
+    if (sub != 0) continue;  // the 3x3 algebra of a query is one lane's work
     // :81-105  f32 products, f64 sums, neighbours in ascending distance
     double mx = 0, my = 0, mz = 0, cxx = 0, cyx = 0, cyy = 0, czx = 0, czy = 0, czz = 0;
-    for (int j = 0; j < cnt; j++) {
-      const float4 t = ix.pts[si[j * kKnnBlock + lane]];
+    auto add = [&](const float4& t) {
       mx += static_cast<double>(t.x);
       my += static_cast<double>(t.y);
       mz += static_cast<double>(t.z);
@@ -136,7 +252,18 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       czx += static_cast<double>(t.z * t.x);
       czy += static_cast<double>(t.z * t.y);
       czz += static_cast<double>(t.z * t.z);
+    };
+    // (an index can only be missing if the cloud had fewer than k points, which the host refuses; clamped anyway)
+    auto fetch = [&](int j) { return ix.pts[min(merged[j * kTeams + team], ix.n - 1)]; };
+    int j = 0;
+    for (; j + 4 <= k; j += 4) {  // four gathers in flight, added in order
+      const float4 t0 = fetch(j), t1 = fetch(j + 1), t2 = fetch(j + 2), t3 = fetch(j + 3);
+      add(t0);
+      add(t1);
+      add(t2);
+      add(t3);
     }
+    for (; j < k; j++) add(fetch(j));
     const double kd = static_cast<double>(k);
     mx /= kd;
     my /= kd;
@@ -182,18 +309,21 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
                                                        const double* __restrict__ cov_tgt6, double dist_threshold,
                                                        int* __restrict__ corr, float* __restrict__ maha9) {
 #pragma clang fp contract(off)
+  constexpr int kTeams = kBlock / kTeam;
+  const int sub = threadIdx.x & (kTeam - 1);
   const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  const int r_max = max_shells(ix, r_lim);
+  for (int i = blockIdx.x * kTeams + threadIdx.x / kTeam; i < n; i += gridDim.x * kTeams) {  // uniform within a team
     const float4 p = output[i];
     float qx, qy, qz;
     matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
-    float best = INFINITY;
-    int best_i = -1;
-    auto consider = [&](int idx) {
-      const float4 t = ix.pts[idx];
-      const float d = dist2_f32(qx, qy, qz, t.x, t.y, t.z);
-      if (d < best || (d == best && idx < best_i)) {
+    float best = INFINITY;  // this lane's share
+    int best_i = 0x7fffffff;
+    auto consider = [&](float d, unsigned pos) {
+      if (d > best) return;
+      const int idx = ix.sorted_idx[pos];
+      if (d < best || idx < best_i) {  // equal distance: the lower index
         best = d;
         best_i = idx;
       }
@@ -201,25 +331,34 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
     int ci, cj, ck;
     query_cell(ix.geom, qx, qy, qz, ci, cj, ck);
     bool done = false;
-    for (int r = 0; r <= kKnnMaxRing && !done; r++) {
-      for_shell(ix, ci, cj, ck, r, [&](int lf) {
-        const unsigned s0 = ix.leaf_start[lf];
-        const int c = ix.leaf_count[lf];
-        for (int q = 0; q < c; q++) consider(ix.sorted_idx[s0 + q]);
-      });
+    float tb = INFINITY;  // the team's best
+    int tb_i = 0x7fffffff;
+    for (int r = 0; r <= r_max && !done; r++) {
+      team_shell(ix, ci, cj, ck, r, sub, qx, qy, qz, consider);
+      tb = best;
+      tb_i = best_i;
+      team_min(tb, tb_i);
       const float reach = static_cast<float>(r) * leaf - ix.slack;
-      if ((best_i >= 0 && reach > 0.0f && best < reach * reach) || r >= r_lim) done = true;
+      if ((tb_i != 0x7fffffff && reach > 0.0f && tb < reach * reach) || r >= r_lim) done = true;
+      // nothing closer than the gate is left once the shells reach past it: no correspondence either way
+      if (reach > 0.0f && static_cast<double>(reach) * static_cast<double>(reach) >= dist_threshold &&
+          !(static_cast<double>(tb) < dist_threshold))
+        done = true;
     }
     if (!done) {
       best = INFINITY;
-      best_i = -1;
-      for (int q = 0; q < ix.n_sorted; q++) consider(ix.sorted_idx[q]);
+      best_i = 0x7fffffff;
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, consider);
+      tb = best;
+      tb_i = best_i;
+      team_min(tb, tb_i);
     }
+    if (sub != 0) continue;
     int c_out = -1;
-    if (best_i >= 0 && static_cast<double>(best) < dist_threshold) {  // :436
+    if (tb_i != 0x7fffffff && static_cast<double>(tb) < dist_threshold) {  // :436
       double C1[3][3], C2[3][3], M[3][3], tmp[3][3], inv[3][3];
       load_sym(cov_src6 + static_cast<size_t>(i) * 6, C1);
-      load_sym(cov_tgt6 + static_cast<size_t>(best_i) * 6, C2);
+      load_sym(cov_tgt6 + static_cast<size_t>(tb_i) * 6, C2);
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) M[r][c] = (R.m[r * 3] * C1[0][c] + R.m[r * 3 + 1] * C1[1][c]) + R.m[r * 3 + 2] * C1[2][c];
       for (int r = 0; r < 3; r++)
@@ -228,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
       inv3_cofactor(tmp, inv);
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) maha9[static_cast<size_t>(i) * 9 + r * 3 + c] = static_cast<float>(inv[r][c]);
-      c_out = best_i;
+      c_out = tb_i;
     }
     corr[i] = c_out;
   }
@@ -325,11 +464,19 @@ __global__ __launch_bounds__(kBlock) void k_functor(const float4* __restrict__ o
 
 }  // namespace
 
+hipError_t launch_gather_points(const float4* pts, const int* sorted_idx, const unsigned* d_n_sorted, int n_max, float4* out,
+                                hipStream_t stream) {
+  const int blocks = max(1, min(2048, (n_max + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_gather_points, dim3(blocks), dim3(kBlock), 0, stream, pts, sorted_idx, d_n_sorted, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_knn_covariances(const PointIndex& ix, int k, double gicp_epsilon, double* cov6, int* nn_idx, float* nn_d2,
                                   hipStream_t stream) {
   if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
-  const int blocks = max(1, min(8192, (ix.n + kKnnBlock - 1) / kKnnBlock));
-  const size_t lds = static_cast<size_t>(k) * kKnnBlock * 8;
+  constexpr int kQueriesPerBlock = kKnnBlock / kTeam;
+  const int blocks = max(1, min(65536, (ix.n + kQueriesPerBlock - 1) / kQueriesPerBlock));
+  const size_t lds = static_cast<size_t>(k) * (kKnnBlock * 8 + kQueriesPerBlock * 4);
   hipLaunchKernelGGL(k_knn_covariances, dim3(blocks), dim3(kKnnBlock), lds, stream, ix, k, gicp_epsilon, cov6, nn_idx, nn_d2);
   return hipGetLastError();
 }
@@ -339,7 +486,8 @@ hipError_t launch_correspond(const float4* output, int n, const float* T12, cons
                              hipStream_t stream) {
   EvalParams P{};
   for (int i = 0; i < 12; i++) P.T[i] = T12[i];
-  const int blocks = max(1, min(4096, (n + kBlock - 1) / kBlock));
+  constexpr int kQueriesPerBlock = kBlock / kTeam;
+  const int blocks = max(1, min(32768, (n + kQueriesPerBlock - 1) / kQueriesPerBlock));
   hipLaunchKernelGGL(k_correspond, dim3(blocks), dim3(kBlock), 0, stream, output, n, P, R, tgt, cov_src6, cov_tgt6,
                      dist_threshold, corr, maha9);
   return hipGetLastError();

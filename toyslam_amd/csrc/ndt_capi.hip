@@ -249,6 +249,7 @@ struct ndt_context {
   DevBuf<float4> map_pts;
   size_t map_n = 0;
   int map_dense = 1;
+  bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
   // Two command mailboxes, used by alternate server instances: a server told to finish (transform +
   // exit) is not waited for, and the next instance's first command must not overwrite the line the
@@ -672,6 +673,7 @@ ndt_status build_grid(ndt_context* h) {
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
   HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, sizeof(unsigned), st));
   ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!h->index_only)
   HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
                                static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
                                g->lut.p, g->counts.p + 3, nodump, st, g->counts.p));
