@@ -15,8 +15,8 @@ ROT_TOL, TRANS_TOL = 1e-4, 1e-3
 
 
 @pytest.fixture(scope="module")
-def gmod():
-    import torch  # noqa: F401  the GPU runtime is initialised before the library
+def gmod(built_lib):
+    assert built_lib.ndt_device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
     from toyslam_amd import gicp
     return gicp
 

@@ -746,7 +746,13 @@ def test_device_resident_entry_points_equal_host_ones(mods, pair):
     import ctypes as C
     ndt, po, clouds = mods
     t, s = pair
-    hip = C.CDLL("libamdhip64.so")
+    # the HIP runtime the library itself is linked to (a process that has imported torch also holds torch's
+    # bundled copy, a second runtime instance that does not own the device)
+    import re
+    from toyslam_amd import _lib
+    linked = [m.group(1) for m in re.finditer(r"(/\S*libamdhip64\.so[.\d]*)", open("/proc/self/maps").read()) if "/torch/" not in m.group(1)]
+    hip = C.CDLL(linked[0] if linked else "libamdhip64.so")
+    assert _lib.lib() is not None
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipFree.argtypes = [C.c_void_p]
@@ -755,7 +761,12 @@ def test_device_resident_entry_points_equal_host_ones(mods, pair):
     def to_device(a):  # (N, 4) float32 -> device pointer
         a = np.ascontiguousarray(a, dtype=np.float32)
         p = C.c_void_p()
-        assert hip.hipMalloc(C.byref(p), max(a.nbytes, 16)) == 0
+        rc = hip.hipMalloc(C.byref(p), max(a.nbytes, 16))
+        if rc != 0:
+            dev, cnt = C.c_int(-1), C.c_int(-1)
+            r1, r2 = hip.hipGetDevice(C.byref(dev)), hip.hipGetDeviceCount(C.byref(cnt))
+            raise AssertionError("hipMalloc -> %d; hipGetDevice -> %d (%d); hipGetDeviceCount -> %d (%d); lib %s" %
+                                 (rc, r1, dev.value, r2, cnt.value, [l.split()[-1] for l in open("/proc/self/maps") if "amdhip64" in l][:4]))
         assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
         held.append(p)
         return p.value

@@ -18,7 +18,6 @@ struct gicp_context {
   bool have_tgt = false, have_src = false;
   bool have_cov_tgt = false, have_cov_src = false;
   DevBuf<double> cov_tgt, cov_src;  // [n][6]
-  DevBuf<float4> sorted_tgt, sorted_src;  // the clouds in the cell order of their index
   DevBuf<float4> output;            // the source moved by the guess
   DevBuf<int> corr;
   DevBuf<float> maha;
@@ -41,7 +40,7 @@ struct gicp_context {
       (void)hipStreamSynchronize(tgt.stream);
       tls_pool_stream = tgt.stream;
     }
-    cov_tgt.release(); cov_src.release(); sorted_tgt.release(); sorted_src.release(); output.release(); corr.release(); maha.release(); partials.release();
+    cov_tgt.release(); cov_src.release(); output.release(); corr.release(); maha.release(); partials.release();
     counter.release(); out_cloud.release(); nn_idx.release(); nn_d2.release();
     if (host_pub) (void)hipHostFree(host_pub);
   }
@@ -111,19 +110,9 @@ ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t st
   return ensure_cell2leaf(c, c->grid.get());
 }
 
-gicp::PointIndex gicp_index_of(const ndt_context* c, const DevBuf<float4>& sorted) {
-  const DeviceGrid* g = c->grid.get();
+gicp::PointIndex gicp_index_of(const ndt_context* c) {
   gicp::PointIndex ix;
-  ix.pts = c->target->pts.p;
-  ix.n = static_cast<int>(c->target->n);
-  ix.geom = g->geom;
-  ix.cell2leaf = g->cell2leaf.p;
-  ix.leaf_start = g->leaf_start.p;
-  ix.leaf_count = g->leaf_count.p;
-  ix.sorted_idx = g->sorted_idx.p;
-  ix.sorted_pts = sorted.p;
-  ix.n_sorted = static_cast<int>(g->n_sorted);
-  ix.slack = index_slack(g);
+  fill_point_index(c->grid.get(), ix);
   return ix;
 }
 
@@ -168,7 +157,7 @@ ndt_status gicp_cloud_covariances(gicp_context* h, int which, bool want_neighbor
     HIP_TRY(h->nn_idx.reserve(n * static_cast<size_t>(k)));
     HIP_TRY(h->nn_d2.reserve(n * static_cast<size_t>(k)));
   }
-  HIP_TRY(gicp::launch_knn_covariances(gicp_index_of(c, which == 0 ? h->sorted_tgt : h->sorted_src), k, h->prm.gicp_epsilon, cov.p, want_neighbors ? h->nn_idx.p : nullptr,
+  HIP_TRY(gicp::launch_knn_covariances(gicp_index_of(c), k, h->prm.gicp_epsilon, cov.p, want_neighbors ? h->nn_idx.p : nullptr,
                                        want_neighbors ? h->nn_d2.p : nullptr, h->tgt.stream));
   have = true;
   return NDT_OK;
@@ -203,7 +192,7 @@ struct GicpDevice : gicp::Backend {
     for (int i = 0; i < 9; i++) rot.m[i] = R[i];
     const double thr = h->prm.corr_dist_threshold * h->prm.corr_dist_threshold;  // :401
     const hipError_t e = gicp::launch_correspond(h->output.p, static_cast<int>(h->src.target->n), transformation, rot,
-                                                 gicp_index_of(&h->tgt, h->sorted_tgt), h->cov_src.p, h->cov_tgt.p, thr, h->corr.p, h->maha.p,
+                                                 gicp_index_of(&h->tgt), h->cov_src.p, h->cov_tgt.p, thr, h->corr.p, h->maha.p,
                                                  h->tgt.stream);
     if (e != hipSuccess) {
       error = std::string("correspondence kernel: ") + hipGetErrorString(e);
@@ -313,9 +302,6 @@ ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_
   }
   const ndt_status s = gicp_build_index(&h->tgt, pts, n, stride_bytes);
   if (s) return s;
-  HIP_TRY(h->sorted_tgt.reserve(n));
-  HIP_TRY(gicp::launch_gather_points(h->tgt.target->pts.p, h->tgt.grid->sorted_idx.p, h->tgt.grid->counts.p, static_cast<int>(n),
-                                     h->sorted_tgt.p, h->tgt.stream));
   h->have_tgt = true;
   return NDT_OK;
 }
@@ -331,9 +317,6 @@ ndt_status gicp_set_input_source(gicp_handle h, const void* pts, size_t n, size_
   }
   const ndt_status s = gicp_build_index(&h->src, pts, n, stride_bytes);
   if (s) return s;
-  HIP_TRY(h->sorted_src.reserve(n));
-  HIP_TRY(gicp::launch_gather_points(h->src.target->pts.p, h->src.grid->sorted_idx.p, h->src.grid->counts.p, static_cast<int>(n),
-                                     h->sorted_src.p, h->src.stream));
   HIP_TRY(hipStreamSynchronize(h->src.stream));  // the index is read from tgt's stream from here on
   h->have_src = true;
   return NDT_OK;

@@ -8,24 +8,9 @@
 
 namespace gicp {
 
-// A cloud together with the counting-sort voxel index K1 built over it (ndt_kernels.hip): the exact
-// nearest-neighbour searches walk cubic shells of cells around the query.
-struct PointIndex {
-  const float4* pts = nullptr;  // caller's order
-  int n = 0;
-  ndt::GridGeom geom{};
-  const int* cell2leaf = nullptr;        // n_cells: occupied-cell ordinal or -1
-  const unsigned* leaf_start = nullptr;  // per occupied cell: first entry of its segment in sorted_idx
-  const int* leaf_count = nullptr;
-  const int* sorted_idx = nullptr;  // point indices grouped by cell
-  const float4* sorted_pts = nullptr;  // the points in that order (launch_gather_points)
-  int n_sorted = 0;
-  float slack = 0.f;  // build-time vs search-time cell index rounding (SURVEY 8a trap 2)
-};
+using ndt::PointIndex;  // a cloud + the voxel index K1 built over it (ndt_kernels.hpp)
 
-// sorted_pts[q] = pts[sorted_idx[q]] for q < *d_n_sorted (device-side count of the grid build)
-hipError_t launch_gather_points(const float4* pts, const int* sorted_idx, const unsigned* d_n_sorted, int n_max, float4* out,
-                                hipStream_t stream);
+using ndt::launch_gather_points;
 
 constexpr int kMaxK = 64;           // k_correspondences_ supported by the LDS candidate lists
 constexpr int kFunctorValues = 14;  // f, g_t[3], R[9] (row-major), correspondence count

@@ -196,6 +196,7 @@ struct DeviceGrid {
   // getFitnessScore's nearest-neighbour search: cell -> leaf ordinal (or -1), built on first use
   std::mutex fit_mu;
   DevBuf<int> cell2leaf;
+  DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
   bool have_cell2leaf = false;
   ndt::GridView view() const {
     ndt::GridView v;
@@ -1314,6 +1315,9 @@ ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g) {
     HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
     HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
     HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, h->stream));
+    HIP_TRY(g->cell_pts.reserve(g->target->n));
+    HIP_TRY(ndt::launch_gather_points(g->target->pts.p, g->sorted_idx.p, g->counts.p, static_cast<int>(g->target->n), g->cell_pts.p,
+                                      h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     g->have_cell2leaf = true;
   }
@@ -1326,6 +1330,19 @@ float index_slack(const DeviceGrid* g) {
   for (int k = 0; k < 3; k++)
     max_abs = std::max(max_abs, std::max(std::fabs(g->geom.min_b[k] * g->geom.leaf[k]), std::fabs((g->geom.max_b[k] + 1) * g->geom.leaf[k])));
   return 1e-3f * g->resolution + 4e-6f * max_abs;
+}
+// the search structure over a built grid's target (after ensure_cell2leaf + grid_counts)
+void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix) {
+  ix.pts = g->target->pts.p;
+  ix.n = static_cast<int>(g->target->n);
+  ix.geom = g->geom;
+  ix.cell2leaf = g->cell2leaf.p;
+  ix.leaf_start = g->leaf_start.p;
+  ix.leaf_count = g->leaf_count.p;
+  ix.sorted_idx = g->sorted_idx.p;
+  ix.sorted_pts = g->cell_pts.p;
+  ix.n_sorted = static_cast<int>(g->n_sorted);
+  ix.slack = index_slack(g);
 }
 // [PCL] Registration::getFitnessScore of the dense device cloud d_src moved by T against h's target
 ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness) {
@@ -1340,10 +1357,11 @@ ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float*
   if (s) return s;
   float T12[12];
   colmajor_to_T12(T_colmajor, T12);
-  const int nblk = std::max(1, std::min(2048, (n + 255) / 256));
+  const int nblk = std::max(1, std::min(2048, (n + 31) / 32));  // 32 query teams per block
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
-  HIP_TRY(ndt::launch_fitness(d_src, n, T12, g->geom, g->cell2leaf.p, g->leaf_start.p, g->leaf_count.p, g->sorted_idx.p,
-                              static_cast<int>(g->n_sorted), g->target->pts.p, max_range, index_slack(g), nblk, h->partials.p, h->stream));
+  ndt::PointIndex ix;
+  fill_point_index(g, ix);
+  HIP_TRY(ndt::launch_fitness(d_src, n, T12, ix, max_range, nblk, h->partials.p, h->stream));
   HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->host_result[1] > 0) *fitness = h->host_result[0] / h->host_result[1];

@@ -27,6 +27,7 @@
 // accumulators are reduced with a VALU-only wave64 fold, then LDS across the waves of
 // a block, then a fixed-order sum over the blocks.
 #include "ndt_device.hpp"
+#include "ndt_search.hpp"
 
 namespace ndt {
 
@@ -751,71 +752,58 @@ __global__ __launch_bounds__(kBlock) void k_cell_to_leaf(const int* __restrict__
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += gridDim.x * kBlock) cell2leaf[leaf_cell[i]] = i;
 }
 
-constexpr int kFitMaxRing = 6;  // beyond this many shells the query falls back to a scan of all target points
+// Points in cell order (sorted_pts[q] = pts[sorted_idx[q]]): the candidates of a cell are consecutive
+// 16-byte records, so a scan issues several loads at once instead of chasing index -> point one
+// candidate at a time (with ~16k queries the chip is nearly empty and a query's time is its chain of
+// load latencies).
+__global__ __launch_bounds__(kBlock) void k_gather_points(const float4* __restrict__ pts, const int* __restrict__ sorted_idx,
+                                                          const unsigned* __restrict__ d_n_sorted, float4* __restrict__ out) {
+  const int n = static_cast<int>(*d_n_sorted);
+  for (int q = blockIdx.x * kBlock + threadIdx.x; q < n; q += gridDim.x * kBlock) out[q] = pts[sorted_idx[q]];
+}
 
-__global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ src, int n, EvalParams P, GridGeom g,
-                                                    const int* __restrict__ cell2leaf, const unsigned* __restrict__ leaf_start,
-                                                    const int* __restrict__ leaf_count, const int* __restrict__ sorted_idx,
-                                                    int n_sorted, const float4* __restrict__ tgt, double max_range, float slack,
-                                                    double* __restrict__ partials) {
+
+__global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ src, int n, EvalParams P, PointIndex ix,
+                                                    double max_range, double* __restrict__ partials) {
+  constexpr int kTeams = kBlock / kTeam;
   __shared__ double lds[(kBlock / kWave) * 32];
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  const float leaf = fminf(g.leaf[0], fminf(g.leaf[1], g.leaf[2]));
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  const int sub = threadIdx.x & (kTeam - 1);
+  const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
+  const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
+  const int r_max = max_shells(ix, r_lim);
+  for (int i = blockIdx.x * kTeams + threadIdx.x / kTeam; i < n; i += gridDim.x * kTeams) {  // uniform within a team
     const float4 pt = src[i];
     if (!finite3(pt.x, pt.y, pt.z)) continue;  // transformPointCloud leaves it non-finite; no neighbour to report
     float tx, ty, tz;
     xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
     if (!finite3(tx, ty, tz)) continue;
+    float best = INFINITY;  // this lane's share of the candidates
+    auto consider = [&](float d, unsigned) { best = fminf(best, d); };
     int ci, cj, ck;
-    search_ijk(g, tx, ty, tz, ci, cj, ck);
-    // nearest grid cell when the point is outside the bounding box
-    ci = max(g.min_b[0], min(g.max_b[0], ci)) - g.min_b[0];
-    cj = max(g.min_b[1], min(g.max_b[1], cj)) - g.min_b[1];
-    ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
-    float best = INFINITY;
+    query_cell(ix.geom, tx, ty, tz, ci, cj, ck);
     bool done = false;
-    auto scan_leaf = [&](int lf) {
-      const unsigned s0 = leaf_start[lf];
-      const int cnt = leaf_count[lf];
-      for (int q = 0; q < cnt; q++) {
-        const float4 t = tgt[sorted_idx[s0 + q]];
-        best = fminf(best, dist2_f32(tx, ty, tz, t.x, t.y, t.z));
-      }
-    };
-    const int r_lim = max(g.div_b[0], max(g.div_b[1], g.div_b[2]));
-    for (int r = 0; r <= kFitMaxRing && !done; r++) {
-      for (int dz = -r; dz <= r; dz++) {
-        const int z = ck + dz;
-        if (z < 0 || z >= g.div_b[2]) continue;
-        for (int dy = -r; dy <= r; dy++) {
-          const int y = cj + dy;
-          if (y < 0 || y >= g.div_b[1]) continue;
-          const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-          const int step = face ? 1 : max(2 * r, 1);  // interior rows of the shell: only dx = -r and dx = +r
-          for (int dx = -r; dx <= r; dx += step) {
-            const int x = ci + dx;
-            if (x < 0 || x >= g.div_b[0]) continue;
-            const int lf = cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
-            if (lf >= 0) scan_leaf(lf);
-          }
-        }
-      }
+    float tb = INFINITY;
+    for (int r = 0; r <= r_max && !done; r++) {
+      team_shell(ix, ci, cj, ck, r, sub, tx, ty, tz, consider);
+      tb = best;
+#pragma unroll
+      for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
       // every unvisited cell is at least r cells away (less the slack for the build-time / search-time
       // index rounding, trap 2)
-      const float reach = static_cast<float>(r) * leaf - slack;
-      if ((reach > 0.0f && best <= reach * reach) || r >= r_lim) done = true;
+      const float reach = static_cast<float>(r) * leaf - ix.slack;
+      if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
     }
-    if (!done) {  // sparse neighbourhood: exhaustive scan
-      for (int q = 0; q < n_sorted; q++) {
-        const float4 t = tgt[sorted_idx[q]];
-        best = fminf(best, dist2_f32(tx, ty, tz, t.x, t.y, t.z));
-      }
+    if (!done) {  // sparse neighbourhood: the team scans everything
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, consider);
+      tb = best;
+#pragma unroll
+      for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
     }
-    if (static_cast<double>(best) <= max_range) {  // the squared distance against max_range, as PCL does
-      acc[0] += static_cast<double>(best);
+    if (sub == 0 && static_cast<double>(tb) <= max_range) {  // the squared distance against max_range, as PCL does
+      acc[0] += static_cast<double>(tb);
       acc[1] += 1.0;
     }
   }
@@ -1088,13 +1076,18 @@ hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2lea
   return hipGetLastError();
 }
 
-hipError_t launch_fitness(const float4* src, int n, const float* T12, const GridGeom& g, const int* cell2leaf,
-                          const unsigned* leaf_start, const int* leaf_count, const int* sorted_idx, int n_sorted,
-                          const float4* tgt, double max_range, float slack, int n_blocks, double* partials, hipStream_t stream) {
-  EvalParams P = {};
+hipError_t launch_fitness(const float4* src, int n, const float* T12, const PointIndex& tgt, double max_range, int n_blocks,
+                          double* partials, hipStream_t stream) {
+  EvalParams P{};
   for (int i = 0; i < 12; i++) P.T[i] = T12[i];
-  hipLaunchKernelGGL(k_fitness, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, P, g, cell2leaf, leaf_start, leaf_count, sorted_idx,
-                     n_sorted, tgt, max_range, slack, partials);
+  hipLaunchKernelGGL(k_fitness, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, P, tgt, max_range, partials);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_points(const float4* pts, const int* sorted_idx, const unsigned* d_n_sorted, int n_max, float4* out,
+                                hipStream_t stream) {
+  const int blocks = max(1, min(2048, (n_max + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_gather_points, dim3(blocks), dim3(kBlock), 0, stream, pts, sorted_idx, d_n_sorted, out);
   return hipGetLastError();
 }
 

@@ -38,6 +38,21 @@ struct GridView {
   GridGeom g;
 };
 
+// A cloud together with the counting-sort voxel index K1 built over it (ndt_kernels.hip): the exact
+// nearest-neighbour searches walk cubic shells of cells around the query.
+struct PointIndex {
+  const float4* pts = nullptr;  // caller's order
+  int n = 0;
+  ndt::GridGeom geom{};
+  const int* cell2leaf = nullptr;        // n_cells: occupied-cell ordinal or -1
+  const unsigned* leaf_start = nullptr;  // per occupied cell: first entry of its segment in sorted_idx
+  const int* leaf_count = nullptr;
+  const int* sorted_idx = nullptr;  // point indices grouped by cell
+  const float4* sorted_pts = nullptr;  // the points in that order (launch_gather_points)
+  int n_sorted = 0;
+  float slack = 0.f;  // build-time vs search-time cell index rounding (SURVEY 8a trap 2)
+};
+
 // Per-evaluation constants of computeDerivatives (ndt_omp_impl.hpp:179-285).
 struct EvalParams {
   float T[12];      // row-major 3x4 f32 transform applied to the source
@@ -143,9 +158,12 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
 hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
                              int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);
 hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, hipStream_t stream);
-hipError_t launch_fitness(const float4* src, int n, const float* T12, const GridGeom& g, const int* cell2leaf,
-                          const unsigned* leaf_start, const int* leaf_count, const int* sorted_idx, int n_sorted,
-                          const float4* tgt, double max_range, float slack, int n_blocks, double* partials, hipStream_t stream);
+// [PCL] getFitnessScore: team search over the target's point index (ndt_search.hpp); partials [n_blocks][kEvalStride]
+hipError_t launch_fitness(const float4* src, int n, const float* T12, const PointIndex& tgt, double max_range, int n_blocks,
+                          double* partials, hipStream_t stream);
+// pts in the cell order of an index: out[q] = pts[sorted_idx[q]] for q < *d_n_sorted
+hipError_t launch_gather_points(const float4* pts, const int* sorted_idx, const unsigned* d_n_sorted, int n_max, float4* out,
+                                hipStream_t stream);
 hipError_t launch_transform(const float4* src, int n, const float* T12, float4* dst, hipStream_t stream, int dense = 1);
 hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, double d1, double d2, double d3,
                              int search, float r2, int n_blocks, double* partials, hipStream_t stream);

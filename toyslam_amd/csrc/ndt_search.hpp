@@ -1,0 +1,137 @@
+// ndt_search.hpp -- exact nearest-neighbour search over a PointIndex (a cloud + the counting-sort voxel
+// index K1 builds over it), shared by getFitnessScore (ndt_kernels.hip) and the GICP kernels
+// (gicp_kernels.hip).  Device code in an anonymous namespace, like ndt_device.hpp.
+//
+// Search: the query's cell, then cubic shells of cells around it, until no unvisited shell can hold a
+// better point -- exact; ties are resolved by the callers on (distance, index).
+#pragma once
+#include "ndt_device.hpp"
+
+namespace ndt {
+namespace {
+
+constexpr int kKnnMaxRing = 8;  // shells every query may try (see max_shells) before one scan over all points
+
+__device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, float z, int& ci, int& cj, int& ck) {
+  search_ijk(g, x, y, z, ci, cj, ck);
+  ci = max(g.min_b[0], min(g.max_b[0], ci)) - g.min_b[0];  // nearest grid cell when outside the bounding box
+  cj = max(g.min_b[1], min(g.max_b[1], cj)) - g.min_b[1];
+  ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
+}
+
+// ---------------------------------------------------------------------------
+// Team search.  A query is worked on by kTeam = 8 adjacent lanes: they look up the same cell and
+// stride over its points, each lane keeping its own best / its own sorted candidate list, and the
+// team combines them with three xor-shuffles.  With a thread per query the few 10^4 queries of a
+// down-sampled scan leave the chip almost empty and every query is one long chain of load
+// latencies (measured on the reference pair: 2 ms per correspondence step, 4 ms per covariance
+// pass); teams cut the chain eightfold and give the machine eight times the waves.
+// ---------------------------------------------------------------------------
+constexpr int kTeam = 8;
+
+// squared distances from (qx,qy,qz) to this lane's share of the `count` cell-ordered points starting at
+// `first` (positions sub, sub + 8, ...), two loads in flight; visit(d, position in the cell order)
+template <class F>
+__device__ __forceinline__ void scan_run(const float4* __restrict__ sp, unsigned first, int count, int sub, float qx, float qy,
+                                         float qz, F&& visit) {
+  int p = sub;
+  for (; p + kTeam < count; p += 2 * kTeam) {
+    const float4 a = sp[first + p], b = sp[first + p + kTeam];
+    const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
+    visit(da, first + p);
+    visit(db, first + p + kTeam);
+  }
+  if (p < count) {
+    const float4 a = sp[first + p];
+    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), first + p);
+  }
+}
+
+// the exhaustive scan of a query without near neighbours: this lane's share of all points, four loads in flight
+template <class F>
+__device__ __forceinline__ void scan_all(const float4* __restrict__ sp, int count, int sub, float qx, float qy, float qz, F&& visit) {
+  int p = sub;
+  for (; p + 3 * kTeam < count; p += 4 * kTeam) {
+    const float4 a = sp[p], b = sp[p + kTeam], c = sp[p + 2 * kTeam], d = sp[p + 3 * kTeam];
+    const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
+    const float dc = dist2_f32(qx, qy, qz, c.x, c.y, c.z), dd = dist2_f32(qx, qy, qz, d.x, d.y, d.z);
+    visit(da, static_cast<unsigned>(p));
+    visit(db, static_cast<unsigned>(p + kTeam));
+    visit(dc, static_cast<unsigned>(p + 2 * kTeam));
+    visit(dd, static_cast<unsigned>(p + 3 * kTeam));
+  }
+  for (; p < count; p += kTeam) {
+    const float4 a = sp[p];
+    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), static_cast<unsigned>(p));
+  }
+}
+
+// lexicographic minimum of (d, idx) over the 8 lanes of a team
+__device__ __forceinline__ void team_min(float& d, int& idx) {
+#pragma unroll
+  for (int off = 1; off < kTeam; off <<= 1) {
+    const float od = __shfl_xor(d, off, kWave);
+    const int oi = __shfl_xor(idx, off, kWave);
+    if (od < d || (od == d && oi < idx)) {
+      d = od;
+      idx = oi;
+    }
+  }
+}
+__device__ __forceinline__ int team_sum(int v) {
+#pragma unroll
+  for (int off = 1; off < kTeam; off <<= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Shell r of cells around (ci, cj, ck), worked on by a team: the (2r+1)^2 rows of the shell are dealt out
+// to the eight lanes, each lane probes one cell of its row per step (face rows: every x; interior rows:
+// only x = -r and x = +r), and every occupied cell any lane finds is then scanned by the whole team.
+// consider(d, position) as in scan_run.  All control flow is uniform within the team.
+template <class F>
+__device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj, int ck, int r, int sub, float qx, float qy,
+                                           float qz, F&& consider) {
+  const GridGeom& g = ix.geom;
+  const int w = 2 * r + 1, rows = w * w;
+  const int team_base = (threadIdx.x & (kWave - 1)) & ~(kTeam - 1);
+  for (int row0 = 0; row0 < rows; row0 += kTeam) {
+    const int row = row0 + sub;
+    const int dz = row / w - r, dy = row % w - r;
+    const int z = ck + dz, y = cj + dy;
+    const bool row_ok = row < rows && z >= 0 && z < g.div_b[2] && y >= 0 && y < g.div_b[1];
+    if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
+    const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
+    const int nx = face ? w : 2;
+    for (int t = 0; t < w; t++) {
+      int lf = -1;
+      if (row_ok && t < nx) {
+        const int x = ci + (face ? t - r : (t == 0 ? -r : r));
+        if (x >= 0 && x < g.div_b[0]) lf = ix.cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+      }
+      unsigned first = 0;
+      int count = 0;
+      if (lf >= 0) {
+        first = ix.leaf_start[lf];
+        count = ix.leaf_count[lf];
+      }
+      unsigned found = static_cast<unsigned>((__ballot(lf >= 0) >> team_base) & 0xffull);
+      while (found) {
+        const int owner = __builtin_ctz(found);
+        found &= found - 1;
+        const unsigned fs = __shfl(first, team_base + owner, kWave);
+        const int fc = __shfl(count, team_base + owner, kWave);
+        scan_run(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
+      }
+    }
+  }
+}
+
+// shells tried before a query falls back to one scan over all points: while probing the shells costs
+// less than that scan
+__device__ __forceinline__ int max_shells(const PointIndex& ix, int r_lim) {
+  const int by_cost = (static_cast<int>(cbrtf(static_cast<float>(ix.n_sorted))) - 1) / 2;  // (2r+1)^3 probes ~ n points
+  return min(r_lim, max(kKnnMaxRing, by_cost));
+}
+
+}  // namespace
+}  // namespace ndt
