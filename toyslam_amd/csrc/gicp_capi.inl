@@ -185,11 +185,19 @@ ndt_status gicp_prepare(gicp_context* h, const float* guess_cm) {
 struct GicpDevice : gicp::Backend {
   gicp_context* h;
   std::string error;
+  // The line search evaluates operator() and then, if the step passes Fletcher's rho test, df at the very same
+  // point (gicp_driver.cpp line_search): the operator() launch also accumulates df's sums, and the df request that
+  // follows is answered from here without a launch.
+  bool fuse = std::getenv("NDT_GICP_NO_FUSE") == nullptr;
+  bool have_grad = false;
+  float grad_T[16];
+  gicp::FunctorSums grad_sums;
   explicit GicpDevice(gicp_context* ctx) : h(ctx) {}
 
   bool correspond(const float transformation[16], const double R[9]) override {
     gicp::Rot3d rot;
     for (int i = 0; i < 9; i++) rot.m[i] = R[i];
+    have_grad = false;
     const double thr = h->prm.corr_dist_threshold * h->prm.corr_dist_threshold;  // :401
     const hipError_t e = gicp::launch_correspond(h->output.p, static_cast<int>(h->src.target->n), transformation, rot,
                                                  gicp_index_of(&h->tgt), h->cov_src.p, h->cov_tgt.p, thr, h->corr.p, h->maha.p,
@@ -202,9 +210,14 @@ struct GicpDevice : gicp::Backend {
   }
 
   bool sums(int mode, const float T[16], gicp::FunctorSums& out) override {
+    if (mode == 1 && have_grad && std::memcmp(T, grad_T, sizeof(grad_T)) == 0) {
+      out = grad_sums;
+      return true;
+    }
     const int n = static_cast<int>(h->src.target->n);
     const unsigned long long seq = ++h->seq;
-    const hipError_t e = gicp::launch_functor(mode, h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, T,
+    const int launch_mode = (mode == 0 && fuse) ? 3 : mode;
+    const hipError_t e = gicp::launch_functor(launch_mode, h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, T,
                                               gicp::functor_blocks(n), h->partials.p, h->counter.p, h->host_pub, seq, h->tgt.stream);
     if (e != hipSuccess) {
       error = std::string("functor kernel: ") + hipGetErrorString(e);
@@ -232,6 +245,11 @@ struct GicpDevice : gicp::Backend {
     for (int i = 0; i < 3; i++) out.g[i] = row[1 + i];
     for (int i = 0; i < 9; i++) out.R[i] = row[4 + i];
     out.m = row[13];
+    if (launch_mode == 3) {  // slot 0 is operator()'s value; keep the gradient sums for the df that follows
+      have_grad = true;
+      std::memcpy(grad_T, T, sizeof(grad_T));
+      grad_sums = out;
+    }
     return true;
   }
 };

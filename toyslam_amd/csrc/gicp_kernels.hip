@@ -242,7 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
   }
 }
 
-template <bool F32>
+// MODE 0: operator() only; 1: df / fdf (f64); 2: operator() in slot 0 AND the f64 gradient sums of df in slots 1..12 --
+// the line search asks for df right after operator() at the same point, and one launch serves both
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_functor(const float4* __restrict__ output, int n, const float4* __restrict__ tgt,
                                                     const int* __restrict__ corr, const float* __restrict__ maha9,
                                                     EvalParams P, double* __restrict__ partials,
@@ -265,18 +267,19 @@ __global__ __launch_bounds__(kBlock) void k_functor(const float4* __restrict__ o
     float px, py, pz;
     matvec_eigen(P.T, ps.x, ps.y, ps.z, px, py, pz);
     const float r0 = px - pt.x, r1 = py - pt.y, r2 = pz - pt.z;
-    if (F32) {  // operator(), :241-274
+    if (MODE != 1) {  // operator(), :241-274
       const float m0 = (M[0] * r0 + M[1] * r1) + M[2] * r2;
       const float m1 = (M[3] * r0 + M[4] * r1) + M[5] * r2;
       const float m2 = (M[6] * r0 + M[7] * r1) + M[8] * r2;
       const float ret = (r0 * m0 + r2 * m2) + r1 * m1;  // [Eigen] 4-wide dot: (p0 + p2) + (p1 + p3)
       acc[0] += static_cast<double>(ret);
-    } else {  // df / fdf, :277-368
+    }
+    if (MODE != 0) {  // df / fdf, :277-368
       const double d0 = static_cast<double>(r0), d1 = static_cast<double>(r1), d2 = static_cast<double>(r2);
       const double t0 = (static_cast<double>(M[0]) * d0 + static_cast<double>(M[1]) * d1) + static_cast<double>(M[2]) * d2;
       const double t1 = (static_cast<double>(M[3]) * d0 + static_cast<double>(M[4]) * d1) + static_cast<double>(M[5]) * d2;
       const double t2 = (static_cast<double>(M[6]) * d0 + static_cast<double>(M[7]) * d1) + static_cast<double>(M[8]) * d2;
-      acc[0] += (d0 * t0 + d1 * t1) + d2 * t2;
+      if (MODE == 1) acc[0] += (d0 * t0 + d1 * t1) + d2 * t2;
       acc[1] += t0;
       acc[2] += t1;
       acc[3] += t2;
@@ -363,11 +366,14 @@ hipError_t launch_functor(int mode, const float4* output, int n, const float4* t
   EvalParams P{};
   for (int i = 0; i < 12; i++) P.T[i] = T12[i];
   if (mode == 0)
-    hipLaunchKernelGGL(k_functor<true>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials,
-                       counter, out_row, seq);
+    hipLaunchKernelGGL(k_functor<0>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials, counter,
+                       out_row, seq);
+  else if (mode == 3)
+    hipLaunchKernelGGL(k_functor<2>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials, counter,
+                       out_row, seq);
   else
-    hipLaunchKernelGGL(k_functor<false>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials,
-                       counter, out_row, seq);
+    hipLaunchKernelGGL(k_functor<1>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials, counter,
+                       out_row, seq);
   return hipGetLastError();
 }
 

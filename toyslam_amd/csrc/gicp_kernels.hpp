@@ -31,7 +31,7 @@ hipError_t launch_correspond(const float4* output, int n, const float* T12, cons
                              hipStream_t stream);
 
 // OptimizationFunctorWithIndices (:241-368) over the current correspondences.  mode 0 = operator()
-// (f32 quadratic form), 1 / 2 = df / fdf (f64).  One launch: per-block rows -> ticket -> the last block
+// (f32 quadratic form), 1 / 2 = df / fdf (f64), 3 = operator() in slot 0 together with df's gradient sums.  One launch: per-block rows -> ticket -> the last block
 // sums them in a fixed order and publishes kFunctorValues raw sums as a tagged row (ndt_device.hpp
 // publish_row_tagged) into pinned host memory.  counter: one zero-initialised u32, reset by the kernel.
 int functor_blocks(int n);

@@ -197,6 +197,7 @@ struct DeviceGrid {
   std::mutex fit_mu;
   DevBuf<int> cell2leaf;
   DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
+  DevBuf<int> row_any;      // per x-row of cells: occupied or not
   bool have_cell2leaf = false;
   ndt::GridView view() const {
     ndt::GridView v;
@@ -1314,7 +1315,11 @@ ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g) {
   if (!g->have_cell2leaf) {
     HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
     HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
-    HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, h->stream));
+    const size_t n_rows = static_cast<size_t>(g->geom.div_b[1]) * static_cast<size_t>(g->geom.div_b[2]);
+    HIP_TRY(g->row_any.reserve(n_rows));
+    HIP_TRY(hipMemsetAsync(g->row_any.p, 0, n_rows * sizeof(int), h->stream));
+    HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, g->geom.div_b[0], g->row_any.p,
+                                     h->stream));
     HIP_TRY(g->cell_pts.reserve(g->target->n));
     HIP_TRY(ndt::launch_gather_points(g->target->pts.p, g->sorted_idx.p, g->counts.p, static_cast<int>(g->target->n), g->cell_pts.p,
                                       h->stream));
@@ -1337,6 +1342,7 @@ void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix) {
   ix.n = static_cast<int>(g->target->n);
   ix.geom = g->geom;
   ix.cell2leaf = g->cell2leaf.p;
+  ix.row_any = g->row_any.p;
   ix.leaf_start = g->leaf_start.p;
   ix.leaf_count = g->leaf_count.p;
   ix.sorted_idx = g->sorted_idx.p;

@@ -748,8 +748,13 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__
 // Distances as [FLANN] L2_Simple computes them: f32, (dx*dx + dy*dy) + dz*dz, no contraction.
 // acc[0] = sum of the accepted squared distances (f64), acc[1] = their count.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cell_to_leaf(const int* __restrict__ leaf_cell, int n_leaves, int* __restrict__ cell2leaf) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += gridDim.x * kBlock) cell2leaf[leaf_cell[i]] = i;
+__global__ __launch_bounds__(kBlock) void k_cell_to_leaf(const int* __restrict__ leaf_cell, int n_leaves, int* __restrict__ cell2leaf,
+                                                         int div_x, int* __restrict__ row_any) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += gridDim.x * kBlock) {
+    const int c = leaf_cell[i];
+    cell2leaf[c] = i;
+    row_any[c / div_x] = 1;  // the x-row (y, z) of this cell holds points: empty rows are skipped by the shell search
+  }
 }
 
 // Points in cell order (sorted_pts[q] = pts[sorted_idx[q]]): the candidates of a cell are consecutive
@@ -1071,8 +1076,9 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
   return hipGetLastError();
 }
 
-hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, hipStream_t stream) {
-  hipLaunchKernelGGL(k_cell_to_leaf, dim3(grid_for(n_leaves, 1024)), dim3(kBlock), 0, stream, leaf_cell, n_leaves, cell2leaf);
+hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, int div_x, int* row_any, hipStream_t stream) {
+  hipLaunchKernelGGL(k_cell_to_leaf, dim3(grid_for(n_leaves, 1024)), dim3(kBlock), 0, stream, leaf_cell, n_leaves, cell2leaf, div_x,
+                     row_any);
   return hipGetLastError();
 }
 

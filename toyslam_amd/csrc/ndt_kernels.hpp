@@ -45,6 +45,7 @@ struct PointIndex {
   int n = 0;
   ndt::GridGeom geom{};
   const int* cell2leaf = nullptr;        // n_cells: occupied-cell ordinal or -1
+  const int* row_any = nullptr;          // div_y * div_z: 1 where the x-row (y, z) has an occupied cell
   const unsigned* leaf_start = nullptr;  // per occupied cell: first entry of its segment in sorted_idx
   const int* leaf_count = nullptr;
   const int* sorted_idx = nullptr;  // point indices grouped by cell
@@ -157,7 +158,8 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
 // all live scans of a lock-step batch step in one launch, kinds mixed (descs[scan].kind, .pad = rows written)
 hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
                              int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);
-hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, hipStream_t stream);
+// cell2leaf (pre-set to -1) and row_any (pre-set to 0, div_y * div_z entries) of a built grid
+hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, int div_x, int* row_any, hipStream_t stream);
 // [PCL] getFitnessScore: team search over the target's point index (ndt_search.hpp); partials [n_blocks][kEvalStride]
 hipError_t launch_fitness(const float4* src, int n, const float* T12, const PointIndex& tgt, double max_range, int n_blocks,
                           double* partials, hipStream_t stream);

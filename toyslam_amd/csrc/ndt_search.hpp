@@ -98,7 +98,8 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
     const int row = row0 + sub;
     const int dz = row / w - r, dy = row % w - r;
     const int z = ck + dz, y = cj + dy;
-    const bool row_ok = row < rows && z >= 0 && z < g.div_b[2] && y >= 0 && y < g.div_b[1];
+    bool row_ok = row < rows && z >= 0 && z < g.div_b[2] && y >= 0 && y < g.div_b[1];
+    if (row_ok) row_ok = ix.row_any[y + z * g.div_b[1]] != 0;  // rows without a single occupied cell cost one load
     if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
     const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
     const int nx = face ? w : 2;
