@@ -45,11 +45,18 @@ struct CellGrid {
     h = std::cbrt(vol * 2.0 / std::max<size_t>(cloud.size(), 1));
     const double ext = std::max({mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], 1e-3});
     h = std::max(h, ext / 1000.0);  // 21-bit keys are ample
-    for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<std::int64_t>::max(); hi[a] = std::numeric_limits<std::int64_t>::min(); }
-    for (size_t i = 0; i < cloud.size(); i++) {
-      const std::int64_t c[3] = {cell_of(cloud[i].x), cell_of(cloud[i].y), cell_of(cloud[i].z)};
-      for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
-      cells[key(c[0], c[1], c[2])].push_back(static_cast<int>(i));
+    // flat or thin clouds make the volume guess far too fine (every point alone in its cell, searches walk
+    // thousands of empty cells): coarsen until an occupied cell holds a few points on average
+    for (int pass = 0; pass < 12; pass++) {
+      cells.clear();
+      for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<std::int64_t>::max(); hi[a] = std::numeric_limits<std::int64_t>::min(); }
+      for (size_t i = 0; i < cloud.size(); i++) {
+        const std::int64_t c[3] = {cell_of(cloud[i].x), cell_of(cloud[i].y), cell_of(cloud[i].z)};
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+        cells[key(c[0], c[1], c[2])].push_back(static_cast<int>(i));
+      }
+      if (cells.size() * 3 <= cloud.size() || cells.size() <= 8) break;
+      h *= 1.6;
     }
   }
 };
@@ -65,7 +72,21 @@ void knn_one(const CellGrid& g, const std::vector<Pt>& cloud, const Pt& q, int k
   std::int64_t c[3] = {g.cell_of(q.x), g.cell_of(q.y), g.cell_of(q.z)};
   std::int64_t far = 0;  // shells needed to cover every occupied cell
   for (int a = 0; a < 3; a++) far = std::max({far, c[a] - g.lo[a], g.hi[a] - c[a]});
+  auto offer = [&](int idx) {
+    const Cand cd{dist2_l2simple(q, cloud[idx]), idx};
+    if (static_cast<int>(best.size()) < k) {
+      best.insert(std::upper_bound(best.begin(), best.end(), cd), cd);
+    } else if (cd < best.back()) {
+      best.pop_back();
+      best.insert(std::upper_bound(best.begin(), best.end(), cd), cd);
+    }
+  };
   for (std::int64_t r = 0; r <= far; r++) {
+    if (r > 24) {  // an isolated query: walking ever larger shells costs more than looking at every point
+      best.clear();
+      for (size_t i = 0; i < cloud.size(); i++) offer(static_cast<int>(i));
+      return;
+    }
     for (std::int64_t dz = -r; dz <= r; dz++)
       for (std::int64_t dy = -r; dy <= r; dy++)
         for (std::int64_t dx = -r; dx <= r; dx++) {
@@ -74,15 +95,7 @@ void knn_one(const CellGrid& g, const std::vector<Pt>& cloud, const Pt& q, int k
           if (x < g.lo[0] || x > g.hi[0] || y < g.lo[1] || y > g.hi[1] || z < g.lo[2] || z > g.hi[2]) continue;
           auto it = g.cells.find(CellGrid::key(x, y, z));
           if (it == g.cells.end()) continue;
-          for (int idx : it->second) {
-            const Cand cd{dist2_l2simple(q, cloud[idx]), idx};
-            if (static_cast<int>(best.size()) < k) {
-              best.insert(std::upper_bound(best.begin(), best.end(), cd), cd);
-            } else if (cd < best.back()) {
-              best.pop_back();
-              best.insert(std::upper_bound(best.begin(), best.end(), cd), cd);
-            }
-          }
+          for (int idx : it->second) offer(idx);
         }
     // every unvisited point is at least r cells away from the query
     if (static_cast<int>(best.size()) == k) {

@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the oracle's OpenMP regions are small; on a many-core host the default team (one thread per core) costs more
+# in start-up than it gains (the NDT oracle sets its own thread count per object)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -157,6 +157,32 @@ def test_align_matches_oracle(gmod, scene, case):
     assert np.array_equal(cloud, po.transform_cloud(src4, T))
 
 
+def test_randomised_scenes_follow_the_oracle(gmod):
+    """tools/fuzz_gicp.py, short and well-conditioned (structured scenes, default gate): random sizes, k, guesses and
+    iteration caps -- identical neighbours and correspondences, the oracle's registration within tolerance."""
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        tgt = clouds.target_surfaces(int(rng.integers(3000, 12000)), seed=int(rng.integers(1 << 30)), extent=float(rng.choice([40.0, 100.0])))[:, :3].astype(np.float32)
+        Tm = clouds.random_T(rng, 0.3, 2.0)
+        pick = tgt[rng.choice(len(tgt), int(rng.integers(800, 3000)), replace=False)]
+        src = (clouds.apply_T(np.linalg.inv(Tm), pick) + rng.normal(0, 0.01, pick.shape)).astype(np.float32)
+        kw = dict(k=int(rng.choice([10, 20, 33])), max_iterations=int(rng.choice([3, 200])), max_inner_iterations=int(rng.choice([5, 20])))
+        guess = None if case % 2 else clouds.random_T(rng, 0.1, 0.5).astype(np.float32)
+        g, o = both(gmod, tgt, src, **kw)
+        cov, idx, d2 = g.covariances(1, neighbors=True)
+        oi, od = po.gicp_knn(src, src, kw["k"])
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od), case
+        o.prepare(guess)
+        m_o, ci_o, _ = o.correspond(np.eye(4))
+        m_g, ci_g, _ = g.step_correspond(guess)
+        assert m_o == m_g and np.array_equal(ci_o, ci_g), case
+        ro = o.align(guess)
+        g.align(guess)
+        T = g.getFinalTransformation()
+        assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL, (case, kw)
+        assert g.hasConverged() == ro["converged"] and g.getFinalNumIteration() == ro["iterations"], (case, kw)
+
+
 def test_align_on_the_reference_pair(gmod, pair):
     """the bundled scan pair after the 0.1 m prefilter, as ndt_omp/apps/align.cpp:80-86 runs pclomp::GICP on it."""
     tgt, src = pair

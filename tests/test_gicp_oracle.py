@@ -153,6 +153,20 @@ def test_product_driver_equals_oracle_driver(tmp_path):
     assert "mismatches 0" in out.stdout
 
 
+def test_product_driver_under_sanitizers(tmp_path):
+    """the same harness built with ASan + UBSan (CPU build only): the BFGS / outer-loop state machine and the oracle's
+    restatement run clean over random scenes including the exception path."""
+    exe = str(tmp_path / "gicp_driver_check_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fopenmp", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "toyslam_amd", "csrc"), "-I" + os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "gicp_driver_check.cpp"), os.path.join(ROOT, "toyslam_amd", "csrc", "gicp_driver.cpp"),
+                           os.path.join(ROOT, "oracle", "gicp_oracle.cpp"), os.path.join(ROOT, "oracle", "ndt_oracle.cpp"), "-o", exe])
+    env = dict(os.environ, OMP_NUM_THREADS="2", ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([exe, "8"], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "mismatches 0" in out.stdout
+
+
 def test_gicp_symbols_exported(built_lib):
     """every entry point include/gicp_mi355.h declares is exported by the library (no compute without a GPU)."""
     import re

@@ -92,17 +92,18 @@ ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t st
     return static_cast<float>(leaf);
   };
   float leaf = clamp_leaf(std::cbrt(vol * kGicpPointsPerCell / static_cast<double>(n)));
-  for (int pass = 0; pass < 3; pass++) {
+  for (int pass = 0; pass < 4; pass++) {
     c->resolution = leaf;
     s = build_grid(c);
     if (s) return s;
     s = grid_counts(c, c->grid.get());
     if (s) return s;
     const double per_cell = static_cast<double>(n) / static_cast<double>(std::max<size_t>(c->grid->n_leaves, 1));
-    if (per_cell <= 2.0 * kGicpPointsPerCell) break;
+    if (per_cell <= 2.0 * kGicpPointsPerCell && (per_cell >= 0.4 * kGicpPointsPerCell || c->grid->n_leaves <= 8)) break;
+    // too coarse (dense surfaces) or too fine (flat / thin clouds, where the volume guess means little)
     const float next = clamp_leaf(static_cast<double>(leaf) * std::sqrt(kGicpPointsPerCell / per_cell));
-    if (!(next < 0.9f * leaf)) break;
-    leaf = next;
+    if (next < 0.9f * leaf || next > 1.1f * leaf) leaf = next;
+    else break;
   }
   if (std::getenv("NDT_GICP_DEBUG"))
     std::fprintf(stderr, "[gicp index] n=%zu leaf=%.4f cells=%lld (%d x %d x %d) occupied=%zu\n", n, static_cast<double>(leaf),
