@@ -50,22 +50,27 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
     const float4 q = ix.pts[i];
     int cnt = 0;  // this lane's list length
     float worst = INFINITY;
-    int worst_i = 0x7fffffff;
-    auto consider = [&](float d, unsigned pos) {
-      if (cnt == k && d > worst) return;
-      const int idx = ix.sorted_idx[pos];
-      if (cnt == k && d == worst && idx > worst_i) return;
+    int worst_i = 0;  // (a position; only read when worst is a real distance)
+    // The lists hold POSITIONS in the cell order; the point index behind a position is only looked up when two
+    // distances are equal (the tie rule is on the index) and once at the end -- an index load per inserted
+    // candidate would be one more dependent memory round trip on the query's critical path.
+    auto before = [&](float da, int pa, float db, int pb) {  // (distance, index) order
+      return da < db || (da == db && ix.sorted_idx[pa] < ix.sorted_idx[pb]);
+    };
+    auto consider = [&](float d, unsigned upos) {
+      const int pos = static_cast<int>(upos);
+      if (cnt == k && !before(d, pos, worst, worst_i)) return;
       int j = (cnt < k) ? cnt++ : k - 1;
       while (j > 0) {
         const float pd = sd[(j - 1) * kKnnBlock + lane];
-        const int pi = si[(j - 1) * kKnnBlock + lane];
-        if (pd < d || (pd == d && pi < idx)) break;
+        const int pp = si[(j - 1) * kKnnBlock + lane];
+        if (before(pd, pp, d, pos)) break;
         sd[j * kKnnBlock + lane] = pd;
-        si[j * kKnnBlock + lane] = pi;
+        si[j * kKnnBlock + lane] = pp;
         j--;
       }
       sd[j * kKnnBlock + lane] = d;
-      si[j * kKnnBlock + lane] = idx;
+      si[j * kKnnBlock + lane] = pos;
       if (cnt == k) {
         worst = sd[(k - 1) * kKnnBlock + lane];
         worst_i = si[(k - 1) * kKnnBlock + lane];
@@ -85,12 +90,42 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
         for (int j = 0; j < cnt && sd[j * kKnnBlock + lane] < reach * reach; j++) inside++;
       if (team_sum(inside) >= k || r >= r_lim) done = true;
     }
-    if (!done) {  // sparse neighbourhood: the team scans everything
+    if (!done) {
+      // Sparse neighbourhood: the team looks at every point, twice.  Pass 1 only keeps each lane's eight smallest
+      // distances, in registers; the k-th smallest of the team's 64 values bounds the k-th neighbour's distance
+      // from above.  Pass 2 feeds the candidate lists with the points inside that bound -- about k of them.
+      // (One pass with the lists alone spends its time shifting list entries in LDS: a lane that sees an eighth
+      // of the points in arbitrary order inserts hundreds of them before its own k-th best is a useful bound.)
+      float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY, m4 = INFINITY, m5 = INFINITY, m6 = INFINITY, m7 = INFINITY;
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned, const float4&) {
+        if (!(d < m7)) return;
+        m7 = d;  // bubble the newcomer down the sorted registers
+        float t;
+        if (m7 < m6) { t = m6; m6 = m7; m7 = t; }
+        if (m6 < m5) { t = m5; m5 = m6; m6 = t; }
+        if (m5 < m4) { t = m4; m4 = m5; m5 = t; }
+        if (m4 < m3) { t = m3; m3 = m4; m4 = t; }
+        if (m3 < m2) { t = m2; m2 = m3; m3 = t; }
+        if (m2 < m1) { t = m1; m1 = m2; m2 = t; }
+        if (m1 < m0) { t = m0; m0 = m1; m1 = t; }
+      });
+      float bound = INFINITY;
+      for (int j = 0; j < k; j++) {  // pop the team's smallest head k times (k <= 64 values exist: n >= k)
+        float h = m0;
+        int who = sub;
+        team_min(h, who);
+        bound = h;
+        if (who == sub) { m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5; m5 = m6; m6 = m7; m7 = INFINITY; }
+      }
       cnt = 0;
       worst = INFINITY;
-      worst_i = 0x7fffffff;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, consider);
+      worst_i = 0;
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned pos, const float4&) {
+        if (d > bound) return;
+        consider(d, pos);
+      });
     }
+    for (int j = 0; j < cnt; j++) si[j * kKnnBlock + lane] = ix.sorted_idx[si[j * kKnnBlock + lane]];  // positions -> point indices
     // k-way merge of the eight sorted lists: k rounds of "smallest head wins"
     int head = 0;
     for (int j = 0; j < k; j++) {
@@ -187,14 +222,13 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
     const float4 p = output[i];
     float qx, qy, qz;
     matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
-    float best = INFINITY;  // this lane's share
-    int best_i = 0x7fffffff;
+    float best = INFINITY;  // this lane's share: distance and POSITION in the cell order (the index behind it is
+    int best_p = -1;        // looked up on ties and at the end of a shell only)
     auto consider = [&](float d, unsigned pos) {
       if (d > best) return;
-      const int idx = ix.sorted_idx[pos];
-      if (d < best || idx < best_i) {  // equal distance: the lower index
+      if (d < best || ix.sorted_idx[pos] < ix.sorted_idx[best_p]) {  // equal distance: the lower index
         best = d;
-        best_i = idx;
+        best_p = static_cast<int>(pos);
       }
     };
     int ci, cj, ck;
@@ -205,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
     for (int r = 0; r <= r_max && !done; r++) {
       team_shell(ix, ci, cj, ck, r, sub, qx, qy, qz, consider);
       tb = best;
-      tb_i = best_i;
+      tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
       team_min(tb, tb_i);
       const float reach = static_cast<float>(r) * leaf - ix.slack;
       if ((tb_i != 0x7fffffff && reach > 0.0f && tb < reach * reach) || r >= r_lim) done = true;
@@ -214,12 +248,10 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
           !(static_cast<double>(tb) < dist_threshold))
         done = true;
     }
-    if (!done) {
-      best = INFINITY;
-      best_i = 0x7fffffff;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, consider);
+    if (!done) {  // (a point met twice changes nothing for a single nearest neighbour: the shells' best stays as the bound)
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, [&](float d, unsigned pos, const float4&) { consider(d, pos); });
       tb = best;
-      tb_i = best_i;
+      tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
       team_min(tb, tb_i);
     }
     if (sub != 0) continue;

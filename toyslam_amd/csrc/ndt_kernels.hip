@@ -802,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
       if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
     }
     if (!done) {  // sparse neighbourhood: the team scans everything
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, consider);
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, [&](float d, unsigned pos, const float4&) { consider(d, pos); });
       tb = best;
 #pragma unroll
       for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));

@@ -10,7 +10,7 @@
 namespace ndt {
 namespace {
 
-constexpr int kKnnMaxRing = 8;  // shells every query may try (see max_shells) before one scan over all points
+constexpr int kKnnMinRing = 3;  // shells every query may try (see max_shells) before one scan over all points
 
 __device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, float z, int& ci, int& cj, int& ck) {
   search_ijk(g, x, y, z, ci, cj, ck);
@@ -47,7 +47,8 @@ __device__ __forceinline__ void scan_run(const float4* __restrict__ sp, unsigned
   }
 }
 
-// the exhaustive scan of a query without near neighbours: this lane's share of all points, four loads in flight
+// the exhaustive scan of a query without near neighbours: this lane's share of all points, four loads in flight;
+// visit(d, position, point)
 template <class F>
 __device__ __forceinline__ void scan_all(const float4* __restrict__ sp, int count, int sub, float qx, float qy, float qz, F&& visit) {
   int p = sub;
@@ -55,15 +56,26 @@ __device__ __forceinline__ void scan_all(const float4* __restrict__ sp, int coun
     const float4 a = sp[p], b = sp[p + kTeam], c = sp[p + 2 * kTeam], d = sp[p + 3 * kTeam];
     const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
     const float dc = dist2_f32(qx, qy, qz, c.x, c.y, c.z), dd = dist2_f32(qx, qy, qz, d.x, d.y, d.z);
-    visit(da, static_cast<unsigned>(p));
-    visit(db, static_cast<unsigned>(p + kTeam));
-    visit(dc, static_cast<unsigned>(p + 2 * kTeam));
-    visit(dd, static_cast<unsigned>(p + 3 * kTeam));
+    visit(da, static_cast<unsigned>(p), a);
+    visit(db, static_cast<unsigned>(p + kTeam), b);
+    visit(dc, static_cast<unsigned>(p + 2 * kTeam), c);
+    visit(dd, static_cast<unsigned>(p + 3 * kTeam), d);
   }
   for (; p < count; p += kTeam) {
     const float4 a = sp[p];
-    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), static_cast<unsigned>(p));
+    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), static_cast<unsigned>(p), a);
   }
+}
+
+// the cell a point was binned into when the index was built (ndt_kernels.hip build_cell: floor(x * inv_leaf) - float(min_b),
+// f32, product rounded before floor) -- tells whether the shells already walked have covered it
+__device__ __forceinline__ bool in_walked_cube(const GridGeom& g, const float4& p, int ci, int cj, int ck, int r_done) {
+#pragma clang fp contract(off)
+  const float fx = p.x * g.inv_leaf[0], fy = p.y * g.inv_leaf[1], fz = p.z * g.inv_leaf[2];
+  const int i0 = static_cast<int>(floorf(fx) - static_cast<float>(g.min_b[0]));
+  const int i1 = static_cast<int>(floorf(fy) - static_cast<float>(g.min_b[1]));
+  const int i2 = static_cast<int>(floorf(fz) - static_cast<float>(g.min_b[2]));
+  return abs(i0 - ci) <= r_done && abs(i1 - cj) <= r_done && abs(i2 - ck) <= r_done;
 }
 
 // lexicographic minimum of (d, idx) over the 8 lanes of a team
@@ -127,11 +139,12 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
   }
 }
 
-// shells tried before a query falls back to one scan over all points: while probing the shells costs
-// less than that scan
+// Shells tried before a query falls back to one scan over all points.  Shell r costs the team up to
+// (2r+1)^3 / 8 probe steps, the shells up to r about (2r+1)^4 / 64 together; the scan costs n / 32 steps
+// (8 lanes, four loads in flight): stop walking shells where the two meet.
 __device__ __forceinline__ int max_shells(const PointIndex& ix, int r_lim) {
-  const int by_cost = (static_cast<int>(cbrtf(static_cast<float>(ix.n_sorted))) - 1) / 2;  // (2r+1)^3 probes ~ n points
-  return min(r_lim, max(kKnnMaxRing, by_cost));
+  const int by_cost = (static_cast<int>(sqrtf(sqrtf(2.0f * static_cast<float>(ix.n_sorted)))) - 1) / 2;
+  return min(r_lim, max(kKnnMinRing, by_cost));
 }
 
 }  // namespace
