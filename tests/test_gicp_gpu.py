@@ -237,3 +237,52 @@ def test_handles_are_independent_and_reusable(gmod, scene):
     a.setInputTarget(tgt[::2])
     a.align()
     assert np.array_equal(a.getFinalTransformation(), Tb)
+
+
+def test_concurrent_handles_from_threads(gmod, scene):
+    """four host threads, each with its own handle on the same GPU, registering at the same time: every result equals the
+    single-threaded one (handles share nothing but the device pool, which is keyed by stream)."""
+    import threading
+    tgt, src = scene
+    g0 = gmod.GeneralizedIterativeClosestPoint()
+    g0.setInputTarget(tgt)
+    g0.setInputSource(src)
+    g0.align()
+    want = g0.getFinalTransformation()
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            g = gmod.GeneralizedIterativeClosestPoint()
+            for rep in range(3):
+                g.setInputTarget(tgt)
+                g.setInputSource(src)
+                g.align()
+            results[tid] = g.getFinalTransformation()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid in range(4):
+        assert np.array_equal(results[tid], want)
+
+
+def test_repeated_registrations_are_bit_identical(gmod, pair):
+    """the same registration 200 times on one handle, inputs re-set every 20th time: identical transform every time."""
+    tgt, src = pair
+    g = gmod.GeneralizedIterativeClosestPoint()
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align()
+    want, st = g.getFinalTransformation(), g.stats()
+    for rep in range(200):
+        if rep % 20 == 19:
+            g.setInputSource(src)
+            g.setInputTarget(tgt)
+        g.align()
+        assert np.array_equal(g.getFinalTransformation(), want) and g.stats() == st, rep
