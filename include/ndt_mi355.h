@@ -159,6 +159,23 @@ ndt_status ndt_pcd_read_xyz(const char* path, void* out, size_t capacity_points,
                             int* is_dense);
 ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t stride_bytes, int binary);
 
+/* A directory of numbered scans, as the mapping node consumes it (lidar_subscriber/src/ndt_omp_mapping_node.cpp):
+ * process_new_clouds (:110-136) lists the *.pcd files whose number -- the integer after the last '_' of the file
+ * stem (extract_file_number, :231-239) -- is >= loaded_clouds + 1 and loads them in ascending order; the node calls
+ * it once at start-up and then once per second (:28-34, directory polling).  ndt_pcd_sequence_poll is that listing;
+ * ndt_pcd_sequence_next hands out the queued files one by one as x, y, z, 1.0f records (16 bytes) in page-locked host
+ * memory, and while the caller works on one scan the next file is read and parsed by a background thread (the two
+ * buffers alternate; a scan stays valid until the following call of ndt_pcd_sequence_next).
+ * next: *pts == NULL when nothing is queued.  A file that cannot be parsed returns NDT_ERR_INVALID and is skipped,
+ * like load_and_filter_cloud's nullptr (:138-141).  Works without a device (pageable buffers then). */
+typedef struct ndt_pcd_sequence* ndt_pcd_sequence_handle;
+ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out);
+ndt_status ndt_pcd_sequence_poll(ndt_pcd_sequence_handle s, size_t loaded_clouds, size_t* n_new_files);
+ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, size_t* n, int* is_dense, int* file_number);
+void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s);
+/* extract_file_number (:231-239) */
+int ndt_host_extract_file_number(const char* file_stem);
+
 /* ---- batch (map-build mode: many sources against the one target) ----------
  * Registers n_scans sources in lock-step, one fused derivative launch per
  * line-search step for the whole batch.  Scan k is points

@@ -131,3 +131,61 @@ def test_align_app_reproduces_readme_table(built_lib, pair, golden, tmp_path):
     # with the down-sample step (idempotent on an already filtered cloud up to the order of the points)
     out2 = subprocess.check_output([exe, tp, sp, "0.1"], text=True)
     assert "after the 0.10 m voxel grid" in out2
+
+
+@pytest.mark.gpu
+def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
+    """apps/map_sequence.cpp -- the mapping node's processing loop (ndt_omp_mapping_node.cpp:64-211) over the C-ABI:
+    numbered PCD scans in, voxel filter, consecutive registrations, pose chain, global map.  Checked against the same
+    loop built from the oracle's restatements (VoxelGrid, NDT, transformPointCloud, Eigen's Matrix4f product)."""
+    from oracle import pyoracle as po
+    from toyslam_amd import clouds, ndt
+    rng = np.random.default_rng(9)
+    world = clouds.target_surfaces(60000, seed=77, extent=60.0)[:, :3].astype(np.float32)
+    steps = [clouds.make_T([0.4, 0.1, 0.0], np.deg2rad([0.0, 0.0, 1.5])), clouds.make_T([0.5, -0.1, 0.02], np.deg2rad([0.2, 0.0, -1.0])),
+             clouds.make_T([0.3, 0.2, 0.0], np.deg2rad([0.0, -0.3, 2.0]))]
+    pose = np.eye(4)
+    scans = []
+    for k in range(4):  # the sensor moves through a static world: scan k = the world seen from pose k
+        if k:
+            pose = pose @ steps[k - 1]
+        pick = world[rng.choice(len(world), 30000, replace=False)]
+        scans.append((clouds.apply_T(np.linalg.inv(pose), pick) + rng.normal(0, 0.01, pick.shape)).astype(np.float32))
+    d = tmp_path / "pcd"
+    d.mkdir()
+    for k, sc in enumerate(scans, 1):
+        ndt.pcd_write_xyz(str(d / ("cloud_%d.pcd" % k)), sc)
+    (d / "cloud_3.pcd").rename(d / "cloud_03.pcd")  # numbers, not names, give the order
+    exe = str(tmp_path / "map_sequence")
+    libdir = os.path.join(ROOT, "toyslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "map_sequence.cpp"),
+                           "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
+    map_out = str(tmp_path / "map.pcd")
+    out = subprocess.check_output([exe, str(d), "0.5", map_out], text=True)
+    lines = out.splitlines()
+    traj = []
+    for i, ln in enumerate(lines):
+        if ln.startswith("trajectory["):
+            traj.append(np.array([[float(x) for x in lines[i + 1 + r].split()] for r in range(4)]))
+    assert len(traj) == 3 and "clouds 4  registrations 3 (not converged 0)" in out
+
+    # the same loop from the oracle's pieces
+    filt = [po.voxel_grid_filter(sc, 0.5)[0] for sc in scans]
+    glob = None
+    ref_map = po.voxel_grid_filter(filt[0], 0.5)[0]
+    for k in range(1, 4):
+        o = po.OracleNDT(resolution=1.0, step_size=0.1, trans_eps=0.01, max_iter=64, num_threads=8)
+        o.set_target(filt[k - 1])
+        o.set_source(filt[k])
+        r = o.align()
+        assert r["converged"]
+        glob = r["T"] if glob is None else ndt.host_chain_pose(glob, r["T"])
+        assert rot_err(traj[k - 1], glob) < 2e-4 and trans_err(traj[k - 1], glob) < 2e-3, k  # tolerances add up along the chain
+        moved = po.transform_cloud(np.c_[filt[k], np.ones(len(filt[k]), np.float32)], glob)[:, :3]
+        ref_map = po.voxel_grid_filter(np.concatenate([ref_map, moved]), 0.5)[0]
+        # ... and the registrations roughly recover the motion the scans were generated with (the node's epsilon of 0.01
+        # stops the Newton iteration early; independent random subsets of the world per scan)
+        assert trans_err(r["T"], steps[k - 1]) < 0.25
+    got_map, _ = ndt.pcd_read_xyz(map_out)
+    assert abs(len(got_map) - len(ref_map)) <= 0.005 * len(ref_map)  # poses differ in the last bits: a few voxels may flip
+    assert "global map %d points" % len(got_map) in out

@@ -217,3 +217,74 @@ def test_reader_survives_mutated_files_under_sanitizers(tmp_path):
     out = subprocess.run([exe, "5000", str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "no crash" in out.stdout
+
+
+# ------------------------------------------------------------------ numbered scans of a directory (the mapping node's input)
+def test_extract_file_number_follows_the_node(ndt):
+    """extract_file_number (ndt_omp_mapping_node.cpp:231-239): std::stoi of what follows the last underscore, -1 otherwise."""
+    cases = {"cloud_12": 12, "cloud_0007": 7, "a_b_42": 42, "scan_3extra": 3, "cloud": -1, "cloud_": -1, "cloud_x9": -1,
+             "x_-3": -3, "x_+8": 8, "x_ 5": 5, "x_99999999999": -1, "_1": 1}
+    for stem, want in cases.items():
+        assert ndt.extract_file_number(stem) == want, stem
+
+
+def test_sequence_order_polling_and_bad_files(ndt, tmp_path):
+    """process_new_clouds (:110-136): only *.pcd, only numbers >= loaded + 1, ascending by NUMBER (not by name); later
+    polls pick up files that have appeared since; a file that cannot be parsed is reported and skipped."""
+    rng = np.random.default_rng(5)
+    clouds = {k: rng.uniform(-5, 5, (50 + k, 3)).astype(np.float32) for k in (1, 2, 3, 10, 11)}
+    for k in (10, 2, 1):  # written out of order; "cloud_10" sorts before "cloud_2" by name
+        ndt.pcd_write_xyz(str(tmp_path / ("cloud_%d.pcd" % k)), clouds[k], binary=(k != 2))
+    (tmp_path / "notes_5.txt").write_text("not a scan")
+    ndt.pcd_write_xyz(str(tmp_path / "unnumbered.pcd"), clouds[1])
+    (tmp_path / "cloud_4.pcd").write_bytes(b"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 9\nHEIGHT 1\nPOINTS 9\nDATA binary\nxx")
+    seq = ndt.PcdSequence(str(tmp_path))
+    assert seq.next() is None  # nothing queued before the first poll
+    assert seq.poll(0) == 4  # 1, 2, 4 (broken), 10
+    got = []
+    from toyslam_amd import NdtError
+    for _ in range(4):
+        try:
+            xyz, dense, number = seq.next()
+            assert dense and np.array_equal(xyz, clouds[number])
+            got.append(number)
+        except NdtError as e:
+            assert "cloud_4.pcd" in str(e)
+            got.append("bad")
+    assert got == [1, 2, "bad", 10] and seq.next() is None
+    # three clouds are loaded: the next poll takes numbers >= 4 -- the node's rule re-lists 4 and 10 (its count of loaded
+    # clouds, not the last number, is the threshold) together with the newcomers
+    ndt.pcd_write_xyz(str(tmp_path / "cloud_3.pcd"), clouds[3])
+    ndt.pcd_write_xyz(str(tmp_path / "cloud_11.pcd"), clouds[11])
+    assert seq.poll(3) == 3
+    numbers = []
+    for _ in range(3):
+        try:
+            numbers.append(seq.next()[2])
+        except NdtError:
+            numbers.append("bad")
+    assert numbers == ["bad", 10, 11]
+    # with contiguous numbering from 1 (what lidar_subscriber_node writes) every file is delivered exactly once
+    assert seq.poll(11) == 0 and seq.next() is None
+    with pytest.raises(NdtError):
+        ndt.PcdSequence(str(tmp_path / "missing")).poll(0)
+
+
+def test_sequence_read_ahead_keeps_scans_intact(ndt, tmp_path):
+    """the two buffers alternate: a scan handed out stays intact while the next file is being read, for files of very
+    different sizes (buffers grow) in all three encodings."""
+    rng = np.random.default_rng(6)
+    sizes = [5, 40000, 17, 90000, 1, 30000, 30000, 64]
+    clouds = [rng.normal(0, 30, (n, 3)).astype(np.float32) for n in sizes]
+    for k, c in enumerate(clouds, 1):
+        ndt.pcd_write_xyz(str(tmp_path / ("cloud_%d.pcd" % k)), c, binary=(k % 3 != 0))
+    seq = ndt.PcdSequence(str(tmp_path))
+    assert seq.poll(0) == len(sizes)
+    for k, c in enumerate(clouds, 1):
+        xyz, dense, number = seq.next()
+        assert number == k and xyz.shape == c.shape
+        if k % 3 != 0:
+            assert np.array_equal(xyz, c)
+        else:  # ascii: decimal text of the writer's precision
+            assert np.allclose(xyz, c, rtol=2e-6, atol=0)
+    assert seq.next() is None

@@ -102,6 +102,11 @@ SIGNATURES = {
     "ndt_host_gauss": (None, [C.c_float, C.c_double, dp]),
     "ndt_host_run_driver": (C.c_int, [EVAL_CB, vp, C.c_size_t, fp, C.c_float, C.c_double, C.c_double, C.c_double,
                                       C.c_int, fp, ip, ip, dp, ip, ip]),
+    "ndt_pcd_sequence_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "ndt_pcd_sequence_poll": (C.c_int, [vp, C.c_size_t, szp]),
+    "ndt_pcd_sequence_next": (C.c_int, [vp, C.POINTER(vp), szp, ip, ip]),
+    "ndt_pcd_sequence_close": (None, [vp]),
+    "ndt_host_extract_file_number": (C.c_int, [C.c_char_p]),
     # GICP row (include/gicp_mi355.h)
     "gicp_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "gicp_destroy": (None, [vp]),

@@ -27,6 +27,7 @@
 #include "ndt_driver.hpp"
 #include "ndt_kernels.hpp"
 #include "ndt_pcd.hpp"
+#include "ndt_sequence.hpp"
 #include "ndt_mi355.h"
 
 namespace {
@@ -1595,6 +1596,60 @@ ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t
   }
   return NDT_OK;
 }
+
+// ---- N3: numbered scans of a directory, read ahead into page-locked buffers -------------------
+struct ndt_pcd_sequence {
+  std::unique_ptr<ndt::PcdSequence> seq;
+};
+
+ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out) {
+  if (!directory || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  // page-locked when a device is there (the scans go straight into ndt_set_input_* / ndt_voxel_grid_filter uploads),
+  // pageable otherwise -- reading files needs no GPU
+  const bool pinned = usable_devices() > 0;
+  auto alloc = [pinned](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+    return nullptr;
+  };
+  auto seq = new ndt_pcd_sequence();
+  if (pinned)
+    seq->seq.reset(new ndt::PcdSequence(directory, alloc, [](void* p) { (void)hipHostFree(p); }));
+  else
+    seq->seq.reset(new ndt::PcdSequence(directory, [](size_t bytes) { return std::malloc(bytes); }, [](void* p) { std::free(p); }));
+  *out = seq;
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_poll(ndt_pcd_sequence_handle s, size_t loaded_clouds, size_t* n_new_files) {
+  if (!s) return fail(NDT_ERR_INVALID, "null");
+  std::string err;
+  try {
+    const int n = s->seq->poll(loaded_clouds, err);
+    if (n < 0) return fail(NDT_ERR_INVALID, err);
+    if (n_new_files) *n_new_files = static_cast<size_t>(n);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("directory listing: ") + e.what());
+  }
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, size_t* n, int* is_dense, int* file_number) {
+  if (!s || !pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt::PcdSequence::Scan scan;
+  std::string err;
+  const int rc = s->seq->next(scan, err);
+  *pts = scan.pts;
+  *n = scan.n;
+  if (is_dense) *is_dense = scan.is_dense;
+  if (file_number) *file_number = scan.file_number;
+  if (rc == 2) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
+}
+
+void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s) { delete s; }
+
+int ndt_host_extract_file_number(const char* file_stem) { return file_stem ? ndt::extract_file_number(file_stem) : -1; }
 
 // ---- batch ---------------------------------------------------------------
 static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,

@@ -1,0 +1,120 @@
+// ndt_sequence.cpp -- see ndt_sequence.hpp.
+#include "ndt_sequence.hpp"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdlib>
+#include <filesystem>
+#include <utility>
+
+#include "ndt_pcd.hpp"
+
+namespace ndt {
+
+int extract_file_number(const std::string& stem) {
+  const size_t underscore = stem.find_last_of('_');
+  if (underscore == std::string::npos) return -1;
+  // std::stoi: optional white space, optional sign, then at least one digit; trailing text is ignored;
+  // no digits or out of int range -> exception -> the node's catch (...) -> -1
+  const char* s = stem.c_str() + underscore + 1;
+  char* end = nullptr;
+  errno = 0;
+  const long v = std::strtol(s, &end, 10);
+  if (end == s || errno == ERANGE || v < static_cast<long>(INT32_MIN) || v > static_cast<long>(INT32_MAX)) return -1;
+  return static_cast<int>(v);
+}
+
+PcdSequence::PcdSequence(std::string directory, Alloc alloc, Release release)
+    : dir_(std::move(directory)), alloc_(std::move(alloc)), release_(std::move(release)) {}
+
+PcdSequence::~PcdSequence() {
+  if (inflight_.valid()) inflight_.wait();
+  for (Slot& s : slots_)
+    if (s.buf) release_(s.buf);
+}
+
+int PcdSequence::poll(size_t loaded_clouds, std::string& err) {
+  namespace fs = std::filesystem;
+  std::error_code ec;
+  fs::directory_iterator it(dir_, ec);
+  if (ec) {
+    err = "cannot read directory " + dir_ + ": " + ec.message();
+    return -1;
+  }
+  std::vector<Entry> fresh;
+  const long long threshold = static_cast<long long>(loaded_clouds) + 1;
+  for (const fs::directory_entry& e : it) {
+    if (e.path().extension() != ".pcd") continue;
+    const int number = extract_file_number(e.path().stem().string());
+    if (number < threshold) continue;
+    // a file already queued and not yet handed out is not queued twice
+    bool queued = false;
+    for (size_t q = cursor_; q < queue_.size(); q++) queued = queued || queue_[q].path == e.path().string();
+    if (!queued) fresh.push_back(Entry{e.path().string(), number});
+  }
+  std::stable_sort(fresh.begin(), fresh.end(), [](const Entry& a, const Entry& b) { return a.number < b.number; });
+  for (Entry& e : fresh) queue_.push_back(std::move(e));
+  return static_cast<int>(fresh.size());
+}
+
+void PcdSequence::start_read(size_t index) {
+  if (index >= queue_.size()) return;
+  Slot* slot = &slots_[index & 1];
+  const std::string path = queue_[index].path;
+  inflight_index_ = index;
+  inflight_ = std::async(std::launch::async, [this, slot, path] {
+    slot->status = 0;
+    slot->err.clear();
+    slot->n = 0;
+    try {
+      size_t n_points = 0;
+      int fields = 0, kind = 0;
+      if (pcd_read_header(path.c_str(), &n_points, &fields, &kind, slot->err)) {
+        slot->status = 2;
+        return;
+      }
+      if (n_points > slot->cap_points || !slot->buf) {
+        if (slot->buf) release_(slot->buf);
+        slot->cap_points = std::max<size_t>(n_points + n_points / 4, 1024);
+        slot->buf = alloc_(slot->cap_points * 16);
+        if (!slot->buf) {
+          slot->cap_points = 0;
+          slot->err = "out of memory for a scan buffer";
+          slot->status = 2;
+          return;
+        }
+      }
+      if (pcd_read_xyz(path.c_str(), slot->buf, slot->cap_points, 16, &slot->n, &slot->dense, slot->err)) slot->status = 2;
+    } catch (const std::exception& e) {
+      slot->err = std::string("PCD: ") + e.what();
+      slot->status = 2;
+    }
+  });
+}
+
+int PcdSequence::next(Scan& out, std::string& err) {
+  out = Scan{};
+  if (cursor_ >= queue_.size()) return 1;
+  if (!(inflight_.valid() && inflight_index_ == cursor_)) {
+    if (inflight_.valid()) inflight_.wait();
+    start_read(cursor_);
+  }
+  inflight_.wait();
+  const size_t mine = cursor_++;
+  const Slot& slot = slots_[mine & 1];
+  // the other buffer is free now (its scan was handed out one call ago): read ahead into it
+  if (cursor_ < queue_.size()) start_read(cursor_);
+  out.file_number = queue_[mine].number;
+  out.path = queue_[mine].path.c_str();
+  if (slot.status) {
+    err = queue_[mine].path + ": " + slot.err;
+    return 2;
+  }
+  out.pts = slot.buf;
+  out.n = slot.n;
+  out.is_dense = slot.dense;
+  return 0;
+}
+
+}  // namespace ndt

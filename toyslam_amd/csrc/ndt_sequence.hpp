@@ -1,0 +1,67 @@
+// ndt_sequence.hpp -- a directory of numbered PCD scans read in order with the NEXT file parsed in the
+// background (host, no PCL, no ROS): the file handling of the reference's mapping node
+// (lidar_subscriber/src/ndt_omp_mapping_node.cpp:110-136 process_new_clouds, :231-239
+// extract_file_number) behind the C-ABI, row N3 of the scope table.
+#pragma once
+#include <cstddef>
+#include <functional>
+#include <future>
+#include <string>
+#include <vector>
+
+namespace ndt {
+
+// the number after the last underscore of a file stem, std::stoi semantics, -1 when there is none (:231-239)
+int extract_file_number(const std::string& stem);
+
+class PcdSequence {
+ public:
+  // alloc / release of the two scan buffers (pinned host memory when a GPU is there)
+  using Alloc = std::function<void*(size_t)>;
+  using Release = std::function<void(void*)>;
+  PcdSequence(std::string directory, Alloc alloc, Release release);
+  ~PcdSequence();
+  PcdSequence(const PcdSequence&) = delete;
+  PcdSequence& operator=(const PcdSequence&) = delete;
+
+  // process_new_clouds (:110-136): appends the *.pcd files whose number is >= loaded_clouds + 1, ascending by
+  // number.  Returns the number of files appended, -1 when the directory cannot be read (err set).
+  int poll(size_t loaded_clouds, std::string& err);
+  size_t pending() const { return queue_.size() - cursor_; }
+
+  struct Scan {
+    const void* pts = nullptr;  // x, y, z, 1.0f records of 16 bytes; valid until the next call of next()
+    size_t n = 0;
+    int is_dense = 1;
+    int file_number = -1;
+    const char* path = nullptr;
+  };
+  // The next queued file (0), nothing queued (1), or a file that cannot be read (2: err set, the file is skipped,
+  // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following file is being read.
+  int next(Scan& out, std::string& err);
+
+ private:
+  struct Entry {
+    std::string path;
+    int number;
+  };
+  struct Slot {
+    void* buf = nullptr;
+    size_t cap_points = 0;
+    size_t n = 0;
+    int dense = 1;
+    int status = 0;
+    std::string err;
+  };
+  void start_read(size_t index);
+  std::string dir_;
+  Alloc alloc_;
+  Release release_;
+  std::vector<Entry> queue_;
+  size_t cursor_ = 0;
+  Slot slots_[2];
+  std::future<void> inflight_;
+  size_t inflight_index_ = static_cast<size_t>(-1);
+};
+
+}  // namespace ndt

@@ -437,3 +437,39 @@ def host_run_driver(evaluator, n_source, guess=None, resolution=1.0, step_size=0
                                          C.byref(tp), C.byref(ne), C.byref(nh)))
     return dict(T=_from_colmajor(T), converged=bool(conv.value), iterations=it.value, trans_probability=tp.value,
                 n_evals=ne.value, n_hessian_recomputes=nh.value)
+
+
+def extract_file_number(stem):
+    """extract_file_number of the mapping node (ndt_omp_mapping_node.cpp:231-239)."""
+    return _lib.lib().ndt_host_extract_file_number(stem.encode())
+
+
+class PcdSequence:
+    """The numbered *.pcd scans of a directory in the mapping node's order (process_new_clouds,
+    ndt_omp_mapping_node.cpp:110-136), the next file being read in the background."""
+
+    def __init__(self, directory):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.ndt_pcd_sequence_open(os.fsencode(directory), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            self._L.ndt_pcd_sequence_close(self._h)
+        except Exception:
+            pass
+
+    def poll(self, loaded_clouds):
+        n = C.c_size_t(0)
+        check(self._L.ndt_pcd_sequence_poll(self._h, loaded_clouds, C.byref(n)))
+        return n.value
+
+    def next(self):
+        """-> (xyz (n,3) float32 copy, is_dense, file_number) or None when nothing is queued."""
+        p, n, dense, num = C.c_void_p(), C.c_size_t(0), C.c_int(1), C.c_int(-1)
+        check(self._L.ndt_pcd_sequence_next(self._h, C.byref(p), C.byref(n), C.byref(dense), C.byref(num)))
+        if not p.value:
+            return None
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 4))
+        return a[:, :3].copy(), bool(dense.value), num.value
