@@ -175,6 +175,13 @@ ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, si
 void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s);
 /* extract_file_number (:231-239) */
 int ndt_host_extract_file_number(const char* file_stem);
+/* pcl::fromROSMsg(sensor_msgs::PointCloud2, PointCloud<PointXYZ>) for the layouts lidar drivers publish
+ * (ndt_rosbag_mapping_node.cpp:45-50): n records of point_step bytes with three f32 fields at byte offsets
+ * off_x, off_y, off_z -- any step and any offsets, aligned or not (e.g. the 22-byte x,y,z,intensity,ring,time
+ * records of a Velodyne driver) -- repacked into x, y, z, 1.0f records of 16 bytes, which is what every other
+ * entry point takes with stride 16.  Host only.  *is_dense = every coordinate finite. */
+ndt_status ndt_host_repack_fields(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                                  void* out_xyz1, int* is_dense);
 
 /* ---- batch (map-build mode: many sources against the one target) ----------
  * Registers n_scans sources in lock-step, one fused derivative launch per

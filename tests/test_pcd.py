@@ -288,3 +288,27 @@ def test_sequence_read_ahead_keeps_scans_intact(ndt, tmp_path):
         else:  # ascii: decimal text of the writer's precision
             assert np.allclose(xyz, c, rtol=2e-6, atol=0)
     assert seq.next() is None
+
+
+def test_pointcloud2_style_records(ndt):
+    """ndt_host_repack_fields: what pcl::fromROSMsg does for the rosbag node (ndt_rosbag_mapping_node.cpp:45-50) -- x, y, z
+    picked by byte offset out of records of any step, here the unaligned 22-byte Velodyne layout and a reordered one."""
+    rng = np.random.default_rng(8)
+    n = 1000
+    xyz = rng.normal(0, 20, (n, 3)).astype(np.float32)
+    velodyne = np.dtype({"names": ["x", "y", "z", "intensity", "ring", "time"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u2", "<f4"],
+                         "offsets": [0, 4, 8, 12, 16, 18], "itemsize": 22})
+    rec = np.zeros(n, dtype=velodyne)
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    rec["ring"] = rng.integers(0, 32, n)
+    out, dense = ndt.repack_fields(rec.tobytes(), n, 22)
+    assert dense and np.array_equal(out[:, :3], xyz) and np.all(out[:, 3] == 1)
+    odd = np.dtype({"names": ["t", "z", "pad", "x", "y"], "formats": ["<f8", "<f4", "u1", "<f4", "<f4"], "offsets": [0, 8, 12, 13, 17], "itemsize": 21})
+    rec2 = np.zeros(n, dtype=odd)
+    rec2["x"], rec2["y"], rec2["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    rec2["x"][7] = np.nan
+    out2, dense2 = ndt.repack_fields(rec2.tobytes(), n, 21, off_x=13, off_y=17, off_z=8)
+    assert not dense2 and np.array_equal(out2[:, :3], np.c_[rec2["x"], rec2["y"], rec2["z"]], equal_nan=True)
+    from toyslam_amd import NdtError
+    with pytest.raises(NdtError):
+        ndt.repack_fields(rec.tobytes(), n, 22, off_x=20)

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ndt_pcd_sequence_next": (C.c_int, [vp, C.POINTER(vp), szp, ip, ip]),
     "ndt_pcd_sequence_close": (None, [vp]),
     "ndt_host_extract_file_number": (C.c_int, [C.c_char_p]),
+    "ndt_host_repack_fields": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, ip]),
     # GICP row (include/gicp_mi355.h)
     "gicp_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "gicp_destroy": (None, [vp]),

@@ -1651,6 +1651,30 @@ void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s) { delete s; }
 
 int ndt_host_extract_file_number(const char* file_stem) { return file_stem ? ndt::extract_file_number(file_stem) : -1; }
 
+ndt_status ndt_host_repack_fields(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                                  void* out_xyz1, int* is_dense) {
+  if ((n && (!data || !out_xyz1)) || point_step < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  for (size_t off : {off_x, off_y, off_z})
+    if (off + sizeof(float) > point_step) return fail(NDT_ERR_INVALID, "field offset outside the point record");
+  const unsigned char* src = static_cast<const unsigned char*>(data);
+  float* dst = static_cast<float*>(out_xyz1);
+  bool finite = true;
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char* rec = src + i * point_step;
+    float v[3];
+    std::memcpy(&v[0], rec + off_x, sizeof(float));  // unaligned-safe
+    std::memcpy(&v[1], rec + off_y, sizeof(float));
+    std::memcpy(&v[2], rec + off_z, sizeof(float));
+    finite = finite && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]);
+    dst[4 * i] = v[0];
+    dst[4 * i + 1] = v[1];
+    dst[4 * i + 2] = v[2];
+    dst[4 * i + 3] = 1.0f;
+  }
+  if (is_dense) *is_dense = finite ? 1 : 0;
+  return NDT_OK;
+}
+
 // ---- batch ---------------------------------------------------------------
 static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
                                    bool on_device, const float* guesses, float* final_T, int* conv, int* iters,

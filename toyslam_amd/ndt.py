@@ -473,3 +473,13 @@ class PcdSequence:
             return None
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 4))
         return a[:, :3].copy(), bool(dense.value), num.value
+
+
+def repack_fields(data, n, point_step, off_x=0, off_y=4, off_z=8):
+    """PointCloud2-style records (bytes-like, any step / offsets) -> ((n, 4) float32 x,y,z,1, is_dense)."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    assert buf.size >= n * point_step
+    out = np.zeros((n, 4), dtype=np.float32)
+    dense = C.c_int(1)
+    check(_lib.lib().ndt_host_repack_fields(buf.ctypes.data, n, point_step, off_x, off_y, off_z, out.ctypes.data, C.byref(dense)))
+    return out, bool(dense.value)
