@@ -21,6 +21,26 @@ for name in ("pair", "large"):
     open("%s/kernel_stats_%s.csv" % (O, name), "w").write(open(f).read())
     out["kernels"][name] = {r["Name"][:90]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                             "pct": float(r["Percentage"])} for r in list(csv.DictReader(open(f)))[:8]}
+# roofline (HBM, 8 TB/s) of the three GICP kernels from their longest call in each run: algorithmic bytes as DESIGN.md section 9
+# states them -- covariances n (16 + 16 k + 48), correspondence step n (16 + 16 + 2 * 48 + 40), objective m (16 + 16 + 4 + 36)
+out["roofline"] = {}
+for name in ("pair", "large"):
+    t = out["timings"][name]
+    nt, ns, k, m = t["n_target"], t["n_source"], 20, t["n_source"]
+    rows = {r: v for r, v in out["kernels"][name].items()}
+    def pick(prefix):
+        for r, v in rows.items():
+            if prefix in r:
+                return v
+        return None
+    rl = {}
+    for kern, nbytes, which in (("k_knn_covariances", nt * (16 + 16 * k + 48), "max_us"), ("k_correspond", ns * (16 + 16 + 96 + 40), "max_us"),
+                                ("k_functor<2>", m * 72, "avg_us")):
+        v = pick(kern)
+        if v:
+            gbs = nbytes / (v[which] * 1e-6) / 1e9
+            rl[kern] = {"bound": "hbm", "algorithmic_bytes": nbytes, "kernel_us": v[which], "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0}
+    out["roofline"][name] = rl
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:5000])
 PY

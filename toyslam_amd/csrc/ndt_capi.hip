@@ -196,7 +196,7 @@ struct DeviceGrid {
   bool counts_known = true;     // host copies above are current (grid_counts() fetches them lazily)
   // getFitnessScore's nearest-neighbour search: cell -> leaf ordinal (or -1), built on first use
   std::mutex fit_mu;
-  DevBuf<int> cell2leaf;
+  DevBuf<uint2> cell_range;  // per cell: its segment of cell_pts (count 0 = empty)
   DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
   DevBuf<int> row_any;      // per x-row of cells: occupied or not
   bool have_cell2leaf = false;
@@ -1314,13 +1314,13 @@ namespace {
 ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g) {
   std::lock_guard<std::mutex> lock(g->fit_mu);
   if (!g->have_cell2leaf) {
-    HIP_TRY(g->cell2leaf.reserve(static_cast<size_t>(g->geom.n_cells)));
-    HIP_TRY(hipMemsetAsync(g->cell2leaf.p, 0xFF, static_cast<size_t>(g->geom.n_cells) * sizeof(int), h->stream));
+    HIP_TRY(g->cell_range.reserve(static_cast<size_t>(g->geom.n_cells)));
+    HIP_TRY(hipMemsetAsync(g->cell_range.p, 0, static_cast<size_t>(g->geom.n_cells) * sizeof(uint2), h->stream));
     const size_t n_rows = static_cast<size_t>(g->geom.div_b[1]) * static_cast<size_t>(g->geom.div_b[2]);
     HIP_TRY(g->row_any.reserve(n_rows));
     HIP_TRY(hipMemsetAsync(g->row_any.p, 0, n_rows * sizeof(int), h->stream));
-    HIP_TRY(ndt::launch_cell_to_leaf(g->leaf_cell.p, static_cast<int>(g->n_leaves), g->cell2leaf.p, g->geom.div_b[0], g->row_any.p,
-                                     h->stream));
+    HIP_TRY(ndt::launch_cell_ranges(g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, static_cast<int>(g->n_leaves), g->cell_range.p,
+                                    g->geom.div_b[0], g->row_any.p, h->stream));
     HIP_TRY(g->cell_pts.reserve(g->target->n));
     HIP_TRY(ndt::launch_gather_points(g->target->pts.p, g->sorted_idx.p, g->counts.p, static_cast<int>(g->target->n), g->cell_pts.p,
                                       h->stream));
@@ -1342,10 +1342,8 @@ void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix) {
   ix.pts = g->target->pts.p;
   ix.n = static_cast<int>(g->target->n);
   ix.geom = g->geom;
-  ix.cell2leaf = g->cell2leaf.p;
+  ix.cell_range = g->cell_range.p;
   ix.row_any = g->row_any.p;
-  ix.leaf_start = g->leaf_start.p;
-  ix.leaf_count = g->leaf_count.p;
   ix.sorted_idx = g->sorted_idx.p;
   ix.sorted_pts = g->cell_pts.p;
   ix.n_sorted = static_cast<int>(g->n_sorted);

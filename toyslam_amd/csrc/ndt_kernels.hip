@@ -748,11 +748,14 @@ __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__
 // Distances as [FLANN] L2_Simple computes them: f32, (dx*dx + dy*dy) + dz*dz, no contraction.
 // acc[0] = sum of the accepted squared distances (f64), acc[1] = their count.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cell_to_leaf(const int* __restrict__ leaf_cell, int n_leaves, int* __restrict__ cell2leaf,
-                                                         int div_x, int* __restrict__ row_any) {
+__global__ __launch_bounds__(kBlock) void k_cell_ranges(const int* __restrict__ leaf_cell, const unsigned* __restrict__ leaf_start,
+                                                        const int* __restrict__ leaf_count, int n_leaves, uint2* __restrict__ cell_range,
+                                                        int div_x, int* __restrict__ row_any) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_leaves; i += gridDim.x * kBlock) {
     const int c = leaf_cell[i];
-    cell2leaf[c] = i;
+    // the cell's segment of the cell-ordered points, in the table itself: a probe that finds an occupied cell needs
+    // no second dependent lookup (on a 40 MB table of a 1M-point target that lookup is another trip to HBM)
+    cell_range[c] = make_uint2(leaf_start[i], static_cast<unsigned>(leaf_count[i]));
     row_any[c / div_x] = 1;  // the x-row (y, z) of this cell holds points: empty rows are skipped by the shell search
   }
 }
@@ -1076,9 +1079,10 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
   return hipGetLastError();
 }
 
-hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, int div_x, int* row_any, hipStream_t stream) {
-  hipLaunchKernelGGL(k_cell_to_leaf, dim3(grid_for(n_leaves, 1024)), dim3(kBlock), 0, stream, leaf_cell, n_leaves, cell2leaf, div_x,
-                     row_any);
+hipError_t launch_cell_ranges(const int* leaf_cell, const unsigned* leaf_start, const int* leaf_count, int n_leaves, uint2* cell_range,
+                              int div_x, int* row_any, hipStream_t stream) {
+  hipLaunchKernelGGL(k_cell_ranges, dim3(grid_for(n_leaves, 1024)), dim3(kBlock), 0, stream, leaf_cell, leaf_start, leaf_count, n_leaves,
+                     cell_range, div_x, row_any);
   return hipGetLastError();
 }
 

@@ -44,10 +44,8 @@ struct PointIndex {
   const float4* pts = nullptr;  // caller's order
   int n = 0;
   ndt::GridGeom geom{};
-  const int* cell2leaf = nullptr;        // n_cells: occupied-cell ordinal or -1
+  const uint2* cell_range = nullptr;     // n_cells: (first position, count) of the cell's points in the cell order; count 0 = empty
   const int* row_any = nullptr;          // div_y * div_z: 1 where the x-row (y, z) has an occupied cell
-  const unsigned* leaf_start = nullptr;  // per occupied cell: first entry of its segment in sorted_idx
-  const int* leaf_count = nullptr;
   const int* sorted_idx = nullptr;  // point indices grouped by cell
   const float4* sorted_pts = nullptr;  // the points in that order (launch_gather_points)
   int n_sorted = 0;
@@ -158,8 +156,9 @@ hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, cons
 // all live scans of a lock-step batch step in one launch, kinds mixed (descs[scan].kind, .pad = rows written)
 hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
                              int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);
-// cell2leaf (pre-set to -1) and row_any (pre-set to 0, div_y * div_z entries) of a built grid
-hipError_t launch_cell_to_leaf(const int* leaf_cell, int n_leaves, int* cell2leaf, int div_x, int* row_any, hipStream_t stream);
+// cell_range (pre-set to 0) and row_any (pre-set to 0, div_y * div_z entries) of a built grid
+hipError_t launch_cell_ranges(const int* leaf_cell, const unsigned* leaf_start, const int* leaf_count, int n_leaves, uint2* cell_range,
+                              int div_x, int* row_any, hipStream_t stream);
 // [PCL] getFitnessScore: team search over the target's point index (ndt_search.hpp); partials [n_blocks][kEvalStride]
 hipError_t launch_fitness(const float4* src, int n, const float* T12, const PointIndex& tgt, double max_range, int n_blocks,
                           double* partials, hipStream_t stream);

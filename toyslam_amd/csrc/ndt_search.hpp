@@ -116,18 +116,14 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
     const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
     const int nx = face ? w : 2;
     for (int t = 0; t < w; t++) {
-      int lf = -1;
+      uint2 range = make_uint2(0u, 0u);
       if (row_ok && t < nx) {
         const int x = ci + (face ? t - r : (t == 0 ? -r : r));
-        if (x >= 0 && x < g.div_b[0]) lf = ix.cell2leaf[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+        if (x >= 0 && x < g.div_b[0]) range = ix.cell_range[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
       }
-      unsigned first = 0;
-      int count = 0;
-      if (lf >= 0) {
-        first = ix.leaf_start[lf];
-        count = ix.leaf_count[lf];
-      }
-      unsigned found = static_cast<unsigned>((__ballot(lf >= 0) >> team_base) & 0xffull);
+      const unsigned first = range.x;
+      const int count = static_cast<int>(range.y);
+      unsigned found = static_cast<unsigned>((__ballot(count > 0) >> team_base) & 0xffull);
       while (found) {
         const int owner = __builtin_ctz(found);
         found &= found - 1;
