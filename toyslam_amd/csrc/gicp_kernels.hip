@@ -23,7 +23,7 @@ using namespace ndt;
 
 namespace {
 
-constexpr int kKnnBlock = 64;   // one wave = 8 query teams per block: the candidate lists take k * 544 B of LDS
+constexpr int kKnnBlock = 64;   // one wave = 8 query teams per block
 
 // [Eigen] Matrix4f * Vector4f (column by column): row r = ((T_r0 x + T_r1 y) + T_r2 z) + T_r3 * 1
 __device__ __forceinline__ void matvec_eigen(const float* T12, float x, float y, float z, float& ox, float& oy, float& oz) {
@@ -37,68 +37,100 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
                                                                double* __restrict__ cov6, int* __restrict__ nn_idx,
                                                                float* __restrict__ nn_d2) {
 #pragma clang fp contract(off)
+  // One candidate list PER TEAM (k entries, unordered, its worst entry tracked), not one per lane: an eighth of the
+  // LDS (the per-lane lists capped the kernel at 3.5 waves per SIMD) and a bound every lane prunes with.  A candidate
+  // that beats the worst entry replaces it and the team finds the new worst together; order is established once, at the
+  // end, by a rank sort.  Entries are POSITIONS in the cell order; the point index behind one is looked up only when
+  // two distances are equal (the tie rule is on the index) and at the end.
   constexpr int kTeams = kKnnBlock / kTeam;
   extern __shared__ unsigned char knn_lds[];
-  float* sd = reinterpret_cast<float*>(knn_lds);         // [k][64] this lane's candidates: distances, ascending
-  int* si = reinterpret_cast<int*>(sd + k * kKnnBlock);  // [k][64] and their point indices
-  int* merged = si + k * kKnnBlock;                      // [k][8]  the team's k nearest, in order
-  const int lane = threadIdx.x, sub = lane & (kTeam - 1), team = lane / kTeam;
+  const int lane = threadIdx.x, sub = lane & (kTeam - 1), team = lane / kTeam, team_base = lane & ~(kTeam - 1);
+  float* ld = reinterpret_cast<float*>(knn_lds) + team * k;                    // [8][k] distances
+  int* lp = reinterpret_cast<int*>(knn_lds) + kTeams * k + team * k;           // [8][k] positions
+  int* ordered = reinterpret_cast<int*>(knn_lds) + 2 * kTeams * k + team * k;  // [8][k] point indices, ascending (distance, index)
   const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
   const int r_max = max_shells(ix, r_lim);
+  auto lds_fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };  // one wave per block: program order is enough
   for (int i = blockIdx.x * kTeams + team; i < ix.n; i += gridDim.x * kTeams) {  // i is uniform within a team
     const float4 q = ix.pts[i];
-    int cnt = 0;  // this lane's list length
+    int cnt = 0;  // entries in the list (team-uniform, like everything below that is not marked "lane")
     float worst = INFINITY;
-    int worst_i = 0;  // (a position; only read when worst is a real distance)
-    // The lists hold POSITIONS in the cell order; the point index behind a position is only looked up when two
-    // distances are equal (the tie rule is on the index) and once at the end -- an index load per inserted
-    // candidate would be one more dependent memory round trip on the query's critical path.
+    int worst_p = 0, worst_slot = 0;
     auto before = [&](float da, int pa, float db, int pb) {  // (distance, index) order
       return da < db || (da == db && ix.sorted_idx[pa] < ix.sorted_idx[pb]);
     };
-    auto consider = [&](float d, unsigned upos) {
-      const int pos = static_cast<int>(upos);
-      if (cnt == k && !before(d, pos, worst, worst_i)) return;
-      int j = (cnt < k) ? cnt++ : k - 1;
-      while (j > 0) {
-        const float pd = sd[(j - 1) * kKnnBlock + lane];
-        const int pp = si[(j - 1) * kKnnBlock + lane];
-        if (before(pd, pp, d, pos)) break;
-        sd[j * kKnnBlock + lane] = pd;
-        si[j * kKnnBlock + lane] = pp;
-        j--;
+    auto find_worst = [&] {  // the list's last entry in (distance, index) order
+      float bd = -1.0f;  // lane: best so far over my slots
+      int bp = 0, bs = -1;
+      for (int j = sub; j < cnt; j += kTeam) {
+        const float d = ld[j];
+        const int p = lp[j];
+        if (bs < 0 || before(bd, bp, d, p)) {
+          bd = d;
+          bp = p;
+          bs = j;
+        }
       }
-      sd[j * kKnnBlock + lane] = d;
-      si[j * kKnnBlock + lane] = pos;
-      if (cnt == k) {
-        worst = sd[(k - 1) * kKnnBlock + lane];
-        worst_i = si[(k - 1) * kKnnBlock + lane];
+#pragma unroll
+      for (int off = 1; off < kTeam; off <<= 1) {
+        const float od = __shfl_xor(bd, off, kWave);
+        const int op = __shfl_xor(bp, off, kWave), os = __shfl_xor(bs, off, kWave);
+        if (os >= 0 && (bs < 0 || before(bd, bp, od, op))) {
+          bd = od;
+          bp = op;
+          bs = os;
+        }
+      }
+      worst = bd;
+      worst_p = bp;
+      worst_slot = bs;
+    };
+    // every lane brings one candidate (or none); the ones that can enter the list are taken one at a time
+    auto offer = [&](float d, unsigned upos, bool ok) {
+      const int pos = static_cast<int>(upos);
+      const bool want = ok && (cnt < k || before(d, pos, worst, worst_p));
+      unsigned pending = static_cast<unsigned>((__ballot(want) >> team_base) & 0xffull);
+      while (pending) {
+        const int owner = __builtin_ctz(pending);
+        pending &= pending - 1;
+        const float cd = __shfl(d, team_base + owner, kWave);
+        const int cp = __shfl(pos, team_base + owner, kWave);
+        if (cnt < k) {
+          if (sub == 0) {
+            ld[cnt] = cd;
+            lp[cnt] = cp;
+          }
+          lds_fence();
+          cnt++;
+          if (cnt == k) find_worst();
+        } else if (before(cd, cp, worst, worst_p)) {
+          if (sub == 0) {
+            ld[worst_slot] = cd;
+            lp[worst_slot] = cp;
+          }
+          lds_fence();
+          find_worst();
+        }
       }
     };
     int ci, cj, ck;
     query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck);
     bool done = false;
     for (int r = 0; r <= r_max && !done; r++) {
-      team_shell(ix, ci, cj, ck, r, sub, q.x, q.y, q.z, consider);
-      // Every unvisited point is at least r cells (less the index-rounding slack) away.  Once k visited
-      // candidates lie strictly inside that reach no unvisited point can enter the k nearest: a candidate
-      // a lane has dropped was beaten by k better ones of the same lane, so counting the lists is enough.
+      team_shell(ix, ci, cj, ck, r, sub, q.x, q.y, q.z, offer);
+      // Every unvisited point is at least r cells (less the index-rounding slack) away: once the k-th best lies
+      // strictly inside that reach no unvisited point can enter the k nearest.
       const float reach = static_cast<float>(r) * leaf - ix.slack;
-      int inside = 0;
-      if (reach > 0.0f)
-        for (int j = 0; j < cnt && sd[j * kKnnBlock + lane] < reach * reach; j++) inside++;
-      if (team_sum(inside) >= k || r >= r_lim) done = true;
+      if ((cnt == k && reach > 0.0f && worst < reach * reach) || r >= r_lim) done = true;
     }
     if (!done) {
       // Sparse neighbourhood: the team looks at every point, twice.  Pass 1 only keeps each lane's eight smallest
       // distances, in registers; the k-th smallest of the team's 64 values bounds the k-th neighbour's distance
-      // from above.  Pass 2 feeds the candidate lists with the points inside that bound -- about k of them.
-      // (One pass with the lists alone spends its time shifting list entries in LDS: a lane that sees an eighth
-      // of the points in arbitrary order inserts hundreds of them before its own k-th best is a useful bound.)
+      // from above.  Pass 2 fills the list with the points inside that bound -- about k of them.
       float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY, m4 = INFINITY, m5 = INFINITY, m6 = INFINITY, m7 = INFINITY;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned, const float4&) {
-        if (!(d < m7)) return;
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned, const float4&, bool ok) {
+        if (!ok || !(d < m7)) return;
         m7 = d;  // bubble the newcomer down the sorted registers
         float t;
         if (m7 < m6) { t = m6; m6 = m7; m7 = t; }
@@ -110,7 +142,7 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
         if (m1 < m0) { t = m0; m0 = m1; m1 = t; }
       });
       float bound = INFINITY;
-      for (int j = 0; j < k; j++) {  // pop the team's smallest head k times (k <= 64 values exist: n >= k)
+      for (int j = 0; j < k; j++) {  // pop the team's smallest head k times (n >= k values exist)
         float h = m0;
         int who = sub;
         team_min(h, who);
@@ -119,30 +151,28 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       }
       cnt = 0;
       worst = INFINITY;
-      worst_i = 0;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned pos, const float4&) {
-        if (d > bound) return;
-        consider(d, pos);
-      });
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z,
+               [&](float d, unsigned pos, const float4&, bool ok) { offer(d, pos, ok && !(d > bound)); });
     }
-    for (int j = 0; j < cnt; j++) si[j * kKnnBlock + lane] = ix.sorted_idx[si[j * kKnnBlock + lane]];  // positions -> point indices
-    // k-way merge of the eight sorted lists: k rounds of "smallest head wins"
-    int head = 0;
-    for (int j = 0; j < k; j++) {
-      float d = (head < cnt) ? sd[head * kKnnBlock + lane] : INFINITY;
-      int idx = (head < cnt) ? si[head * kKnnBlock + lane] : 0x7fffffff;
-      const float my_d = d;
-      const int my_i = idx;
-      team_min(d, idx);
-      if (head < cnt && my_d == d && my_i == idx) head++;  // (distance, index) pairs are unique: one winner
-      if (sub == 0) {
-        merged[j * kTeams + team] = idx;
-        if (nn_idx) {
-          nn_idx[static_cast<size_t>(i) * k + j] = (idx == 0x7fffffff) ? -1 : idx;
-          nn_d2[static_cast<size_t>(i) * k + j] = d;
-        }
+    // rank sort: entry j goes to the place given by the number of entries before it
+    for (int j = sub; j < cnt; j += kTeam) {
+      const float d = ld[j];
+      const int p = lp[j];
+      int rank = 0;
+      for (int t = 0; t < cnt; t++) rank += (t != j && before(ld[t], lp[t], d, p)) ? 1 : 0;
+      const int idx = ix.sorted_idx[p];
+      ordered[rank] = idx;
+      if (nn_idx) {
+        nn_idx[static_cast<size_t>(i) * k + rank] = idx;
+        nn_d2[static_cast<size_t>(i) * k + rank] = d;
       }
     }
+    if (nn_idx)
+      for (int j = cnt + sub; j < k; j += kTeam) {  // (only a cloud smaller than k, which the host refuses)
+        nn_idx[static_cast<size_t>(i) * k + j] = -1;
+        nn_d2[static_cast<size_t>(i) * k + j] = INFINITY;
+      }
+    lds_fence();
     if (sub != 0) continue;  // the 3x3 algebra of a query is one lane's work
     // :81-105  f32 products, f64 sums, neighbours in ascending distance
     double mx = 0, my = 0, mz = 0, cxx = 0, cyx = 0, cyy = 0, czx = 0, czy = 0, czz = 0;
@@ -157,17 +187,16 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       czy += static_cast<double>(t.z * t.y);
       czz += static_cast<double>(t.z * t.z);
     };
-    // (an index can only be missing if the cloud had fewer than k points, which the host refuses; clamped anyway)
-    auto fetch = [&](int j) { return ix.pts[min(merged[j * kTeams + team], ix.n - 1)]; };
+    auto fetch = [&](int j) { return ix.pts[min(max(ordered[j], 0), ix.n - 1)]; };
     int j = 0;
-    for (; j + 4 <= k; j += 4) {  // four gathers in flight, added in order
+    for (; j + 4 <= cnt; j += 4) {  // four gathers in flight, added in order
       const float4 t0 = fetch(j), t1 = fetch(j + 1), t2 = fetch(j + 2), t3 = fetch(j + 3);
       add(t0);
       add(t1);
       add(t2);
       add(t3);
     }
-    for (; j < k; j++) add(fetch(j));
+    for (; j < cnt; j++) add(fetch(j));
     const double kd = static_cast<double>(k);
     mx /= kd;
     my /= kd;
@@ -224,8 +253,8 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
     matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
     float best = INFINITY;  // this lane's share: distance and POSITION in the cell order (the index behind it is
     int best_p = -1;        // looked up on ties and at the end of a shell only)
-    auto consider = [&](float d, unsigned pos) {
-      if (d > best) return;
+    auto consider = [&](float d, unsigned pos, bool ok) {
+      if (!ok || d > best) return;
       if (d < best || ix.sorted_idx[pos] < ix.sorted_idx[best_p]) {  // equal distance: the lower index
         best = d;
         best_p = static_cast<int>(pos);
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
         done = true;
     }
     if (!done) {  // (a point met twice changes nothing for a single nearest neighbour: the shells' best stays as the bound)
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, [&](float d, unsigned pos, const float4&) { consider(d, pos); });
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, [&](float d, unsigned pos, const float4&, bool ok) { consider(d, pos, ok); });
       tb = best;
       tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
       team_min(tb, tb_i);
@@ -373,7 +402,7 @@ hipError_t launch_knn_covariances(const PointIndex& ix, int k, double gicp_epsil
   if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
   constexpr int kQueriesPerBlock = kKnnBlock / kTeam;
   const int blocks = max(1, min(65536, (ix.n + kQueriesPerBlock - 1) / kQueriesPerBlock));
-  const size_t lds = static_cast<size_t>(k) * (kKnnBlock * 8 + kQueriesPerBlock * 4);
+  const size_t lds = static_cast<size_t>(k) * kQueriesPerBlock * 12;  // per team: k distances, k positions, k ordered indices
   hipLaunchKernelGGL(k_knn_covariances, dim3(blocks), dim3(kKnnBlock), lds, stream, ix, k, gicp_epsilon, cov6, nn_idx, nn_d2);
   return hipGetLastError();
 }

@@ -789,7 +789,9 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
     xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
     if (!finite3(tx, ty, tz)) continue;
     float best = INFINITY;  // this lane's share of the candidates
-    auto consider = [&](float d, unsigned) { best = fminf(best, d); };
+    auto consider = [&](float d, unsigned, bool ok) {
+      if (ok) best = fminf(best, d);
+    };
     int ci, cj, ck;
     query_cell(ix.geom, tx, ty, tz, ci, cj, ck);
     bool done = false;
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
       if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
     }
     if (!done) {  // sparse neighbourhood: the team scans everything
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, [&](float d, unsigned pos, const float4&) { consider(d, pos); });
+      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, [&](float d, unsigned pos, const float4&, bool ok) { consider(d, pos, ok); });
       tb = best;
 #pragma unroll
       for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));

@@ -30,40 +30,37 @@ __device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, 
 constexpr int kTeam = 8;
 
 // squared distances from (qx,qy,qz) to this lane's share of the `count` cell-ordered points starting at
-// `first` (positions sub, sub + 8, ...), two loads in flight; visit(d, position in the cell order)
+// `first` (positions sub, sub + 8, ...), two loads in flight.  visit(d, position in the cell order, valid) is
+// called the same number of times by every lane of the team (valid = false past the end), so that a visitor may
+// use team-wide operations.
 template <class F>
 __device__ __forceinline__ void scan_run(const float4* __restrict__ sp, unsigned first, int count, int sub, float qx, float qy,
                                          float qz, F&& visit) {
-  int p = sub;
-  for (; p + kTeam < count; p += 2 * kTeam) {
-    const float4 a = sp[first + p], b = sp[first + p + kTeam];
+  for (int base = 0; base < count; base += 2 * kTeam) {
+    const int p0 = base + sub, p1 = p0 + kTeam;
+    const bool v0 = p0 < count, v1 = p1 < count;
+    // clamped, not predicated: both loads issue together (count >= 1 here)
+    const float4 a = sp[first + min(p0, count - 1)], b = sp[first + min(p1, count - 1)];
     const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
-    visit(da, first + p);
-    visit(db, first + p + kTeam);
-  }
-  if (p < count) {
-    const float4 a = sp[first + p];
-    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), first + p);
+    visit(da, first + p0, v0);
+    visit(db, first + p1, v1);
   }
 }
 
 // the exhaustive scan of a query without near neighbours: this lane's share of all points, four loads in flight;
-// visit(d, position, point)
+// visit(d, position, point, valid), uniform across the team like scan_run
 template <class F>
 __device__ __forceinline__ void scan_all(const float4* __restrict__ sp, int count, int sub, float qx, float qy, float qz, F&& visit) {
-  int p = sub;
-  for (; p + 3 * kTeam < count; p += 4 * kTeam) {
-    const float4 a = sp[p], b = sp[p + kTeam], c = sp[p + 2 * kTeam], d = sp[p + 3 * kTeam];
+  for (int base = 0; base < count; base += 4 * kTeam) {
+    const int p0 = base + sub, p1 = p0 + kTeam, p2 = p1 + kTeam, p3 = p2 + kTeam;
+    const bool v0 = p0 < count, v1 = p1 < count, v2 = p2 < count, v3 = p3 < count;
+    const float4 a = sp[min(p0, count - 1)], b = sp[min(p1, count - 1)], c = sp[min(p2, count - 1)], d = sp[min(p3, count - 1)];
     const float da = dist2_f32(qx, qy, qz, a.x, a.y, a.z), db = dist2_f32(qx, qy, qz, b.x, b.y, b.z);
     const float dc = dist2_f32(qx, qy, qz, c.x, c.y, c.z), dd = dist2_f32(qx, qy, qz, d.x, d.y, d.z);
-    visit(da, static_cast<unsigned>(p), a);
-    visit(db, static_cast<unsigned>(p + kTeam), b);
-    visit(dc, static_cast<unsigned>(p + 2 * kTeam), c);
-    visit(dd, static_cast<unsigned>(p + 3 * kTeam), d);
-  }
-  for (; p < count; p += kTeam) {
-    const float4 a = sp[p];
-    visit(dist2_f32(qx, qy, qz, a.x, a.y, a.z), static_cast<unsigned>(p), a);
+    visit(da, static_cast<unsigned>(p0), a, v0);
+    visit(db, static_cast<unsigned>(p1), b, v1);
+    visit(dc, static_cast<unsigned>(p2), c, v2);
+    visit(dd, static_cast<unsigned>(p3), d, v3);
   }
 }
 
