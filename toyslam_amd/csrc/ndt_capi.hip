@@ -257,7 +257,8 @@ struct ndt_context {
   // Two command mailboxes, used by alternate server instances: a server told to finish (transform +
   // exit) is not waited for, and the next instance's first command must not overwrite the line the
   // old one may still be reading.
-  void* server_host_mbs = nullptr;  // pinned, 2 mailboxes
+  void* server_host_mbs = nullptr;  // 2 command mailboxes the host writes: host-visible device memory (large BAR) or pinned host memory
+  bool server_mbs_on_device = false;
   void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
   int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
@@ -287,7 +288,7 @@ struct ndt_context {
     if (host_result) (void)hipHostFree(host_result);
     if (host_pub) (void)hipHostFree(host_pub);
     if (bbox_rows) (void)hipHostFree(bbox_rows);
-    if (server_host_mbs) (void)hipHostFree(server_host_mbs);
+    if (server_host_mbs) (void)(server_mbs_on_device ? hipFree(server_host_mbs) : hipHostFree(server_host_mbs));
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -906,8 +907,23 @@ ndt_status server_start(ndt_context* h) {
   const int n = h->source->k2_n();
   const size_t mb_bytes = ndt::server_mailbox_bytes();
   if (!h->server_host_mbs) {
-    HIP_TRY(hipHostMalloc(&h->server_host_mbs, 2 * mb_bytes, hipHostMallocDefault));
-    std::memset(h->server_host_mbs, 0, 2 * mb_bytes);
+    // Where the host posts its commands.  On a large-BAR system: fine-grained DEVICE memory, written by the CPU
+    // through the BAR (posted PCIe writes) and polled by the relay wave in its own memory -- a poll of pinned
+    // host memory is a PCIe read round trip per look (tools/probes/bar_probe.cpp: 2.6 -> 2.0 us per host-GPU-host
+    // ping-pong).  Otherwise, or with NDT_MAILBOX=host: pinned host memory.
+    const char* where = std::getenv("NDT_MAILBOX");
+    hipDeviceProp_t prop;
+    const bool large_bar = hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.isLargeBar != 0;
+    if (large_bar && !(where && std::strcmp(where, "host") == 0) &&
+        hipExtMallocWithFlags(&h->server_host_mbs, 2 * mb_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      h->server_mbs_on_device = true;
+      HIP_TRY(hipMemset(h->server_host_mbs, 0, 2 * mb_bytes));
+    } else {
+      h->server_host_mbs = nullptr;
+      (void)hipGetLastError();
+      HIP_TRY(hipHostMalloc(&h->server_host_mbs, 2 * mb_bytes, hipHostMallocDefault));
+      std::memset(h->server_host_mbs, 0, 2 * mb_bytes);
+    }
   }
   if (!h->server_dev_mb.p) {
     HIP_TRY(h->server_dev_mb.reserve(2 * mb_bytes));
