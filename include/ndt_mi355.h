@@ -245,6 +245,10 @@ ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, doubl
 /* Device self-test of the wave64 fold reduction used by every kernel epilogue: n_blocks blocks
  * of known per-thread values; block_sums receives n_blocks x NDT_EVAL_STRIDE doubles (slots 0..28). */
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums);
+/* liveness of the persistent evaluation server: one evaluation, a host stall of stall_ms (the server's patience is
+ * 20 ms), one more request (*served_after_stall = 0 when the server had left, as it must for stall_ms > 20), then the
+ * same evaluation through the launch path and through a fresh server; scores[3] = the three results. */
+ndt_status ndt_selftest_server_idle(ndt_handle h, const double* p, int stall_ms, int* served_after_stall, double* scores);
 
 /* Diagnostic (development aid): one DIRECT7 evaluation at pose p by the s_memtime-stamped build of
  * the derivative kernel.  stamps receives n_waves x 8 u64 (shader cycles at: entry, point

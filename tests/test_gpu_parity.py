@@ -922,3 +922,21 @@ def test_grid_far_from_the_origin_is_still_the_reference_grid(mods):
     assert b["n"].max() > 64  # voxels beyond the register / insertion sort paths of the finalize kernel
     scale = np.abs(b["icov"][ok]).max()
     assert np.abs(a["icov"][ok] - b["icov"][ok]).max() <= 1e-9 * scale
+
+
+def test_evaluation_server_gives_up_when_the_host_goes_quiet(mods, pair):
+    """Liveness of the persistent kernel: with no command for longer than its patience (20 ms) the server tells the host and
+    drains on its own; the next request comes back unserved (no hang), the launch path answers, and a fresh server serves
+    again -- all three with the same bits.  A short pause does not disturb it."""
+    ndt, po, clouds = mods
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    g.setInputSource(s)
+    p = np.array([0.1, -0.05, 0.02, 0.003, -0.002, 0.01])
+    served, scores = g.selftest_server_idle(p, 150)
+    assert not served and scores[0] == scores[1] == scores[2] and scores[0] != 0
+    served, scores = g.selftest_server_idle(p, 2)
+    assert served and scores[0] == scores[1] == scores[2]
+    g.align()  # and the handle is fine afterwards
+    assert g.hasConverged()

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ndt_diag_stamps": (C.c_int, [vp, dp, C.POINTER(C.c_ulonglong), szp]),
     "ndt_diag_server_roundtrip": (C.c_int, [vp, dp, C.c_int, dp]),
     "ndt_selftest_reduce": (C.c_int, [vp, C.c_int, dp]),
+    "ndt_selftest_server_idle": (C.c_int, [vp, dp, C.c_int, ip, dp]),
     "ndt_profile_enable": (C.c_int, [vp, C.c_int]),
     "ndt_set_evaluation_path": (C.c_int, [vp, C.c_int]),
     "ndt_profile_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_longlong), dp, C.c_int]),

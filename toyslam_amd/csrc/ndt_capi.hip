@@ -951,7 +951,8 @@ ndt_status server_start(ndt_context* h) {
   HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
                                   h->partials.p, h->server_counter.p, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
-                                  h->server_want_dbg ? h->server_dbg.p : nullptr));
+                                  h->server_want_dbg ? h->server_dbg.p : nullptr,
+                                  (h->server_mbs_on_device && !(std::getenv("NDT_SERVER_DIRECT") && std::atoi(std::getenv("NDT_SERVER_DIRECT")) == 0)) ? 1 : 0));
   undo.armed = false;
   return NDT_OK;
 }
@@ -2060,6 +2061,52 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
                  us_of(d[1]), us_of(got_min), us_of(got_max), us_of(tk_min), us_of(tk_max), us_of(d[2]), us_of(d[3]), nblk);
   }
   return NDT_OK;
+}
+
+// Liveness self-test of the evaluation server: serve one evaluation, let the host go quiet for stall_ms (the
+// server's patience is 20 ms: it must tell the host and leave on its own), ask again -- the request must come back
+// unserved, not hang -- then evaluate through the launch path and through a FRESH server.  scores[3]: before the
+// stall (server), after it (launch path), fresh server; *served_after_stall: whether the stalled server still answered.
+ndt_status ndt_selftest_server_idle(ndt_handle h, const double* p, int stall_ms, int* served_after_stall, double* scores) {
+  if (!h || !p || !served_after_stall || !scores) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  if (h->source->k2_n() == 0 || h->grid->empty) return fail(NDT_ERR_INVALID, "empty inputs");
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  ndt::EvalRequest rq;
+  rq.kind = ndt::EVAL_WITH_HESSIAN;
+  std::memcpy(rq.p, p, sizeof(rq.p));
+  ndt::pose_to_matrix(p, rq.T);
+  ndt::EvalResult r;
+  bool served = false;
+  s = server_start(h);
+  if (s) return s;
+  s = server_evaluate(h, rq, gs, r, nullptr, &served);
+  if (s || !served) {
+    (void)server_stop(h);
+    return s ? s : fail(NDT_ERR_HIP, "server did not serve its first evaluation");
+  }
+  scores[0] = r.score;
+  std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+  s = server_evaluate(h, rq, gs, r, nullptr, &served);
+  if (s) return s;
+  *served_after_stall = served ? 1 : 0;
+  if (served) {
+    s = server_stop(h);
+    if (s) return s;
+  }
+  s = evaluate_single(h, rq, r, nullptr);
+  if (s) return s;
+  scores[1] = r.score;
+  s = server_start(h);
+  if (s) return s;
+  s = server_evaluate(h, rq, gs, r, nullptr, &served);
+  if (s || !served) {
+    (void)server_stop(h);
+    return s ? s : fail(NDT_ERR_HIP, "fresh server did not serve");
+  }
+  scores[2] = r.score;
+  return server_stop(h);
 }
 
 ndt_status ndt_selftest_reduce(ndt_handle h, int n_blocks, double* block_sums) {

@@ -284,6 +284,13 @@ class NormalDistributionsTransform:
         check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
         return out
 
+    def selftest_server_idle(self, p, stall_ms):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        served = C.c_int(-1)
+        scores = np.zeros(3)
+        check(self._L.ndt_selftest_server_idle(self._h, _d(p), int(stall_ms), C.byref(served), _d(scores)))
+        return bool(served.value), scores
+
     def setEvaluationPath(self, persistent):
         """True (default): one persistent kernel per registration; False: one launch per evaluation."""
         check(self._L.ndt_set_evaluation_path(self._h, int(bool(persistent))))
