@@ -485,12 +485,15 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-template <int NNB, bool WANT_H, class P, bool STAMP = false, bool FACTORED = true>
+// PRELOADED: the caller already holds src[first] (the evaluation server keeps each lane's first point in registers
+// across rounds: the scan does not change between the evaluations of a registration, and the load would otherwise
+// head every round's dependent chain)
+template <int NNB, bool WANT_H, class P, bool STAMP = false, bool FACTORED = true, bool PRELOADED = false>
 __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
                                                  int first, int stride, double (&acc)[kNumAcc],
-                                                 unsigned long long* st = nullptr) {
+                                                 unsigned long long* st = nullptr, float4 first_pt = float4{0.f, 0.f, 0.f, 0.f}) {
   for (int i = first; i < n; i += stride) {
-    const float4 pt = src[i];
+    const float4 pt = (PRELOADED && i == first) ? first_pt : src[i];
     if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[1] = stamp(); }
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);

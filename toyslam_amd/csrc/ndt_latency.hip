@@ -165,12 +165,23 @@ __device__ __constant__ signed char kAngleTerms[69][8] = {
 };
 
 // one coefficient of the f64 vectors j_ang_* (e < 24) / h_ang_* (e >= 24) from f = {1,sx,cx,sy,cy,sz,cz}
-__device__ __forceinline__ double angle_coefficient_f64(int e, const double* f) {
+__device__ __forceinline__ double angle_coefficient_terms(const signed char* t, const double* f) {
 #pragma clang fp contract(off)
-  const signed char* t = kAngleTerms[e];
   const double t1 = ((static_cast<double>(t[0]) * f[t[1]]) * f[t[2]]) * f[t[3]];
   const double t2 = ((static_cast<double>(t[4]) * f[t[5]]) * f[t[6]]) * f[t[7]];
   return t1 + t2;
+}
+__device__ __forceinline__ double angle_coefficient_f64(int e, const double* f) { return angle_coefficient_terms(kAngleTerms[e], f); }
+// the same from a thread's own copy of its table row (the server keeps it in two registers across rounds: the row is
+// fixed per thread, and its load from constant memory headed every round's table phase)
+__device__ __forceinline__ double angle_coefficient_f64_held(unsigned lo, unsigned hi, const double* f) {
+  signed char t[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    t[k] = static_cast<signed char>((lo >> (8 * k)) & 0xff);
+    t[4 + k] = static_cast<signed char>((hi >> (8 * k)) & 0xff);
+  }
+  return angle_coefficient_terms(t, f);
 }
 // the f32 matrices j_ang / h_ang hold the same values rounded, except h_ang row d1, z: +sy (:383)
 // where the f64 vector has -sy (:361)
@@ -197,6 +208,18 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   __shared__ int s_kind;
   __shared__ int s_last;
   unsigned long long expect = first_seq;
+  // this lane's first point of every round (see derivatives_body PRELOADED)
+  const int my_first = xcd_chunk(blockIdx.x, gridDim.x) * kServerTPB + static_cast<int>(threadIdx.x);
+  float4 my_pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (my_first < n) my_pt = src[my_first];
+  unsigned terms_lo = 0, terms_hi = 0;  // this thread's row of kAngleTerms (threads 0..68 build the angle tables)
+  if (threadIdx.x < 69) {
+    const signed char* t = kAngleTerms[threadIdx.x];
+    for (int k = 0; k < 4; k++) {
+      terms_lo |= static_cast<unsigned>(static_cast<unsigned char>(t[k])) << (8 * k);
+      terms_hi |= static_cast<unsigned>(static_cast<unsigned char>(t[4 + k])) << (8 * k);
+    }
+  }
   if (threadIdx.x == 0) {
     sP.d1 = gauss_d1;
     sP.d2 = static_cast<float>(gauss_d2);
@@ -291,12 +314,12 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
     }
     if (kind < 0 || kind > 3) return;  // EXIT or time-out: the whole block leaves together (3 = no-op round)
     if (tid < 69) {
+      const double c64 = angle_coefficient_f64_held(terms_lo, terms_hi, s_f);
       if (kind == 2) {  // f64 vectors of computeHessian (:329-361, -sy in row d1)
-        const double c = angle_coefficient_f64(tid, s_f);
-        if (tid < 24) sP64.jd[tid / 3][tid % 3] = c;
-        else sP64.hd[(tid - 24) / 3][(tid - 24) % 3] = c;
-      } else {
-        const float c = angle_coefficient(tid, s_f);
+        if (tid < 24) sP64.jd[tid / 3][tid % 3] = c64;
+        else sP64.hd[(tid - 24) / 3][(tid - 24) % 3] = c64;
+      } else {  // the f32 matrices hold the same values rounded, except h_ang row d1, z: +sy (:383)
+        const float c = static_cast<float>((tid == 24 + 6 * 3 + 2) ? s_f[3] : c64);
         if (tid < 24) sP.j[tid / 3][tid % 3] = c;
         else sP.h[(tid - 24) / 3][(tid - 24) % 3] = c;
       }
@@ -322,8 +345,8 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       if (kind == 0) derivatives_body_kd<true>(src, limit, gv, sP, first, stride, acc);
       else if (kind == 1) derivatives_body_kd<false>(src, limit, gv, sP, first, stride, acc);
     } else {
-      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(src, limit, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(src, limit, gv, sP, first, stride, acc);
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true, true>(src, limit, gv, sP, first, stride, acc, nullptr, my_pt);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true, true>(src, limit, gv, sP, first, stride, acc, nullptr, my_pt);
     }
     if (fine && tid == 0) fine[1] = __builtin_amdgcn_s_memrealtime();
     const double tot = wave_fold<kNumAcc>(acc);
