@@ -248,6 +248,7 @@ struct ndt_context {
   size_t out_n = 0;
   // persistent evaluation server (single-scan align)
   bool server_running = false;
+  int server_blocks = 0;  // grid of the running server: min(16, blocks) part rows come back per evaluation
   // N2: accumulated global map (dense float4, HBM resident)
   DevBuf<float4> map_pts;
   size_t map_n = 0;
@@ -354,8 +355,8 @@ ndt_status ensure_host_rows(ndt_context* h, size_t rows) {
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_result), rows * ndt::kEvalStride * sizeof(double),
                         hipHostMallocDefault));
   if (!h->host_pub) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_pub), ndt::kPublishSlots * sizeof(double), hipHostMallocDefault));
-    std::memset(h->host_pub, 0, ndt::kPublishSlots * sizeof(double));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->host_pub), ndt::kServerParts * ndt::kPublishSlots * sizeof(double), hipHostMallocDefault));
+    std::memset(h->host_pub, 0, ndt::kServerParts * ndt::kPublishSlots * sizeof(double));
   }
   h->host_result_rows = rows;
   return NDT_OK;
@@ -933,10 +934,11 @@ ndt_status server_start(ndt_context* h) {
   h->server_host_mb = static_cast<unsigned char*>(h->server_host_mbs) + h->server_flip * mb_bytes;
   ndt::server_reset_mailbox(h->server_host_mb);
   void* dev_mb = h->server_dev_mb.p + h->server_flip * mb_bytes;
-  HIP_TRY(h->server_counter.reserve(32 * 9));  // top counter + 8 shard counters, one per 128-B line
-  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * 9 * sizeof(unsigned), h->stream));
+  HIP_TRY(h->server_counter.reserve(32 * (1 + ndt::kServerParts)));  // one shard counter per 128-B line
+  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * (1 + ndt::kServerParts) * sizeof(unsigned), h->stream));
   // one 512-thread block per CU at most: every block must be resident for the round to complete
   int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + 511) / 512));
+  h->server_blocks = nblk;
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
   const int n_out = static_cast<int>(h->source->n);
@@ -980,14 +982,23 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
   ndt::server_post(h->server_host_mb, seq, static_cast<int>(rq.kind), T12, cs);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  while (!pub_ready(h->host_pub, seq)) {
+  // one tagged row per part of the fixed-order sum comes back (ndt_latency.hip, the server's epilogue)
+  const int n_parts = std::min(ndt::kServerParts, h->server_blocks);
+  unsigned arrived = 0;  // bit p: part p complete
+  const unsigned all = (n_parts >= 32) ? ~0u : ((1u << n_parts) - 1u);
+  auto parts_ready = [&] {
+    for (int p = 0; p < n_parts; p++)
+      if (!(arrived & (1u << p)) && pub_ready(h->host_pub + static_cast<size_t>(p) * ndt::kPublishSlots, seq)) arrived |= 1u << p;
+    return arrived == all;
+  };
+  while (!parts_ready()) {
     __builtin_ia32_pause();
     if ((++spins & 0x3FFF) == 0) {
       if (ndt::server_dead_word(h->server_host_mb) != 0 || hipStreamQuery(h->stream) != hipErrorNotReady) {
         // the server left (idle time-out or error): drain and let the caller relaunch
         server_mark(h, false);
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (pub_ready(h->host_pub, seq)) break;
+        if (parts_ready()) break;
         ndt::server_reset_mailbox(h->server_host_mb);
         return NDT_OK;
       }
@@ -995,7 +1006,14 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
         return fail(NDT_ERR_HIP, "timed out waiting for the evaluation server");
     }
   }
-  pub_gather(h->host_pub, h->host_result);
+  {  // second stage of the fixed-order sum: t = ((0 + part 0) + part 1) + ... over all kServerParts (absent parts are 0.0)
+    double part[ndt::kEvalStride];
+    for (int k = 0; k < ndt::kEvalStride; k++) h->host_result[k] = 0.0;
+    for (int p = 0; p < ndt::kServerParts; p++) {
+      if (p < n_parts) pub_gather(h->host_pub + static_cast<size_t>(p) * ndt::kPublishSlots, part);
+      for (int k = 0; k < ndt::kEvalStride; k++) h->host_result[k] += (p < n_parts) ? part[k] : 0.0;
+    }
+  }
   unpack_row(h->host_result, rq.kind != ndt::EVAL_NO_HESSIAN, res, nn_total);
   *served = true;
   return NDT_OK;
@@ -2057,7 +2075,7 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
         std::fclose(f);
       }
     }
-    std::fprintf(stderr, "[server stamps, us after the relay saw the command] relayed %.2f | blocks have params %.2f..%.2f | tickets %.2f..%.2f | final sum starts %.2f | published %.2f  (%d blocks)\n",
+    std::fprintf(stderr, "[server stamps, us after the relay (direct mailbox: block 0) saw the command] relayed %.2f | blocks have params %.2f..%.2f | tickets %.2f..%.2f | final sum starts %.2f | published %.2f  (%d blocks)\n",
                  us_of(d[1]), us_of(got_min), us_of(got_max), us_of(tk_min), us_of(tk_max), us_of(d[2]), us_of(d[3]), nblk);
   }
   return NDT_OK;

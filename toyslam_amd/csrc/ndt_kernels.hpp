@@ -135,6 +135,8 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
                                     unsigned long long seq, hipStream_t stream);
 // Persistent evaluation server (one launch per align): see ndt_kernels.hip.
 constexpr int kPublishSlots = 64;  // tagged publication row: value k as words 2k, 2k+1 = (half << 32) | seq32
+constexpr int kServerParts = 16;   // the evaluation server publishes one row per PART of the fixed-order sum (rows b, b % 16 == part);
+                                   // the host adds the parts in order (= server block size / kEvalStride)
 constexpr int kServerCmdExit = 0x7fffffff;
 constexpr int kServerCmdTransformExit = 4;  // write the aligned cloud with the command's transform, then exit
 size_t server_mailbox_bytes();

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
 // drains, whatever the host does.  gridDim.x must not exceed the number of co-resident blocks.
 // ---------------------------------------------------------------------------
 constexpr int kServerTPB = 512;
+static_assert(kServerTPB / kEvalStride == kServerParts, "the host adds kServerParts part sums");
 constexpr int kCmdExit = 0x7fffffff;
 constexpr int kCmdTransformExit = 4;  // transform the source by T into the output cloud, then exit
 
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
                                                             int direct) {
   constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
   __shared__ double lds[kWaves * 32];
-  __shared__ double lds2[kParts * kEvalStride];
   __shared__ EvalParams sP;
   __shared__ Hess64Params sP64;
   __shared__ double s_f[8];  // 1, sx, cx, sy, cy, sz, cz
@@ -298,7 +298,11 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       }
       if (lane == 0) {
         s_kind = kind;
-        if (dbg && kind != kCmdExit) dbg[8 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its command
+        if (dbg && kind != kCmdExit) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          dbg[8 + 2 * blockIdx.x] = now;  // block has its command
+          if (direct && blockIdx.x == 0 && kind != kCmdTransformExit) dbg[0] = dbg[1] = now;  // direct mailbox: time zero of the diagnostics
+        }
       }
     }
     __syncthreads();
@@ -368,39 +372,28 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (fine && lane == 0) fine[4] = __builtin_amdgcn_s_memrealtime();
       if (lane == 0) {
-        // Two-level fan-in: 8 shard counters (blocks b and b+8 usually share an XCD; only speed
-        // depends on that) and one top counter.  ~200 returning atomics on ONE word serialise at
-        // ~13 ns each (measured 2.5-3 us of arrival skew); sharded, the longest chain is ~25+8.
+        // Fan-in over kParts = 16 shard counters: shard p = the blocks b with b % 16 == p, exactly the rows that part p
+        // of the fixed-order sum (sum_rows_fixed) adds.  The last arriver of a shard adds its shard's rows and publishes
+        // that PART sum to the host, which adds the 16 parts in order -- the same additions in the same order as one
+        // last block doing both stages, without the top-level ticket and the second stage on the device
+        // (~200 returning atomics on ONE word would serialise at ~13 ns each; a shard sees 12-13).
         // Counters live 128 B apart and are never reset inside a launch.
         const unsigned round = static_cast<unsigned>(expect - first_seq);
-        const unsigned shard = blockIdx.x & 7u;
-        const unsigned in_shard = (gridDim.x + 7u - shard) / 8u;  // blocks with this residue
+        const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
+        const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
         const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = 0;
-        if (t1 == (round + 1u) * in_shard - 1u) {
-          const unsigned n_shards = gridDim.x < 8u ? gridDim.x : 8u;
-          const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = (t2 == (round + 1u) * n_shards - 1u) ? 1 : 0;
-        }
-        s_last = last;
+        s_last = (t1 == (round + 1u) * in_shard - 1u) ? 1 : 0;
         if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
       }
     }
     __syncthreads();
     if (s_last) {
-      if (dbg && tid == 0)  // last arriver starts the final sum (written through: the last block changes XCD from round to round)
+      const int shard = static_cast<int>(blockIdx.x % static_cast<unsigned>(kParts));
+      if (dbg && tid == 0)  // a shard's last arriver starts its part sum (the latest writer is the one that matters)
         __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int k = tid % kEvalStride, part = tid / kEvalStride;
-      lds2[part * kEvalStride + k] = sum_rows_fixed<kParts>(partials, gridDim.x, tid);
+      if (tid < kEvalStride) lds[tid] = sum_rows_fixed<kParts>(partials, gridDim.x, shard * kEvalStride + tid);
       __syncthreads();
-      if (tid < kEvalStride) {
-        double t = 0.0;
-#pragma unroll
-        for (int p = 0; p < kParts; p++) t += lds2[p * kEvalStride + tid];
-        lds[tid] = t;
-      }
-      __syncthreads();
-      publish_row_tagged(out_row, lds, tid, expect);
+      publish_row_tagged(out_row + static_cast<size_t>(shard) * kPublishSlots, lds, tid, expect);
       if (dbg && tid == 0)  // published
         __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
