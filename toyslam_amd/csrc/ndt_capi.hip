@@ -678,10 +678,13 @@ ndt_status build_grid(ndt_context* h) {
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
   HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, sizeof(unsigned), st));
   ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (!h->index_only)
-  HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
-                               static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
-                               g->lut.p, g->counts.p + 3, nodump, st, g->counts.p));
+  DevBuf<float4> big_pts;  // scratch of the crowded-leaf path (k_presort_large)
+  if (!h->index_only) {
+    HIP_TRY(big_pts.reserve(n));
+    HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
+                                 static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
+                                 g->lut.p, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
+  }
   // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
   // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
   g->counts_known = false;
@@ -1479,7 +1482,9 @@ static ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p));
+  DevBuf<float4> big_pts;  // scratch of the crowded-voxel path (k_presort_large)
+  HIP_TRY(big_pts.reserve(n));
+  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p, big_pts.p));
   unsigned tot[3];
   HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit

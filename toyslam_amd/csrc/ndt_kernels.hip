@@ -345,6 +345,54 @@ __device__ __forceinline__ void sort_segment(int* seg, int cnt) {
   }
 }
 
+// Leaves with more points than the register path of k_finalize takes (real scans: a 1 m voxel of a 0.1 m-filtered
+// cloud holds hundreds): one WAVE per leaf restores ascending point order -- rank sort in LDS, every lane places its
+// elements by counting the smaller ones -- and gathers the points into `big_pts` in that order, so that k_finalize's
+// strictly sequential f64 sums read contiguous memory with many loads in flight instead of sorting the segment in
+// global memory with one thread and chasing index -> point per addition (measured on the reference pair: 583 us per
+// target build, almost all of it in that one-thread path).
+constexpr int kPresortMin = 16;    // <= this many points: k_finalize's register path
+constexpr int kPresortLds = 4096;  // segments up to here are sorted in LDS; longer ones by lane 0 (heap sort) as before
+__global__ __launch_bounds__(kWave) void k_presort_large(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
+                                                        const int* __restrict__ leaf_count, int n_leaves_host,
+                                                        const unsigned* __restrict__ d_totals, int* __restrict__ sorted_idx,
+                                                        float4* __restrict__ big_pts, int chunk) {
+  __shared__ int s_idx[kPresortLds];
+  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;
+  const int lane = threadIdx.x;
+  // `chunk` (1..64, the launcher picks it so that the grid stays within 8192 waves) leaves are looked at per step (one load of their counts); the crowded ones among them are taken one
+  // after the other by the whole wave -- few leaves: about one crowded leaf per wave; many leaves without crowded
+  // ones: a short pass over leaf_count
+  for (int base = blockIdx.x * chunk; base < n_leaves; base += gridDim.x * chunk) {
+   const int my_cnt = (lane < chunk && base + lane < n_leaves) ? leaf_count[base + lane] : 0;
+   unsigned long long crowded = __ballot(my_cnt > kPresortMin);
+   while (crowded) {
+    const int pick = __builtin_ctzll(crowded);
+    crowded &= crowded - 1;
+    const int leaf = base + pick;
+    const int cnt = __shfl(my_cnt, pick, kWave);
+    const unsigned start = leaf_start[leaf];
+    int* seg = sorted_idx + start;
+    if (cnt <= kPresortLds) {
+      for (int i = lane; i < cnt; i += kWave) s_idx[i] = seg[i];
+      __syncthreads();  // (one wave per block)
+      for (int i = lane; i < cnt; i += kWave) {
+        const int v = s_idx[i];
+        int rank = 0;
+        for (int j = 0; j < cnt; j++) rank += (s_idx[j] < v) ? 1 : 0;  // point indices are unique
+        seg[rank] = v;
+        big_pts[start + rank] = pts[v];
+      }
+      __syncthreads();  // s_idx is reused by the next leaf
+    } else {
+      if (lane == 0) sort_segment(seg, cnt);
+      __syncthreads();
+      for (int i = lane; i < cnt; i += kWave) big_pts[start + i] = pts[__hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    }
+   }
+  }
+}
+
 // Source ordering: after the counting sort by lattice cell, sort each cell's indices (stable,
 // hence deterministic) and gather the points, so that consecutive lanes of K2 touch the same or
 // adjacent target voxels (coalesced LUT probes and record gathers).
@@ -356,6 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict
   if (o >= n_leaves) return;
   const unsigned start = leaf_start[o];
   const int cnt = leaf_count[o];
+  if (cnt > kPresortMin) return;  // crowded cells: k_presort_large has sorted and gathered them straight into `out`
   int* seg = sorted_idx + start;
   sort_segment(seg, cnt);
   for (int i = 0; i < cnt; i++) out[start + i] = pts[seg[i]];
@@ -370,16 +419,36 @@ __global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_voxel_centroids(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
                                                             const int* __restrict__ leaf_count, int n_leaves_host, const unsigned* __restrict__ d_totals,
-                                                            int* __restrict__ sorted_idx, float4* __restrict__ out) {
+                                                            int* __restrict__ sorted_idx, float4* __restrict__ out,
+                                                            const float4* __restrict__ big_pts) {
   const int o = blockIdx.x * kBlock + threadIdx.x;
   const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
   if (o >= n_leaves) return;
   const unsigned start = leaf_start[o];
   const int cnt = leaf_count[o];
   int* seg = sorted_idx + start;
-  sort_segment(seg, cnt);
   float sx = 0.f, sy = 0.f, sz = 0.f;
   int i = 0;
+  if (big_pts && cnt > kPresortMin) {  // crowded voxel: sorted and laid out in order by k_presort_large
+    const float4* bp = big_pts + start;
+    for (; i + 8 <= cnt; i += 8) {
+      const float4 p0 = bp[i], p1 = bp[i + 1], p2 = bp[i + 2], p3 = bp[i + 3], p4 = bp[i + 4], p5 = bp[i + 5], p6 = bp[i + 6], p7 = bp[i + 7];
+      sx += p0.x; sy += p0.y; sz += p0.z;
+      sx += p1.x; sy += p1.y; sz += p1.z;
+      sx += p2.x; sy += p2.y; sz += p2.z;
+      sx += p3.x; sy += p3.y; sz += p3.z;
+      sx += p4.x; sy += p4.y; sz += p4.z;
+      sx += p5.x; sy += p5.y; sz += p5.z;
+      sx += p6.x; sy += p6.y; sz += p6.z;
+      sx += p7.x; sy += p7.y; sz += p7.z;
+    }
+    for (; i < cnt; i++) {
+      const float4 p = bp[i];
+      sx += p.x; sy += p.y; sz += p.z;
+    }
+  } else {
+    sort_segment(seg, cnt);
+  }
   for (; i + 4 <= cnt; i += 4) {
     const float4 p0 = pts[seg[i]], p1 = pts[seg[i + 1]], p2 = pts[seg[i + 2]], p3 = pts[seg[i + 3]];
     sx += p0.x; sy += p0.y; sz += p0.z;
@@ -401,7 +470,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
                                                      const int* __restrict__ leaf_rec, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
                                                      VoxelRec* __restrict__ recs, int* __restrict__ lut,
-                                                     unsigned* __restrict__ n_valid, FinalizeDump dump) {
+                                                     unsigned* __restrict__ n_valid, FinalizeDump dump,
+                                                     const float4* __restrict__ big_pts) {
   // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
   // covariance formula (_impl.hpp:329-330) cancels catastrophically when the coordinates are large
   // against the voxel size (sum of squares ~ n x^2 against a spread of millimetres), so a single fused
@@ -455,6 +525,15 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
         add_point(pp[i]);
       }
     }
+  } else if (big_pts) {
+    // k_presort_large has sorted the segment and laid its points out in order: eight contiguous loads in flight
+    const float4* bp = big_pts + start;
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) {
+      const float4 p0 = bp[i], p1 = bp[i + 1], p2 = bp[i + 2], p3 = bp[i + 3], p4 = bp[i + 4], p5 = bp[i + 5], p6 = bp[i + 6], p7 = bp[i + 7];
+      add_point(p0); add_point(p1); add_point(p2); add_point(p3); add_point(p4); add_point(p5); add_point(p6); add_point(p7);
+    }
+    for (; i < cnt; i++) add_point(bp[i]);
   } else {
     sort_segment(seg, cnt);
     int i = 0;
@@ -855,6 +934,10 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
   block_reduce_store<1>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
 }
 
+// k_presort_large: leaves per wave-step and grid (one leaf per wave while that stays within 8192 waves)
+inline int presort_chunk(int n_leaves) { return max(1, min(64, (n_leaves + 8191) / 8192)); }
+inline int presort_grid(int n_leaves) { return max(1, min(8192, (n_leaves + presort_chunk(n_leaves) - 1) / presort_chunk(n_leaves))); }
+
 inline int grid_for(size_t n, int max_blocks) {
   size_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -942,12 +1025,15 @@ hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
                            int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
-                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals) {
+                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
   // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
   if (n_leaves == 0) return hipSuccess;
+  if (d_big_pts)  // leaves with many points: sorted and gathered by one wave each, ahead of the per-leaf pass
+    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, d_leaf_start, d_leaf_count, n_leaves,
+                       d_totals, d_sorted_idx, d_big_pts, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
                      d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
-                     d_n_valid, dump);
+                     d_n_valid, dump, d_big_pts);
   return hipGetLastError();
 }
 
@@ -959,6 +1045,9 @@ hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream)
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
   if (n_leaves == 0) return hipSuccess;
+  // crowded cells first, one wave each (sorted and gathered straight into `out`); k_sort_gather takes the rest
+  hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
+                     sorted_idx, out, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_sort_gather, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
                      leaf_count, n_leaves, d_totals, sorted_idx, out);
   return hipGetLastError();
@@ -971,10 +1060,13 @@ hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& 
 }
 
 hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
+                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
   if (n_leaves == 0) return hipSuccess;
+  if (d_big_pts)
+    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
+                       sorted_idx, d_big_pts, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
-                     leaf_count, n_leaves, d_totals, sorted_idx, out);
+                     leaf_count, n_leaves, d_totals, sorted_idx, out, d_big_pts);
   return hipGetLastError();
 }
 

@@ -118,7 +118,8 @@ struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
                            int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
-                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals = nullptr);
+                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals = nullptr,
+                           float4* d_big_pts = nullptr /* n points of scratch: enables the wave pre-sort of crowded leaves */);
 
 // K2: derivatives.  search: NDT_DIRECT26/7/1.  Single scan: descs == nullptr, params by value,
 // partials [n_blocks][kEvalStride].  Batch: grid.y walks active[0..n_active) -- the scans that want
@@ -172,7 +173,8 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
                              int search, float r2, int n_blocks, double* partials, hipStream_t stream);
 
 hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals = nullptr);
+                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals = nullptr,
+                                  float4* d_big_pts = nullptr /* n points of scratch for crowded voxels */);
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals = nullptr);
 hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,
