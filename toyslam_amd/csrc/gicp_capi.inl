@@ -48,7 +48,9 @@ struct gicp_context {
 
 namespace {
 
-constexpr double kGicpPointsPerCell = 6.0;           // what the index leaf size aims for
+// what the index leaf size aims for (points per occupied cell; NDT_GICP_PPC overrides it for tuning runs): with the
+// margin bound most queries finish inside their own cell, so fuller cells cost little and far queries need fewer shells
+static const double kGicpPointsPerCell = std::getenv("NDT_GICP_PPC") ? std::atof(std::getenv("NDT_GICP_PPC")) : 12.0;
 constexpr long long kGicpMaxCells = 1ll << 26;       // dense cell table budget (256 MB of int)
 
 // Builds the voxel index of a host cloud on `c`: finite check, upload, leaf size from the cloud's own

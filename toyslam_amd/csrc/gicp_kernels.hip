@@ -115,13 +115,14 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       }
     };
     int ci, cj, ck;
-    query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck);
+    float margin;
+    query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck, margin);
     bool done = false;
     for (int r = 0; r <= r_max && !done; r++) {
       team_shell(ix, ci, cj, ck, r, sub, q.x, q.y, q.z, offer);
       // Every unvisited point is at least r cells (less the index-rounding slack) away: once the k-th best lies
       // strictly inside that reach no unvisited point can enter the k nearest.
-      const float reach = static_cast<float>(r) * leaf - ix.slack;
+      const float reach = static_cast<float>(r) * leaf + margin - ix.slack;
       if ((cnt == k && reach > 0.0f && worst < reach * reach) || r >= r_lim) done = true;
     }
     if (!done) {
@@ -247,42 +248,58 @@ __global__ __launch_bounds__(kBlock) void k_correspond(const float4* __restrict_
   const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
   const int r_max = max_shells(ix, r_lim);
-  for (int i = blockIdx.x * kTeams + threadIdx.x / kTeam; i < n; i += gridDim.x * kTeams) {  // uniform within a team
-    const float4 p = output[i];
-    float qx, qy, qz;
-    matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
-    float best = INFINITY;  // this lane's share: distance and POSITION in the cell order (the index behind it is
-    int best_p = -1;        // looked up on ties and at the end of a shell only)
-    auto consider = [&](float d, unsigned pos, bool ok) {
-      if (!ok || d > best) return;
-      if (d < best || ix.sorted_idx[pos] < ix.sorted_idx[best_p]) {  // equal distance: the lower index
-        best = d;
-        best_p = static_cast<int>(pos);
-      }
-    };
-    int ci, cj, ck;
-    query_cell(ix.geom, qx, qy, qz, ci, cj, ck);
-    bool done = false;
+  // The loop is uniform across the WAVE (a team without a query idles): the fallback below is a wave-wide operation.
+  constexpr int kTeamsPerWave = kWave / kTeam;
+  const int wave_in_block = threadIdx.x / kWave, team_in_wave = (threadIdx.x & (kWave - 1)) / kTeam;
+  for (int base = (blockIdx.x * (kBlock / kWave) + wave_in_block) * kTeamsPerWave; base < n; base += gridDim.x * kTeams) {
+    const int i = base + team_in_wave;
+    const bool live = i < n;  // uniform within a team
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool done = !live;
     float tb = INFINITY;  // the team's best
     int tb_i = 0x7fffffff;
-    for (int r = 0; r <= r_max && !done; r++) {
-      team_shell(ix, ci, cj, ck, r, sub, qx, qy, qz, consider);
-      tb = best;
-      tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
-      team_min(tb, tb_i);
-      const float reach = static_cast<float>(r) * leaf - ix.slack;
-      if ((tb_i != 0x7fffffff && reach > 0.0f && tb < reach * reach) || r >= r_lim) done = true;
-      // nothing closer than the gate is left once the shells reach past it: no correspondence either way
-      if (reach > 0.0f && static_cast<double>(reach) * static_cast<double>(reach) >= dist_threshold &&
-          !(static_cast<double>(tb) < dist_threshold))
-        done = true;
+    if (live) {
+      const float4 p = output[i];
+      matvec_eigen(P.T, p.x, p.y, p.z, qx, qy, qz);
+      float best = INFINITY;  // this lane's share: distance and POSITION in the cell order (the index behind it is
+      int best_p = -1;        // looked up on ties and at the end of a shell only)
+      auto consider = [&](float d, unsigned pos, bool ok) {
+        if (!ok || d > best) return;
+        if (d < best || ix.sorted_idx[pos] < ix.sorted_idx[best_p]) {  // equal distance: the lower index
+          best = d;
+          best_p = static_cast<int>(pos);
+        }
+      };
+      int ci, cj, ck;
+      float margin;
+      query_cell(ix.geom, qx, qy, qz, ci, cj, ck, margin);
+      for (int r = 0; r <= r_max && !done; r++) {
+        team_shell(ix, ci, cj, ck, r, sub, qx, qy, qz, consider);
+        tb = best;
+        tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
+        team_min(tb, tb_i);
+        const float reach = static_cast<float>(r) * leaf + margin - ix.slack;
+        if ((tb_i != 0x7fffffff && reach > 0.0f && tb < reach * reach) || r >= r_lim) done = true;
+        // nothing closer than the gate is left once the shells reach past it: no correspondence either way
+        if (reach > 0.0f && static_cast<double>(reach) * static_cast<double>(reach) >= dist_threshold &&
+            !(static_cast<double>(tb) < dist_threshold))
+          done = true;
+      }
     }
-    if (!done) {  // (a point met twice changes nothing for a single nearest neighbour: the shells' best stays as the bound)
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, qx, qy, qz, [&](float d, unsigned pos, const float4&, bool ok) { consider(d, pos, ok); });
-      tb = best;
-      tb_i = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
-      team_min(tb, tb_i);
+    // sparse neighbourhoods: the wave scans everything, one unfinished query at a time
+    unsigned long long open_teams = __ballot(!done && sub == 0);
+    while (open_teams) {
+      const int src_lane = __builtin_ctzll(open_teams);
+      open_teams &= open_teams - 1;
+      float wd;
+      int wi;
+      wave_nearest(ix, __shfl(qx, src_lane, kWave), __shfl(qy, src_lane, kWave), __shfl(qz, src_lane, kWave), wd, wi);
+      if (team_in_wave == src_lane / kTeam) {
+        tb = wd;
+        tb_i = wi;
+      }
     }
+    if (!live) continue;
     if (sub != 0) continue;
     int c_out = -1;
     if (tb_i != 0x7fffffff && static_cast<double>(tb) < dist_threshold) {  // :436

@@ -861,37 +861,53 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
   const float leaf = fminf(ix.geom.leaf[0], fminf(ix.geom.leaf[1], ix.geom.leaf[2]));
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
   const int r_max = max_shells(ix, r_lim);
-  for (int i = blockIdx.x * kTeams + threadIdx.x / kTeam; i < n; i += gridDim.x * kTeams) {  // uniform within a team
-    const float4 pt = src[i];
-    if (!finite3(pt.x, pt.y, pt.z)) continue;  // transformPointCloud leaves it non-finite; no neighbour to report
-    float tx, ty, tz;
-    xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
-    if (!finite3(tx, ty, tz)) continue;
-    float best = INFINITY;  // this lane's share of the candidates
-    auto consider = [&](float d, unsigned, bool ok) {
-      if (ok) best = fminf(best, d);
-    };
-    int ci, cj, ck;
-    query_cell(ix.geom, tx, ty, tz, ci, cj, ck);
-    bool done = false;
+  // The loop is uniform across the WAVE (a team without a query idles): the fallback below is a wave-wide operation.
+  constexpr int kTeamsPerWave = kWave / kTeam;
+  const int wave_in_block = threadIdx.x / kWave, team_in_wave = (threadIdx.x & (kWave - 1)) / kTeam;
+  for (int base = (blockIdx.x * (kBlock / kWave) + wave_in_block) * kTeamsPerWave; base < n; base += gridDim.x * kTeams) {
+    const int i = base + team_in_wave;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    bool live = i < n;  // uniform within a team
+    if (live) {
+      const float4 pt = src[i];
+      live = finite3(pt.x, pt.y, pt.z);  // transformPointCloud leaves it non-finite; no neighbour to report
+      if (live) {
+        xform_point(P.T, pt.x, pt.y, pt.z, tx, ty, tz);
+        live = finite3(tx, ty, tz);
+      }
+    }
     float tb = INFINITY;
-    for (int r = 0; r <= r_max && !done; r++) {
-      team_shell(ix, ci, cj, ck, r, sub, tx, ty, tz, consider);
-      tb = best;
+    bool done = !live;
+    if (live) {
+      float best = INFINITY;  // this lane's share of the candidates
+      auto consider = [&](float d, unsigned, bool ok) {
+        if (ok) best = fminf(best, d);
+      };
+      int ci, cj, ck;
+      float margin;
+      query_cell(ix.geom, tx, ty, tz, ci, cj, ck, margin);
+      for (int r = 0; r <= r_max && !done; r++) {
+        team_shell(ix, ci, cj, ck, r, sub, tx, ty, tz, consider);
+        tb = best;
 #pragma unroll
-      for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
-      // every unvisited cell is at least r cells away (less the slack for the build-time / search-time
-      // index rounding, trap 2)
-      const float reach = static_cast<float>(r) * leaf - ix.slack;
-      if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
+        for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
+        // every unvisited cell is at least r cells away (less the slack for the build-time / search-time
+        // index rounding, trap 2)
+        const float reach = static_cast<float>(r) * leaf + margin - ix.slack;
+        if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
+      }
     }
-    if (!done) {  // sparse neighbourhood: the team scans everything
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, tx, ty, tz, [&](float d, unsigned pos, const float4&, bool ok) { consider(d, pos, ok); });
-      tb = best;
-#pragma unroll
-      for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
+    // sparse neighbourhoods: the wave scans everything, one unfinished query at a time
+    unsigned long long open_teams = __ballot(!done && sub == 0);
+    while (open_teams) {
+      const int src_lane = __builtin_ctzll(open_teams);
+      open_teams &= open_teams - 1;
+      float wd;
+      int wi;
+      wave_nearest(ix, __shfl(tx, src_lane, kWave), __shfl(ty, src_lane, kWave), __shfl(tz, src_lane, kWave), wd, wi);
+      if ((static_cast<int>(threadIdx.x) & (kWave - 1)) / kTeam == src_lane / kTeam) tb = wd;
     }
-    if (sub == 0 && static_cast<double>(tb) <= max_range) {  // the squared distance against max_range, as PCL does
+    if (live && sub == 0 && static_cast<double>(tb) <= max_range) {  // the squared distance against max_range, as PCL does
       acc[0] += static_cast<double>(tb);
       acc[1] += 1.0;
     }

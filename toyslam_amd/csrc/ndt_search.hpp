@@ -12,11 +12,24 @@ namespace {
 
 constexpr int kKnnMinRing = 3;  // shells every query may try (see max_shells) before one scan over all points
 
-__device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, float z, int& ci, int& cj, int& ck) {
-  search_ijk(g, x, y, z, ci, cj, ck);
-  ci = max(g.min_b[0], min(g.max_b[0], ci)) - g.min_b[0];  // nearest grid cell when outside the bounding box
-  cj = max(g.min_b[1], min(g.max_b[1], cj)) - g.min_b[1];
-  ck = max(g.min_b[2], min(g.max_b[2], ck)) - g.min_b[2];
+// The query's cell (clamped into the grid) and its MARGIN: how far the query is from the nearest face of that cell
+// (0 for a query outside the grid).  After shell r every unvisited point is at least r * leaf + margin away -- with
+// the margin a query in a crowded cell can stop after its own cell (r = 0) instead of always walking 27.
+__device__ __forceinline__ void query_cell(const GridGeom& g, float x, float y, float z, int& ci, int& cj, int& ck, float& margin) {
+  int ri, rj, rk;
+  search_ijk(g, x, y, z, ri, rj, rk);
+  ci = max(g.min_b[0], min(g.max_b[0], ri));
+  cj = max(g.min_b[1], min(g.max_b[1], rj));
+  ck = max(g.min_b[2], min(g.max_b[2], rk));
+  margin = 0.0f;
+  if (ci == ri && cj == rj && ck == rk) {
+    const float fx = x - static_cast<float>(ri) * g.leaf[0], fy = y - static_cast<float>(rj) * g.leaf[1], fz = z - static_cast<float>(rk) * g.leaf[2];
+    margin = fminf(fminf(fminf(fx, g.leaf[0] - fx), fminf(fy, g.leaf[1] - fy)), fminf(fz, g.leaf[2] - fz));
+    margin = fmaxf(margin, 0.0f);
+  }
+  ci -= g.min_b[0];  // nearest grid cell when outside the bounding box
+  cj -= g.min_b[1];
+  ck -= g.min_b[2];
 }
 
 // ---------------------------------------------------------------------------
@@ -130,6 +143,45 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
       }
     }
   }
+}
+
+// The scan over all points for a single nearest neighbour, by the WHOLE wave: the few isolated queries that need it
+// set a search kernel's time when one team of 8 lanes walks the cloud alone.  Every lane of the wave must call this
+// with the same query; returns the smallest (distance, point index) in all lanes.
+__device__ __forceinline__ void wave_nearest(const PointIndex& ix, float qx, float qy, float qz, float& out_d, int& out_idx) {
+  const int lane = threadIdx.x & (kWave - 1);
+  float best = INFINITY;
+  int best_p = -1;
+  auto take = [&](float d, int pos, bool ok) {
+    if (!ok || d > best) return;
+    if (d < best || ix.sorted_idx[pos] < ix.sorted_idx[best_p]) {
+      best = d;
+      best_p = pos;
+    }
+  };
+  const int count = ix.n_sorted;
+  for (int base = 0; base < count; base += 4 * kWave) {
+    const int p0 = base + lane, p1 = p0 + kWave, p2 = p1 + kWave, p3 = p2 + kWave;
+    const float4 a = ix.sorted_pts[min(p0, count - 1)], b = ix.sorted_pts[min(p1, count - 1)];
+    const float4 c = ix.sorted_pts[min(p2, count - 1)], d = ix.sorted_pts[min(p3, count - 1)];
+    take(dist2_f32(qx, qy, qz, a.x, a.y, a.z), p0, p0 < count);
+    take(dist2_f32(qx, qy, qz, b.x, b.y, b.z), p1, p1 < count);
+    take(dist2_f32(qx, qy, qz, c.x, c.y, c.z), p2, p2 < count);
+    take(dist2_f32(qx, qy, qz, d.x, d.y, d.z), p3, p3 < count);
+  }
+  float d = best;
+  int idx = best_p >= 0 ? ix.sorted_idx[best_p] : 0x7fffffff;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const float od = __shfl_xor(d, off, kWave);
+    const int oi = __shfl_xor(idx, off, kWave);
+    if (od < d || (od == d && oi < idx)) {
+      d = od;
+      idx = oi;
+    }
+  }
+  out_d = d;
+  out_idx = idx;
 }
 
 // Shells tried before a query falls back to one scan over all points.  Shell r costs the team up to
