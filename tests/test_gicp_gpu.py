@@ -286,3 +286,31 @@ def test_repeated_registrations_are_bit_identical(gmod, pair):
             g.setInputTarget(tgt)
         g.align()
         assert np.array_equal(g.getFinalTransformation(), want) and g.stats() == st, rep
+
+
+def test_gpu_matches_the_golden_registrations(gmod, pair):
+    """the committed golden vectors (tests/golden/gicp_golden.json, from the oracle) without running the oracle: the GPU gives
+    the same registrations -- transform within tolerance, same iteration and evaluation counts."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gicp_golden.json")))
+    t, s = pair
+    for name, a in gold["aligns"].items():
+        g = gmod.GeneralizedIterativeClosestPoint()
+        kw = a["params"]
+        if "k" in kw:
+            g.setCorrespondenceRandomness(kw["k"])
+        if "corr_dist_threshold" in kw:
+            g.setMaxCorrespondenceDistance(kw["corr_dist_threshold"])
+        if "max_iterations" in kw:
+            g.setMaximumIterations(kw["max_iterations"])
+        if "max_inner_iterations" in kw:
+            g.setMaximumOptimizerIterations(kw["max_inner_iterations"])
+        g.setInputTarget(t)
+        g.setInputSource(s)
+        g.align(None if a["guess"] is None else np.array(a["guess"], np.float32))
+        T, want = g.getFinalTransformation(), np.array(a["T"], np.float32)
+        assert rot_err(T, want) < ROT_TOL and trans_err(T, want) < TRANS_TOL, name
+        st = g.stats()
+        assert (g.hasConverged(), g.getFinalNumIteration(), st["n_f"], st["n_df"], st["n_fdf"], st["correspondences"]) == \
+               (a["converged"], a["iterations"], a["n_f"], a["n_df"], a["n_fdf"], a["correspondences"]), name

@@ -139,6 +139,37 @@ def test_align_without_enough_correspondences(scene):
     assert np.array_equal(r["T"], guess)
 
 
+def test_oracle_reproduces_its_golden_vectors(pair):
+    """tests/golden/gicp_golden.json (oracle/gen_golden_gicp.py): regression pins of the restatement on the committed pair --
+    neighbours, covariances, one correspondence step, the objective, four full registrations."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "gicp_golden.json")))
+    t, s = pair
+    cov = po.gicp_covariances(t, 20, 1e-3)
+    assert np.allclose(cov.sum(axis=0), gold["target_cov_sum"], rtol=0, atol=1e-7) and np.allclose(cov[0], gold["target_cov_first"], atol=1e-12)
+    idx, d2 = po.gicp_knn(t, t[:64], 20)
+    assert int(idx.astype(np.int64).sum()) == gold["knn_first64_idx_sum"] and float(d2.astype(np.float64).sum()) == gold["knn_first64_d2_sum"]
+    o = po.OracleGICP()
+    o.setInputTarget(t)
+    o.setInputSource(s)
+    o.prepare()
+    m, ci, maha = o.correspond(np.eye(4))
+    st = gold["step"]
+    assert m == st["correspondences"] and int(ci.astype(np.int64).sum()) == st["corr_idx_sum"]
+    assert float(maha.astype(np.float64).sum()) == pytest.approx(st["maha_sum"], rel=1e-9)
+    assert o.functor(0, st["x"])[0] == pytest.approx(st["f_operator"], rel=1e-12)
+    f2, g2 = o.functor(2, st["x"])
+    assert f2 == pytest.approx(st["f_fdf"], rel=1e-12) and np.allclose(g2, st["g_fdf"], rtol=1e-10)
+    for name, a in gold["aligns"].items():
+        og = po.OracleGICP(**a["params"])
+        og.setInputTarget(t)
+        og.setInputSource(s)
+        r = og.align(None if a["guess"] is None else np.array(a["guess"], np.float32))
+        assert np.array_equal(r["T"], np.array(a["T"], np.float32)), name
+        assert (r["converged"], r["iterations"], r["n_f"], r["n_df"], r["n_fdf"], r["correspondences"]) == \
+               (a["converged"], a["iterations"], a["n_f"], a["n_df"], a["n_fdf"], a["correspondences"]), name
+
+
 def test_product_driver_equals_oracle_driver(tmp_path):
     """tests/gicp_driver_check.cpp: the product's outer loop + BFGS (gicp_driver.cpp) fed the oracle's sums gives
     the oracle's registration bit for bit -- transform, iterations and functor-call counts -- over random scenes,
