@@ -52,8 +52,11 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
   const int r_lim = max(ix.geom.div_b[0], max(ix.geom.div_b[1], ix.geom.div_b[2]));
   const int r_max = max_shells(ix, r_lim);
   auto lds_fence = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };  // one wave per block: program order is enough
-  for (int i = blockIdx.x * kTeams + team; i < ix.n; i += gridDim.x * kTeams) {  // i is uniform within a team
-    const float4 q = ix.pts[i];
+  // The loop is uniform across the wave (a team without a query idles): the scan of the isolated queries is wave-wide.
+  for (int base = blockIdx.x * kTeams; base < ix.n; base += gridDim.x * kTeams) {
+    const int i = base + team;  // uniform within a team
+    const bool live = i < ix.n;
+    const float4 q = live ? ix.pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;  // entries in the list (team-uniform, like everything below that is not marked "lane")
     float worst = INFINITY;
     int worst_p = 0, worst_slot = 0;
@@ -86,6 +89,24 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       worst_p = bp;
       worst_slot = bs;
     };
+    auto insert_one = [&](float cd, int cp) {  // team-collective: a candidate known to all eight lanes
+      if (cnt < k) {
+        if (sub == 0) {
+          ld[cnt] = cd;
+          lp[cnt] = cp;
+        }
+        lds_fence();
+        cnt++;
+        if (cnt == k) find_worst();
+      } else if (before(cd, cp, worst, worst_p)) {
+        if (sub == 0) {
+          ld[worst_slot] = cd;
+          lp[worst_slot] = cp;
+        }
+        lds_fence();
+        find_worst();
+      }
+    };
     // every lane brings one candidate (or none); the ones that can enter the list are taken one at a time
     auto offer = [&](float d, unsigned upos, bool ok) {
       const int pos = static_cast<int>(upos);
@@ -94,43 +115,34 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
       while (pending) {
         const int owner = __builtin_ctz(pending);
         pending &= pending - 1;
-        const float cd = __shfl(d, team_base + owner, kWave);
-        const int cp = __shfl(pos, team_base + owner, kWave);
-        if (cnt < k) {
-          if (sub == 0) {
-            ld[cnt] = cd;
-            lp[cnt] = cp;
-          }
-          lds_fence();
-          cnt++;
-          if (cnt == k) find_worst();
-        } else if (before(cd, cp, worst, worst_p)) {
-          if (sub == 0) {
-            ld[worst_slot] = cd;
-            lp[worst_slot] = cp;
-          }
-          lds_fence();
-          find_worst();
-        }
+        insert_one(__shfl(d, team_base + owner, kWave), __shfl(pos, team_base + owner, kWave));
       }
     };
     int ci, cj, ck;
     float margin;
     query_cell(ix.geom, q.x, q.y, q.z, ci, cj, ck, margin);
-    bool done = false;
+    bool done = !live;
     for (int r = 0; r <= r_max && !done; r++) {
       team_shell(ix, ci, cj, ck, r, sub, q.x, q.y, q.z, offer);
-      // Every unvisited point is at least r cells (less the index-rounding slack) away: once the k-th best lies
-      // strictly inside that reach no unvisited point can enter the k nearest.
+      // Every unvisited point is at least r cells plus the query's margin (less the index-rounding slack) away: once the
+      // k-th best lies strictly inside that reach no unvisited point can enter the k nearest.
       const float reach = static_cast<float>(r) * leaf + margin - ix.slack;
       if ((cnt == k && reach > 0.0f && worst < reach * reach) || r >= r_lim) done = true;
     }
-    if (!done) {
-      // Sparse neighbourhood: the team looks at every point, twice.  Pass 1 only keeps each lane's eight smallest
-      // distances, in registers; the k-th smallest of the team's 64 values bounds the k-th neighbour's distance
-      // from above.  Pass 2 fills the list with the points inside that bound -- about k of them.
+    // Sparse neighbourhoods: the WAVE looks at every point, twice, for one unfinished query at a time.  Pass 1 only keeps
+    // each lane's eight smallest distances, in registers; the k-th smallest of the wave's 512 values bounds the k-th
+    // neighbour's distance from above.  Pass 2 hands the points inside that bound -- about k of them -- to the query's team,
+    // which fills its list afresh.  (The few isolated queries set this kernel's time when a team walks the cloud alone,
+    // and a single pass with the list spends its time updating it: points arrive in arbitrary order.)
+    unsigned long long open_teams = __ballot(!done && sub == 0);
+    while (open_teams) {
+      const int src_lane = __builtin_ctzll(open_teams);
+      open_teams &= open_teams - 1;
+      const bool mine = (team == src_lane / kTeam);
+      const float ox = __shfl(q.x, src_lane, kWave), oy = __shfl(q.y, src_lane, kWave), oz = __shfl(q.z, src_lane, kWave);
+      const int count = ix.n_sorted;
       float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY, m4 = INFINITY, m5 = INFINITY, m6 = INFINITY, m7 = INFINITY;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z, [&](float d, unsigned, const float4&, bool ok) {
+      auto keep = [&](float d, bool ok) {
         if (!ok || !(d < m7)) return;
         m7 = d;  // bubble the newcomer down the sorted registers
         float t;
@@ -141,20 +153,57 @@ __global__ __launch_bounds__(kKnnBlock) void k_knn_covariances(PointIndex ix, in
         if (m3 < m2) { t = m2; m2 = m3; m3 = t; }
         if (m2 < m1) { t = m1; m1 = m2; m2 = t; }
         if (m1 < m0) { t = m0; m0 = m1; m1 = t; }
-      });
-      float bound = INFINITY;
-      for (int j = 0; j < k; j++) {  // pop the team's smallest head k times (n >= k values exist)
-        float h = m0;
-        int who = sub;
-        team_min(h, who);
-        bound = h;
-        if (who == sub) { m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5; m5 = m6; m6 = m7; m7 = INFINITY; }
+      };
+      for (int b0 = 0; b0 < count; b0 += 4 * kWave) {
+        const int p0 = b0 + lane, p1 = p0 + kWave, p2 = p1 + kWave, p3 = p2 + kWave;
+        const float4 a = ix.sorted_pts[min(p0, count - 1)], b = ix.sorted_pts[min(p1, count - 1)];
+        const float4 c = ix.sorted_pts[min(p2, count - 1)], d = ix.sorted_pts[min(p3, count - 1)];
+        keep(dist2_f32(ox, oy, oz, a.x, a.y, a.z), p0 < count);
+        keep(dist2_f32(ox, oy, oz, b.x, b.y, b.z), p1 < count);
+        keep(dist2_f32(ox, oy, oz, c.x, c.y, c.z), p2 < count);
+        keep(dist2_f32(ox, oy, oz, d.x, d.y, d.z), p3 < count);
       }
-      cnt = 0;
-      worst = INFINITY;
-      scan_all(ix.sorted_pts, ix.n_sorted, sub, q.x, q.y, q.z,
-               [&](float d, unsigned pos, const float4&, bool ok) { offer(d, pos, ok && !(d > bound)); });
+      float bound = INFINITY;
+      for (int j = 0; j < k; j++) {  // pop the wave's smallest head k times (n >= k values exist)
+        float h = m0;
+        int who = lane;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const float oh = __shfl_xor(h, off, kWave);
+          const int ow = __shfl_xor(who, off, kWave);
+          if (oh < h || (oh == h && ow < who)) {
+            h = oh;
+            who = ow;
+          }
+        }
+        bound = h;
+        if (who == lane) { m0 = m1; m1 = m2; m2 = m3; m3 = m4; m4 = m5; m5 = m6; m6 = m7; m7 = INFINITY; }
+      }
+      if (mine) {
+        cnt = 0;
+        worst = INFINITY;
+      }
+      auto hand_over = [&](float d, int pos, bool ok) {  // wave-uniform call: the hits go to the owning team one by one
+        unsigned long long hits = __ballot(ok && !(d > bound));
+        while (hits) {
+          const int from = __builtin_ctzll(hits);
+          hits &= hits - 1;
+          const float cd = __shfl(d, from, kWave);
+          const int cp = __shfl(pos, from, kWave);
+          if (mine) insert_one(cd, cp);
+        }
+      };
+      for (int b0 = 0; b0 < count; b0 += 4 * kWave) {
+        const int p0 = b0 + lane, p1 = p0 + kWave, p2 = p1 + kWave, p3 = p2 + kWave;
+        const float4 a = ix.sorted_pts[min(p0, count - 1)], b = ix.sorted_pts[min(p1, count - 1)];
+        const float4 c = ix.sorted_pts[min(p2, count - 1)], d = ix.sorted_pts[min(p3, count - 1)];
+        hand_over(dist2_f32(ox, oy, oz, a.x, a.y, a.z), p0, p0 < count);
+        hand_over(dist2_f32(ox, oy, oz, b.x, b.y, b.z), p1, p1 < count);
+        hand_over(dist2_f32(ox, oy, oz, c.x, c.y, c.z), p2, p2 < count);
+        hand_over(dist2_f32(ox, oy, oz, d.x, d.y, d.z), p3, p3 < count);
+      }
     }
+    if (!live) continue;
     // rank sort: entry j goes to the place given by the number of entries before it
     for (int j = sub; j < cnt; j += kTeam) {
       const float d = ld[j];
