@@ -125,21 +125,28 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
     if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
     const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
     const int nx = face ? w : 2;
-    for (int t = 0; t < w; t++) {
-      uint2 range = make_uint2(0u, 0u);
-      if (row_ok && t < nx) {
-        const int x = ci + (face ? t - r : (t == 0 ? -r : r));
-        if (x >= 0 && x < g.div_b[0]) range = ix.cell_range[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+    for (int t = 0; t < w; t += 2) {  // two cells of the row per step: both table loads are in flight together
+      uint2 range[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int tt = t + u;
+        if (row_ok && tt < nx) {
+          const int x = ci + (face ? tt - r : (tt == 0 ? -r : r));
+          if (x >= 0 && x < g.div_b[0]) range[u] = ix.cell_range[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+        }
       }
-      const unsigned first = range.x;
-      const int count = static_cast<int>(range.y);
-      unsigned found = static_cast<unsigned>((__ballot(count > 0) >> team_base) & 0xffull);
-      while (found) {
-        const int owner = __builtin_ctz(found);
-        found &= found - 1;
-        const unsigned fs = __shfl(first, team_base + owner, kWave);
-        const int fc = __shfl(count, team_base + owner, kWave);
-        scan_run(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const unsigned first = range[u].x;
+        const int count = static_cast<int>(range[u].y);
+        unsigned found = static_cast<unsigned>((__ballot(count > 0) >> team_base) & 0xffull);
+        while (found) {
+          const int owner = __builtin_ctz(found);
+          found &= found - 1;
+          const unsigned fs = __shfl(first, team_base + owner, kWave);
+          const int fc = __shfl(count, team_base + owner, kWave);
+          scan_run(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
+        }
       }
     }
   }
