@@ -352,7 +352,8 @@ __device__ __forceinline__ void sort_segment(int* seg, int cnt) {
 // global memory with one thread and chasing index -> point per addition (measured on the reference pair: 583 us per
 // target build, almost all of it in that one-thread path).
 constexpr int kPresortMin = 16;    // <= this many points: k_finalize's register path
-constexpr int kPresortLds = 4096;  // segments up to here are sorted in LDS; longer ones by lane 0 (heap sort) as before
+constexpr int kPresortLds = 8192;  // segments up to here are sorted in LDS; longer ones by lane 0 (heap sort) as before
+constexpr int kPresortRank = 128;  // up to here: rank sort (n^2 / 64 steps); above: bitonic network (n log^2 n / 128 steps)
 __global__ __launch_bounds__(kWave) void k_presort_large(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
                                                         const int* __restrict__ leaf_count, int n_leaves_host,
                                                         const unsigned* __restrict__ d_totals, int* __restrict__ sorted_idx,
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kWave) void k_presort_large(const float4* __restric
     const int cnt = __shfl(my_cnt, pick, kWave);
     const unsigned start = leaf_start[leaf];
     int* seg = sorted_idx + start;
-    if (cnt <= kPresortLds) {
+    if (cnt <= kPresortRank) {
       for (int i = lane; i < cnt; i += kWave) s_idx[i] = seg[i];
       __syncthreads();  // (one wave per block)
       for (int i = lane; i < cnt; i += kWave) {
@@ -384,6 +385,32 @@ __global__ __launch_bounds__(kWave) void k_presort_large(const float4* __restric
         big_pts[start + rank] = pts[v];
       }
       __syncthreads();  // s_idx is reused by the next leaf
+    } else if (cnt <= kPresortLds) {
+      int m = 1;
+      while (m < cnt) m <<= 1;  // padded with INT_MAX to a power of two
+      for (int i = lane; i < m; i += kWave) s_idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
+      __syncthreads();
+      for (int span = 2; span <= m; span <<= 1)
+        for (int j = span >> 1; j > 0; j >>= 1) {
+          for (int i = lane; i < m; i += kWave) {
+            const int partner = i ^ j;
+            if (partner > i) {
+              const int a = s_idx[i], b = s_idx[partner];
+              const bool ascending = (i & span) == 0;
+              if ((a > b) == ascending) {
+                s_idx[i] = b;
+                s_idx[partner] = a;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      for (int i = lane; i < cnt; i += kWave) {
+        const int v = s_idx[i];
+        seg[i] = v;
+        big_pts[start + i] = pts[v];
+      }
+      __syncthreads();
     } else {
       if (lane == 0) sort_segment(seg, cnt);
       __syncthreads();
