@@ -148,7 +148,7 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
-                              unsigned long long* dbg = nullptr, int direct = 0);
+                              unsigned long long* dbg = nullptr, int direct = 0, float4* out_host = nullptr);
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
                             double* partials, hipStream_t stream);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
                                                             unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                                                             int param_pad, const float4* __restrict__ out_src,
                                                             float4* __restrict__ out_dst, int out_n, unsigned long long* dbg,
-                                                            int direct) {
+                                                            int direct, float4* __restrict__ out_host) {
   constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
   __shared__ double lds[kWaves * 32];
   __shared__ EvalParams sP;
@@ -312,7 +312,9 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
         const float4 pt = out_src[i];
         float tx, ty, tz;
         xform_point(sP.T, pt.x, pt.y, pt.z, tx, ty, tz);
-        out_dst[i] = make_float4(tx, ty, tz, 1.0f);
+        const float4 moved = make_float4(tx, ty, tz, 1.0f);
+        out_dst[i] = moved;
+        if (out_host) out_host[i] = moved;  // the caller wants the cloud on the host: written there directly (page-locked)
       }
       return;
     }
@@ -472,21 +474,21 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
-                              unsigned long long* dbg, int direct) {
+                              unsigned long long* dbg, int direct, float4* out_host) {
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 0)
     hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
   else if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
   else if (search == 3)
     hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
   else
     hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
   return hipGetLastError();
 }
 
