@@ -27,6 +27,8 @@ struct gicp_context {
   DevBuf<int> nn_idx;
   DevBuf<float> nn_d2;
   double* host_pub = nullptr;  // pinned tagged publication row
+  void* out_pinned = nullptr;  // page-locked staging of the aligned cloud
+  size_t out_pinned_bytes = 0;
   unsigned long long seq = 0;
   float guess_rm[16];          // guess of the current align / step, row-major
   bool step_ready = false;
@@ -43,6 +45,7 @@ struct gicp_context {
     cov_tgt.release(); cov_src.release(); output.release(); corr.release(); maha.release(); partials.release();
     counter.release(); out_cloud.release(); nn_idx.release(); nn_d2.release();
     if (host_pub) (void)hipHostFree(host_pub);
+    if (out_pinned) (void)hipHostFree(out_pinned);
   }
 };
 
@@ -365,8 +368,18 @@ ndt_status gicp_align(gicp_handle h, const float* guess, float* final_T, int* co
     const size_t n = h->src.target->n;
     HIP_TRY(h->out_cloud.reserve(n));
     HIP_TRY(ndt::launch_transform(h->src.target->pts.p, static_cast<int>(n), r.final_T, h->out_cloud.p, h->tgt.stream));
-    HIP_TRY(hipMemcpyAsync(out_cloud, h->out_cloud.p, n * sizeof(float4), hipMemcpyDeviceToHost, h->tgt.stream));
+    // through page-locked staging: a D2H copy into the caller's pageable buffer is staged by the runtime in small pieces
+    const size_t bytes = n * sizeof(float4);
+    if (h->out_pinned_bytes < bytes) {
+      if (h->out_pinned) (void)hipHostFree(h->out_pinned);
+      h->out_pinned = nullptr;
+      h->out_pinned_bytes = 0;
+      HIP_TRY(hipHostMalloc(&h->out_pinned, bytes + bytes / 4, hipHostMallocDefault));
+      h->out_pinned_bytes = bytes + bytes / 4;
+    }
+    HIP_TRY(hipMemcpyAsync(h->out_pinned, h->out_cloud.p, bytes, hipMemcpyDeviceToHost, h->tgt.stream));
     HIP_TRY(hipStreamSynchronize(h->tgt.stream));
+    std::memcpy(out_cloud, h->out_pinned, bytes);
   }
   return NDT_OK;
 }
