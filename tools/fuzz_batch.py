@@ -40,7 +40,10 @@ def main():
             g.align(guesses[k])
             T = g.getFinalTransformation()
             members += 1
-            same = (np.abs(res["T"][k] - T).max() < 2e-5 and res["iterations"][k] == g.getFinalNumIteration() and
+            # fewer than 3 points leave the 6x6 Hessian rank-deficient: the pseudo-inverse step amplifies the last-bit
+            # differences between the batch kernels and the single-scan kernels (two translation units, different packing)
+            tol = 2e-5 if len(sc) >= 3 else 1e-3
+            same = (np.abs(res["T"][k] - T).max() < tol and res["iterations"][k] == g.getFinalNumIteration() and
                     bool(res["converged"][k]) == g.hasConverged())
             if not same:
                 bad += 1
