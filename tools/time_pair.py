@@ -19,4 +19,11 @@ print("align (no cloud) %.0f us | align + aligned cloud to host %.0f us | iterat
 print("getFitnessScore %.0f us" % med(lambda: g.getFitnessScore()))
 def scan():
     g.setInputTarget(t); g.setInputSource(s); g.align(); g.getFinalTransformation()
-print("per scan (target + source + align + result) %.0f us" % med(scan))
+per_scan = med(scan)
+print("per scan (target + source + align + result) %.0f us" % per_scan)
+import json
+print(json.dumps({"workload": "reference pair after the 0.1 m prefilter (15772 / 15950 points), resolution 1.0, DIRECT7, class defaults",
+                  "set_input_target_us": med(lambda: g.setInputTarget(t)), "set_input_source_us": med(lambda: g.setInputSource(s)),
+                  "align_us": med(lambda: g.align()), "align_with_cloud_to_host_us": med(lambda: g.align(n_out=len(s))),
+                  "get_fitness_score_us": med(lambda: g.getFitnessScore()), "per_scan_us": per_scan,
+                  "iterations": g.getFinalNumIteration(), "evaluations": g.stats()["n_evals"]}))
