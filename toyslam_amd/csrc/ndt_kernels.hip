@@ -353,70 +353,72 @@ __device__ __forceinline__ void sort_segment(int* seg, int cnt) {
 // target build, almost all of it in that one-thread path).
 constexpr int kPresortMin = 16;    // <= this many points: k_finalize's register path
 constexpr int kPresortLds = 8192;  // segments up to here are sorted in LDS; longer ones by lane 0 (heap sort) as before
-constexpr int kPresortRank = 128;  // up to here: rank sort (n^2 / 64 steps); above: bitonic network (n log^2 n / 128 steps)
-__global__ __launch_bounds__(kWave) void k_presort_large(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                        const int* __restrict__ leaf_count, int n_leaves_host,
-                                                        const unsigned* __restrict__ d_totals, int* __restrict__ sorted_idx,
-                                                        float4* __restrict__ big_pts, int chunk) {
+constexpr int kPresortRank = 256;  // up to here: rank sort (one element per thread, n comparisons each); above: bitonic network
+__global__ __launch_bounds__(kBlock) void k_presort_large(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
+                                                         const int* __restrict__ leaf_count, int n_leaves_host,
+                                                         const unsigned* __restrict__ d_totals, int* __restrict__ sorted_idx,
+                                                         float4* __restrict__ big_pts, int chunk) {
   __shared__ int s_idx[kPresortLds];
+  __shared__ int s_cnt[kWave];
   const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;
-  const int lane = threadIdx.x;
-  // `chunk` (1..64, the launcher picks it so that the grid stays within 8192 waves) leaves are looked at per step (one load of their counts); the crowded ones among them are taken one
-  // after the other by the whole wave -- few leaves: about one crowded leaf per wave; many leaves without crowded
-  // ones: a short pass over leaf_count
+  const int tid = threadIdx.x;
+  // `chunk` (1..64, the launcher picks it so that the grid stays within 8192 blocks) leaves are looked at per step (one
+  // load of their counts); the crowded ones among them are taken one after the other by the whole block -- few leaves:
+  // about one crowded leaf per block; many leaves without crowded ones: a short pass over leaf_count
   for (int base = blockIdx.x * chunk; base < n_leaves; base += gridDim.x * chunk) {
-   const int my_cnt = (lane < chunk && base + lane < n_leaves) ? leaf_count[base + lane] : 0;
-   unsigned long long crowded = __ballot(my_cnt > kPresortMin);
-   while (crowded) {
-    const int pick = __builtin_ctzll(crowded);
-    crowded &= crowded - 1;
-    const int leaf = base + pick;
-    const int cnt = __shfl(my_cnt, pick, kWave);
-    const unsigned start = leaf_start[leaf];
-    int* seg = sorted_idx + start;
-    if (cnt <= kPresortRank) {
-      for (int i = lane; i < cnt; i += kWave) s_idx[i] = seg[i];
-      __syncthreads();  // (one wave per block)
-      for (int i = lane; i < cnt; i += kWave) {
-        const int v = s_idx[i];
-        int rank = 0;
-        for (int j = 0; j < cnt; j++) rank += (s_idx[j] < v) ? 1 : 0;  // point indices are unique
-        seg[rank] = v;
-        big_pts[start + rank] = pts[v];
-      }
-      __syncthreads();  // s_idx is reused by the next leaf
-    } else if (cnt <= kPresortLds) {
-      int m = 1;
-      while (m < cnt) m <<= 1;  // padded with INT_MAX to a power of two
-      for (int i = lane; i < m; i += kWave) s_idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
-      __syncthreads();
-      for (int span = 2; span <= m; span <<= 1)
-        for (int j = span >> 1; j > 0; j >>= 1) {
-          for (int i = lane; i < m; i += kWave) {
-            const int partner = i ^ j;
-            if (partner > i) {
-              const int a = s_idx[i], b = s_idx[partner];
-              const bool ascending = (i & span) == 0;
-              if ((a > b) == ascending) {
-                s_idx[i] = b;
-                s_idx[partner] = a;
+    __syncthreads();  // s_cnt / s_idx of the previous step are done with
+    if (tid < chunk) s_cnt[tid] = (base + tid < n_leaves) ? leaf_count[base + tid] : 0;
+    __syncthreads();
+    for (int pick = 0; pick < chunk; pick++) {
+      const int cnt = s_cnt[pick];  // uniform across the block
+      if (cnt <= kPresortMin) continue;
+      const int leaf = base + pick;
+      const unsigned start = leaf_start[leaf];
+      int* seg = sorted_idx + start;
+      if (cnt <= kPresortRank) {
+        for (int i = tid; i < cnt; i += kBlock) s_idx[i] = seg[i];
+        __syncthreads();
+        for (int i = tid; i < cnt; i += kBlock) {
+          const int v = s_idx[i];
+          int rank = 0;
+          for (int j = 0; j < cnt; j++) rank += (s_idx[j] < v) ? 1 : 0;  // point indices are unique
+          seg[rank] = v;
+          big_pts[start + rank] = pts[v];
+        }
+        __syncthreads();  // s_idx is reused by the next leaf
+      } else if (cnt <= kPresortLds) {
+        int m = 1;
+        while (m < cnt) m <<= 1;  // padded with INT_MAX to a power of two
+        for (int i = tid; i < m; i += kBlock) s_idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
+        __syncthreads();
+        for (int span = 2; span <= m; span <<= 1)
+          for (int j = span >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += kBlock) {
+              const int partner = i ^ j;
+              if (partner > i) {
+                const int a = s_idx[i], b = s_idx[partner];
+                const bool ascending = (i & span) == 0;
+                if ((a > b) == ascending) {
+                  s_idx[i] = b;
+                  s_idx[partner] = a;
+                }
               }
             }
+            __syncthreads();
           }
-          __syncthreads();
+        for (int i = tid; i < cnt; i += kBlock) {
+          const int v = s_idx[i];
+          seg[i] = v;
+          big_pts[start + i] = pts[v];
         }
-      for (int i = lane; i < cnt; i += kWave) {
-        const int v = s_idx[i];
-        seg[i] = v;
-        big_pts[start + i] = pts[v];
+        __syncthreads();
+      } else {
+        if (tid == 0) sort_segment(seg, cnt);
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < cnt; i += kBlock) big_pts[start + i] = pts[__hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
       }
-      __syncthreads();
-    } else {
-      if (lane == 0) sort_segment(seg, cnt);
-      __syncthreads();
-      for (int i = lane; i < cnt; i += kWave) big_pts[start + i] = pts[__hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
     }
-   }
   }
 }
 
@@ -1072,7 +1074,7 @@ hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsi
   // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
   if (n_leaves == 0) return hipSuccess;
   if (d_big_pts)  // leaves with many points: sorted and gathered by one wave each, ahead of the per-leaf pass
-    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, d_leaf_start, d_leaf_count, n_leaves,
+    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, d_leaf_start, d_leaf_count, n_leaves,
                        d_totals, d_sorted_idx, d_big_pts, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
                      d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
@@ -1089,7 +1091,7 @@ hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, con
                               int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
   if (n_leaves == 0) return hipSuccess;
   // crowded cells first, one wave each (sorted and gathered straight into `out`); k_sort_gather takes the rest
-  hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
+  hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
                      sorted_idx, out, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_sort_gather, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
                      leaf_count, n_leaves, d_totals, sorted_idx, out);
@@ -1106,7 +1108,7 @@ hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start,
                                   int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
   if (n_leaves == 0) return hipSuccess;
   if (d_big_pts)
-    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kWave), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
+    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
                        sorted_idx, d_big_pts, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
                      leaf_count, n_leaves, d_totals, sorted_idx, out, d_big_pts);
