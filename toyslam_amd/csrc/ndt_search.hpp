@@ -125,7 +125,10 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
     if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
     const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
     const int nx = face ? w : 2;
-    for (int t = 0; t < w; t += 2) {  // two cells of the row per step: both table loads are in flight together
+    int steps = row_ok ? nx : 0;  // the longest occupied row of this batch sets the number of steps (interior rows: 2 cells)
+#pragma unroll
+    for (int off = 1; off < kTeam; off <<= 1) steps = max(steps, __shfl_xor(steps, off, kWave));
+    for (int t = 0; t < steps; t += 2) {  // two cells of the row per step: both table loads are in flight together
       uint2 range[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #pragma unroll
       for (int u = 0; u < 2; u++) {
