@@ -314,3 +314,25 @@ def test_gpu_matches_the_golden_registrations(gmod, pair):
         st = g.stats()
         assert (g.hasConverged(), g.getFinalNumIteration(), st["n_f"], st["n_df"], st["n_fdf"], st["correspondences"]) == \
                (a["converged"], a["iterations"], a["n_f"], a["n_df"], a["n_fdf"], a["correspondences"]), name
+
+
+def test_objective_server_survives_a_quiet_host_and_can_be_switched_off(pair):
+    """The persistent objective server (one launch per BFGS run): a host that goes quiet for 150 ms in the middle of a run --
+    the server's patience is 20 ms, it tells the host and drains on its own -- costs time, not correctness (the launch path
+    answers, the next run gets a fresh server); and with NDT_GICP_SERVER=0 every evaluation is its own launch.  Both give the
+    registration of the default configuration, bit for bit.  (Subprocesses: the switches are read once per process.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from toyslam_amd import gicp; "
+            "d = np.load(%r); g = gicp.GeneralizedIterativeClosestPoint(); g.setInputTarget(d['target']); g.setInputSource(d['source']); "
+            "g.align(); g.align(); print(json.dumps({'T': g.getFinalTransformation().tolist(), 'it': g.getFinalNumIteration(), 'st': g.stats()}))"
+            % (root, os.path.join(root, "tests", "golden", "pair_0p1.npz")))
+    results = {}
+    for name, env in (("default", {}), ("stall", {"NDT_GICP_TEST_STALL_MS": "150"}), ("launches", {"NDT_GICP_SERVER": "0"})):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        results[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert results["stall"] == results["default"] == results["launches"]

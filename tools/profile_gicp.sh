@@ -34,8 +34,10 @@ for name in ("pair", "large"):
                 return v
         return None
     rl = {}
+    # the objective server serves one BFGS run per launch: evaluations / outer iterations of them, m * 72 B each
+    per_launch = max(1.0, t["evaluations"] / max(1, t["iterations"]))
     for kern, nbytes, which in (("k_knn_covariances", nt * (16 + 16 * k + 48), "max_us"), ("k_correspond", ns * (16 + 16 + 96 + 40), "max_us"),
-                                ("k_functor<2>", m * 72, "avg_us")):
+                                ("k_gicp_server", m * 72 * per_launch, "avg_us"), ("k_functor<2>", m * 72, "avg_us")):
         v = pick(kern)
         if v:
             gbs = nbytes / (v[which] * 1e-6) / 1e9

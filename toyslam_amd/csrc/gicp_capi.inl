@@ -28,6 +28,14 @@ struct gicp_context {
   DevBuf<float> nn_d2;
   double* host_pub = nullptr;  // pinned tagged publication row
   void* out_pinned = nullptr;  // page-locked staging of the aligned cloud
+  // persistent objective server (one launch per BFGS run): two alternating command mailboxes in host-visible device
+  // memory, shard counters, the pinned part rows
+  void* srv_mbs = nullptr;
+  int srv_flip = 0;
+  bool srv_tried = false;
+  double* srv_rows = nullptr;
+  DevBuf<unsigned> srv_counter;
+  int srv_blocks = 0;
   size_t out_pinned_bytes = 0;
   unsigned long long seq = 0;
   float guess_rm[16];          // guess of the current align / step, row-major
@@ -46,6 +54,9 @@ struct gicp_context {
     counter.release(); out_cloud.release(); nn_idx.release(); nn_d2.release();
     if (host_pub) (void)hipHostFree(host_pub);
     if (out_pinned) (void)hipHostFree(out_pinned);
+    if (srv_mbs) (void)hipFree(srv_mbs);
+    if (srv_rows) (void)hipHostFree(srv_rows);
+    srv_counter.release();
   }
 };
 
@@ -195,6 +206,7 @@ struct GicpDevice : gicp::Backend {
   // point (gicp_driver.cpp line_search): the operator() launch also accumulates df's sums, and the df request that
   // follows is answered from here without a launch.
   bool fuse = std::getenv("NDT_GICP_NO_FUSE") == nullptr;
+  int evals_served = 0;
   bool have_grad = false;
   float grad_T[16];
   gicp::FunctorSums grad_sums;
@@ -204,6 +216,7 @@ struct GicpDevice : gicp::Backend {
     gicp::Rot3d rot;
     for (int i = 0; i < 9; i++) rot.m[i] = R[i];
     have_grad = false;
+    server_stop();  // the correspondences change: the next BFGS run gets a fresh server behind this kernel
     const double thr = h->prm.corr_dist_threshold * h->prm.corr_dist_threshold;  // :401
     const hipError_t e = gicp::launch_correspond(h->output.p, static_cast<int>(h->src.target->n), transformation, rot,
                                                  gicp_index_of(&h->tgt), h->cov_src.p, h->cov_tgt.p, thr, h->corr.p, h->maha.p,
@@ -215,38 +228,125 @@ struct GicpDevice : gicp::Backend {
     return true;
   }
 
+  // ---- persistent objective server -------------------------------------------------------------------------
+  void* mailbox() const { return static_cast<unsigned char*>(h->srv_mbs) + static_cast<size_t>(h->srv_flip) * ndt::server_mailbox_bytes(); }
+  bool server_available() {
+    if (h->srv_tried) return h->srv_mbs != nullptr;
+    h->srv_tried = true;
+    const char* v = std::getenv("NDT_GICP_SERVER");
+    if (v && std::atoi(v) == 0) return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->tgt.device) != hipSuccess || prop.isLargeBar == 0) return false;  // the direct mailbox needs the BAR
+    const size_t mb = ndt::server_mailbox_bytes();
+    if (hipExtMallocWithFlags(&h->srv_mbs, 2 * mb, hipDeviceMallocFinegrained) != hipSuccess) {
+      h->srv_mbs = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    if (hipMemset(h->srv_mbs, 0, 2 * mb) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->srv_rows), gicp::kGicpServerParts * ndt::kPublishSlots * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        h->srv_counter.reserve(32 * gicp::kGicpServerParts) != hipSuccess) {
+      (void)hipFree(h->srv_mbs);
+      h->srv_mbs = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    std::memset(h->srv_rows, 0, gicp::kGicpServerParts * ndt::kPublishSlots * sizeof(double));
+    return true;
+  }
+  bool server_start() {
+    server_mark(&h->tgt, true);  // this device's turn among the persistent kernels of the process
+    h->srv_flip ^= 1;
+    ndt::server_reset_mailbox(mailbox());
+    const int n = static_cast<int>(h->src.target->n);
+    h->srv_blocks = gicp::server_blocks(n);
+    hipError_t e = hipMemsetAsync(h->srv_counter.p, 0, 32 * gicp::kGicpServerParts * sizeof(unsigned), h->tgt.stream);
+    if (e == hipSuccess) e = h->partials.reserve(static_cast<size_t>(std::max(h->srv_blocks, gicp::kFunctorMaxBlocks)) * ndt::kEvalStride);
+    if (e == hipSuccess)
+      e = gicp::launch_server(h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, mailbox(), h->srv_blocks, h->partials.p,
+                              h->srv_counter.p, h->srv_rows, h->seq + 1, 2000000ull /* 20 ms */, h->tgt.stream);
+    if (e != hipSuccess) {
+      server_mark(&h->tgt, false);
+      error = std::string("objective server: ") + hipGetErrorString(e);
+      return false;
+    }
+    return true;
+  }
+  void server_stop() {  // the last command: everything queued later on the stream runs behind the exiting kernel
+    if (!h->tgt.server_running) return;
+    ndt::server_post(mailbox(), ++h->seq, ndt::kServerCmdExit, nullptr, nullptr);
+    server_mark(&h->tgt, false);
+  }
+  // one evaluation through the server; false = it has left (idle time-out): the caller uses the launch path
+  bool server_sums(int launch_mode, const float T[16], double row[ndt::kEvalStride]) {
+    const unsigned long long seq = ++h->seq;
+    ndt::server_post(mailbox(), seq, launch_mode, T, nullptr);
+    const int n_parts = std::min(gicp::kGicpServerParts, h->srv_blocks);
+    unsigned arrived = 0;
+    const unsigned all = (1u << n_parts) - 1u;
+    unsigned spins = 0;
+    for (;;) {
+      for (int p = 0; p < n_parts; p++)
+        if (!(arrived & (1u << p)) && pub_ready(h->srv_rows + static_cast<size_t>(p) * ndt::kPublishSlots, seq)) arrived |= 1u << p;
+      if (arrived == all) break;
+      __builtin_ia32_pause();
+      if ((++spins & 0x3FFF) == 0 && (ndt::server_dead_word(mailbox()) != 0 || hipStreamQuery(h->tgt.stream) != hipErrorNotReady)) {
+        server_mark(&h->tgt, false);
+        (void)hipStreamSynchronize(h->tgt.stream);
+        return false;
+      }
+    }
+    double part[ndt::kEvalStride];
+    for (int k = 0; k < ndt::kEvalStride; k++) row[k] = 0.0;
+    for (int p = 0; p < gicp::kGicpServerParts; p++) {  // second stage of k_functor's fixed-order sum
+      if (p < n_parts) pub_gather(h->srv_rows + static_cast<size_t>(p) * ndt::kPublishSlots, part);
+      for (int k = 0; k < ndt::kEvalStride; k++) row[k] += (p < n_parts) ? part[k] : 0.0;
+    }
+    return true;
+  }
+
   bool sums(int mode, const float T[16], gicp::FunctorSums& out) override {
     if (mode == 1 && have_grad && std::memcmp(T, grad_T, sizeof(grad_T)) == 0) {
       out = grad_sums;
       return true;
     }
     const int n = static_cast<int>(h->src.target->n);
-    const unsigned long long seq = ++h->seq;
     const int launch_mode = (mode == 0 && fuse) ? 3 : mode;
-    const hipError_t e = gicp::launch_functor(launch_mode, h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, T,
-                                              gicp::functor_blocks(n), h->partials.p, h->counter.p, h->host_pub, seq, h->tgt.stream);
-    if (e != hipSuccess) {
-      error = std::string("functor kernel: ") + hipGetErrorString(e);
-      return false;
+    double row[ndt::kEvalStride];
+    bool have_row = false;
+    if (server_available()) {
+      if (!h->tgt.server_running && !server_start()) return false;
+      // liveness test hook: a host that goes quiet in the middle of a BFGS run (the server's patience is 20 ms)
+      static const int stall_ms = std::getenv("NDT_GICP_TEST_STALL_MS") ? std::atoi(std::getenv("NDT_GICP_TEST_STALL_MS")) : 0;
+      if (stall_ms > 0 && ++evals_served == 5) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+      have_row = server_sums(launch_mode, T, row);
     }
-    // the row arrives as 64 self-validating words; poll, and look at the stream now and then so that a
-    // failed launch cannot hang the caller
-    for (unsigned long long spins = 1; !pub_ready(h->host_pub, seq); spins++) {
-      if ((spins & 0xfffff) == 0) {
-        const hipError_t q = hipStreamQuery(h->tgt.stream);
-        if (q == hipSuccess) {
-          if (pub_ready(h->host_pub, seq)) break;
-          error = "functor kernel finished without publishing its result";
-          return false;
-        }
-        if (q != hipErrorNotReady) {
-          error = std::string("functor kernel: ") + hipGetErrorString(q);
-          return false;
+    if (!have_row) {
+      const unsigned long long seq = ++h->seq;
+      const hipError_t e = gicp::launch_functor(launch_mode, h->output.p, n, h->tgt.target->pts.p, h->corr.p, h->maha.p, T,
+                                                gicp::functor_blocks(n), h->partials.p, h->counter.p, h->host_pub, seq, h->tgt.stream);
+      if (e != hipSuccess) {
+        error = std::string("functor kernel: ") + hipGetErrorString(e);
+        return false;
+      }
+      // the row arrives as 64 self-validating words; poll, and look at the stream now and then so that a
+      // failed launch cannot hang the caller
+      for (unsigned long long spins = 1; !pub_ready(h->host_pub, seq); spins++) {
+        if ((spins & 0xfffff) == 0) {
+          const hipError_t q = hipStreamQuery(h->tgt.stream);
+          if (q == hipSuccess) {
+            if (pub_ready(h->host_pub, seq)) break;
+            error = "functor kernel finished without publishing its result";
+            return false;
+          }
+          if (q != hipErrorNotReady) {
+            error = std::string("functor kernel: ") + hipGetErrorString(q);
+            return false;
+          }
         }
       }
+      pub_gather(h->host_pub, row);
     }
-    double row[ndt::kEvalStride];
-    pub_gather(h->host_pub, row);
     out.f = row[0];
     for (int i = 0; i < 3; i++) out.g[i] = row[1 + i];
     for (int i = 0; i < 9; i++) out.R[i] = row[4 + i];
@@ -258,6 +358,7 @@ struct GicpDevice : gicp::Backend {
     }
     return true;
   }
+  ~GicpDevice() override { server_stop(); }
 };
 
 }  // namespace

@@ -461,6 +461,139 @@ __global__ __launch_bounds__(kBlock) void k_functor(const float4* __restrict__ o
   publish_row_tagged(out_row, lds, threadIdx.x, seq);
 }
 
+// ---------------------------------------------------------------------------
+// Persistent objective server: ONE launch per BFGS run (the ~50 objective / gradient evaluations between two
+// correspondence steps) instead of one launch per evaluation -- the protocol of the NDT evaluation server
+// (ndt_latency.hip) with the direct mailbox: the host writes a 256-byte command (32 self-validating words: T[12], the
+// mode) through the BAR into fine-grained device memory, every block reads it there, evaluates its slice of the
+// correspondences, stores its partial row, takes a ticket on one of 8 shard counters (shard = part of k_functor's
+// fixed-order sum), and a shard's last arriver publishes the part sum as a tagged row into pinned host memory; the host
+// adds the 8 parts in order -- the same additions in the same order as k_functor's last block.
+// Liveness: every spin is bounded by s_memrealtime budgets; block 0 tells the host when the server gives up.
+// gridDim.x must not exceed the number of co-resident blocks (the launcher keeps it small).
+// ---------------------------------------------------------------------------
+constexpr int kGicpCmdWords = 32;
+constexpr int kGicpCmdExit = 0x7fffffff;
+struct GicpMailbox {  // layout of ndt_latency.hip's ServerMailbox (the host fills it with ndt::server_post)
+  unsigned long long cmd[kGicpCmdWords];
+  unsigned long long dead;
+  unsigned long long pad[15];
+};
+
+__global__ __launch_bounds__(kBlock) void k_gicp_server(const float4* __restrict__ output, int n, const float4* __restrict__ tgt,
+                                                        const int* __restrict__ corr, const float* __restrict__ maha9,
+                                                        GicpMailbox* mb, double* __restrict__ partials,
+                                                        unsigned* __restrict__ counter, double* __restrict__ out_rows,
+                                                        unsigned long long first_seq, unsigned long long idle_ticks) {
+#pragma clang fp contract(off)
+  constexpr int kWaves = kBlock / kWave, kParts = kBlock / kEvalStride;  // 8 parts, as in k_functor
+  static_assert(kParts == kGicpServerParts, "the host adds kGicpServerParts part sums");
+  __shared__ double lds[kWaves * 32];
+  __shared__ float sT[12];
+  __shared__ int s_mode;
+  __shared__ int s_last;
+  unsigned long long expect = first_seq;
+  for (;;) {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (wave == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long patience = (blockIdx.x == 0) ? idle_ticks : 4 * idle_ticks;
+      unsigned long long w = 0;
+      bool got = false;
+      for (;;) {
+        if (lane < kGicpCmdWords) w = __hip_atomic_load(&mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__ballot(lane >= kGicpCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > patience) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!got && blockIdx.x == 0 && lane == 0) __hip_atomic_store(&mb->dead, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      int mode = kGicpCmdExit;
+      if (got) {
+        const unsigned payload = static_cast<unsigned>(w >> 32);
+        mode = static_cast<int>(__shfl(payload, 12, kWave));
+        if (lane < 12) sT[lane] = __int_as_float(static_cast<int>(payload));
+      }
+      if (lane == 0) s_mode = mode;
+    }
+    __syncthreads();
+    const int mode = s_mode;
+    if (mode < 0 || mode > 3) return;  // EXIT, time-out or garbage: the whole block leaves together (0 f, 1 df, 2 fdf, 3 f + df)
+    double acc[kFunctorValues];
+#pragma unroll
+    for (int k = 0; k < kFunctorValues; k++) acc[k] = 0.0;
+    for (int i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
+      const int c = corr[i];
+      if (c < 0) continue;
+      const float4 ps = output[i];
+      const float4 pt = tgt[c];
+      const float* M = maha9 + static_cast<size_t>(i) * 9;
+      float px, py, pz;
+      matvec_eigen(sT, ps.x, ps.y, ps.z, px, py, pz);
+      const float r0 = px - pt.x, r1 = py - pt.y, r2 = pz - pt.z;
+      if (mode == 0 || mode == 3) {  // operator(), :241-274
+        const float m0 = (M[0] * r0 + M[1] * r1) + M[2] * r2;
+        const float m1 = (M[3] * r0 + M[4] * r1) + M[5] * r2;
+        const float m2 = (M[6] * r0 + M[7] * r1) + M[8] * r2;
+        const float ret = (r0 * m0 + r2 * m2) + r1 * m1;
+        acc[0] += static_cast<double>(ret);
+      }
+      if (mode != 0) {  // df / fdf, :277-368
+        const double d0 = static_cast<double>(r0), d1 = static_cast<double>(r1), d2 = static_cast<double>(r2);
+        const double t0 = (static_cast<double>(M[0]) * d0 + static_cast<double>(M[1]) * d1) + static_cast<double>(M[2]) * d2;
+        const double t1 = (static_cast<double>(M[3]) * d0 + static_cast<double>(M[4]) * d1) + static_cast<double>(M[5]) * d2;
+        const double t2 = (static_cast<double>(M[6]) * d0 + static_cast<double>(M[7]) * d1) + static_cast<double>(M[8]) * d2;
+        if (mode != 3) acc[0] += (d0 * t0 + d1 * t1) + d2 * t2;
+        acc[1] += t0;
+        acc[2] += t1;
+        acc[3] += t2;
+        const double sx = static_cast<double>(ps.x), sy = static_cast<double>(ps.y), sz = static_cast<double>(ps.z);
+        acc[4] += sx * t0;
+        acc[5] += sx * t1;
+        acc[6] += sx * t2;
+        acc[7] += sy * t0;
+        acc[8] += sy * t1;
+        acc[9] += sy * t2;
+        acc[10] += sz * t0;
+        acc[11] += sz * t1;
+        acc[12] += sz * t2;
+      }
+      acc[13] += 1.0;
+    }
+    const double tot = wave_fold<kFunctorValues>(acc);
+    if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < kEvalStride) {
+        double v = 0.0;
+        if (lane < kFunctorValues) {
+          v = lds[lane];
+#pragma unroll
+          for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+        }
+        __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned round = static_cast<unsigned>(expect - first_seq);
+        const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
+        const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
+        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t1 == (round + 1u) * in_shard - 1u) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (s_last) {
+      const int shard = static_cast<int>(blockIdx.x % static_cast<unsigned>(kParts));
+      if (tid < kEvalStride) lds[tid] = sum_rows_fixed<kParts>(partials, gridDim.x, shard * kEvalStride + tid);
+      __syncthreads();
+      publish_row_tagged(out_rows + static_cast<size_t>(shard) * kPubWords, lds, tid, expect);
+    }
+    __syncthreads();  // s_mode / s_last / lds are rewritten by the next round
+    expect++;
+  }
+}
+
 }  // namespace
 
 hipError_t launch_knn_covariances(const PointIndex& ix, int k, double gicp_epsilon, double* cov6, int* nn_idx, float* nn_d2,
@@ -501,6 +634,17 @@ hipError_t launch_functor(int mode, const float4* output, int n, const float4* t
   else
     hipLaunchKernelGGL(k_functor<1>, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9, P, partials, counter,
                        out_row, seq);
+  return hipGetLastError();
+}
+
+int server_blocks(int n) { return max(1, min(512, (n + kBlock - 1) / kBlock)); }
+
+hipError_t launch_server(const float4* output, int n, const float4* tgt, const int* corr, const float* maha9, void* mailbox,
+                         int n_blocks, double* partials, unsigned* counter, double* out_rows, unsigned long long first_seq,
+                         unsigned long long idle_ticks, hipStream_t stream) {
+  if (ndt::server_mailbox_bytes() != sizeof(GicpMailbox)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_gicp_server, dim3(n_blocks), dim3(kBlock), 0, stream, output, n, tgt, corr, maha9,
+                     static_cast<GicpMailbox*>(mailbox), partials, counter, out_rows, first_seq, idle_ticks);
   return hipGetLastError();
 }
 

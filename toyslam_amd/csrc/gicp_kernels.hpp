@@ -39,4 +39,13 @@ hipError_t launch_functor(int mode, const float4* output, int n, const float4* t
                           const float* T12, int n_blocks, double* partials, unsigned* counter, double* out_row,
                           unsigned long long seq, hipStream_t stream);
 
+// Persistent objective server (one launch per BFGS run), see gicp_kernels.hip.  mailbox: 256 + 128 bytes of fine-grained
+// device memory laid out like the NDT server's (the host posts with ndt::server_post: kind = functor mode 0 / 1 / 3, or
+// ndt::kServerCmdExit); counter: kGicpServerParts * 32 zeroed u32; out_rows: kGicpServerParts tagged rows of pinned host memory.
+constexpr int kGicpServerParts = 8;
+int server_blocks(int n);
+hipError_t launch_server(const float4* output, int n, const float4* tgt, const int* corr, const float* maha9, void* mailbox,
+                         int n_blocks, double* partials, unsigned* counter, double* out_rows, unsigned long long first_seq,
+                         unsigned long long idle_ticks, hipStream_t stream);
+
 }  // namespace gicp
