@@ -336,3 +336,20 @@ def test_objective_server_survives_a_quiet_host_and_can_be_switched_off(pair):
         assert out.returncode == 0, out.stderr[-2000:]
         results[name] = json.loads(out.stdout.strip().splitlines()[-1])
     assert results["stall"] == results["default"] == results["launches"]
+
+
+def test_align_with_the_aligned_cloud_does_not_wait_for_the_server(gmod, pair):
+    """regression: the objective server is told to exit before the aligned cloud is produced and waited for -- otherwise every
+    registration sits out the server's 20 ms patience (seen as 80 ms per align in apps/align.cpp)."""
+    import time
+    t, s = pair
+    g = gmod.GeneralizedIterativeClosestPoint()
+    g.setInputTarget(t)
+    g.setInputSource(s)
+    g.align(want_cloud=True)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        g.align(want_cloud=True)
+        times.append(time.perf_counter() - t0)
+    assert np.median(times) < 0.010, times

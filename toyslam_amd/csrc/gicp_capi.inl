@@ -454,6 +454,7 @@ ndt_status gicp_align(gicp_handle h, const float* guess, float* final_T, int* co
   h->step_ready = false;
   GicpDevice dev(h);
   const gicp::Result r = gicp::run(h->prm, h->guess_rm, dev);
+  dev.server_stop();  // before anything else is queued on the stream or waited for: the server would sit out its patience
   if (r.backend_failed || !dev.error.empty()) return fail(NDT_ERR_HIP, dev.error.empty() ? "device failure" : dev.error);
   colmajor_from_rowmajor(r.final_T, h->final_T);
   h->converged = r.converged ? 1 : 0;
