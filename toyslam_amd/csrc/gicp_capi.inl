@@ -36,6 +36,8 @@ struct gicp_context {
   double* srv_rows = nullptr;
   DevBuf<unsigned> srv_counter;
   int srv_blocks = 0;
+  bool src_cov_pending = false;
+  hipEvent_t ev_src = nullptr;  // the source's covariance pass (on the source index's stream) -> the main stream
   size_t out_pinned_bytes = 0;
   unsigned long long seq = 0;
   float guess_rm[16];          // guess of the current align / step, row-major
@@ -54,6 +56,7 @@ struct gicp_context {
     counter.release(); out_cloud.release(); nn_idx.release(); nn_d2.release();
     if (host_pub) (void)hipHostFree(host_pub);
     if (out_pinned) (void)hipHostFree(out_pinned);
+    if (ev_src) (void)hipEventDestroy(ev_src);
     if (srv_mbs) (void)hipFree(srv_mbs);
     if (srv_rows) (void)hipHostFree(srv_rows);
     srv_counter.release();
@@ -174,9 +177,25 @@ ndt_status gicp_cloud_covariances(gicp_context* h, int which, bool want_neighbor
     HIP_TRY(h->nn_idx.reserve(n * static_cast<size_t>(k)));
     HIP_TRY(h->nn_d2.reserve(n * static_cast<size_t>(k)));
   }
+  // the source's pass runs on the source index's own stream, next to the target's (two independent kernels of a few
+  // thousand waves each); everything that follows on the main stream waits for it through an event
+  hipStream_t st = (which == 1) ? h->src.stream : h->tgt.stream;
   HIP_TRY(gicp::launch_knn_covariances(gicp_index_of(c), k, h->prm.gicp_epsilon, cov.p, want_neighbors ? h->nn_idx.p : nullptr,
-                                       want_neighbors ? h->nn_d2.p : nullptr, h->tgt.stream));
+                                       want_neighbors ? h->nn_d2.p : nullptr, st));
+  if (which == 1) {
+    if (!h->ev_src) HIP_TRY(hipEventCreateWithFlags(&h->ev_src, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_src, h->src.stream));
+    h->src_cov_pending = true;  // gicp_join_source makes the main stream wait -- after the target's pass has been queued
+  }
   have = true;
+  return NDT_OK;
+}
+
+ndt_status gicp_join_source(gicp_context* h) {
+  if (h->src_cov_pending) {
+    HIP_TRY(hipStreamWaitEvent(h->tgt.stream, h->ev_src, 0));
+    h->src_cov_pending = false;
+  }
   return NDT_OK;
 }
 
@@ -184,9 +203,11 @@ ndt_status gicp_cloud_covariances(gicp_context* h, int which, bool want_neighbor
 ndt_status gicp_prepare(gicp_context* h, const float* guess_cm) {
   ndt_status s = gicp_ready(h);
   if (s) return s;
+  s = gicp_cloud_covariances(h, 1, false);  // (source first: it runs on its own stream while the target's is queued here)
+  if (s) return s;
   s = gicp_cloud_covariances(h, 0, false);
   if (s) return s;
-  s = gicp_cloud_covariances(h, 1, false);
+  s = gicp_join_source(h);
   if (s) return s;
   const size_t n = h->src.target->n;
   rowmajor_from_colmajor(guess_cm, h->guess_rm);
@@ -517,6 +538,8 @@ ndt_status gicp_covariances(gicp_handle h, int which, double* cov, int* nn_idx, 
   if (s) return s;
   const bool want_nn = nn_idx && nn_d2;
   s = gicp_cloud_covariances(h, which, want_nn);
+  if (s) return s;
+  s = gicp_join_source(h);
   if (s) return s;
   ndt_context* c = which == 0 ? &h->tgt : &h->src;
   const size_t n = c->target->n;
