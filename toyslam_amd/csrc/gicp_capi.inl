@@ -37,6 +37,8 @@ struct gicp_context {
   DevBuf<unsigned> srv_counter;
   int srv_blocks = 0;
   bool src_cov_pending = false;
+  float hint_leaf[2] = {0.f, 0.f};  // index leaf the previous target / source ended up with, and its size
+  size_t hint_n[2] = {0, 0};
   hipEvent_t ev_src = nullptr;  // the source's covariance pass (on the source index's stream) -> the main stream
   size_t out_pinned_bytes = 0;
   unsigned long long seq = 0;
@@ -73,7 +75,7 @@ constexpr long long kGicpMaxCells = 1ll << 26;       // dense cell table budget 
 // Builds the voxel index of a host cloud on `c`: finite check, upload, leaf size from the cloud's own
 // density (volume guess first, then corrected once from the measured points per occupied cell --
 // scans are surfaces, so occupancy grows with the square of the leaf).
-ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t stride) {
+ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t stride, float* hint_leaf, size_t* hint_n) {
   if (!pts || n == 0) return fail(NDT_ERR_INVALID, "invalid or empty point cloud dataset given");
   if (stride < 12 || stride % 4) return fail(NDT_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
@@ -111,6 +113,9 @@ ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t st
     return static_cast<float>(leaf);
   };
   float leaf = clamp_leaf(std::cbrt(vol * kGicpPointsPerCell / static_cast<double>(n)));
+  // consecutive scans of a sequence have about the same density: start from the leaf the previous cloud of about this size
+  // ended up with (usually right at once; the search results do not depend on the leaf, only the time does)
+  if (*hint_leaf > 0 && n >= *hint_n - *hint_n / 4 && n <= *hint_n + *hint_n / 4) leaf = clamp_leaf(*hint_leaf);
   for (int pass = 0; pass < 4; pass++) {
     c->resolution = leaf;
     s = build_grid(c);
@@ -127,6 +132,8 @@ ndt_status gicp_build_index(ndt_context* c, const void* pts, size_t n, size_t st
   if (std::getenv("NDT_GICP_DEBUG"))
     std::fprintf(stderr, "[gicp index] n=%zu leaf=%.4f cells=%lld (%d x %d x %d) occupied=%zu\n", n, static_cast<double>(leaf),
                  c->grid->geom.n_cells, c->grid->geom.div_b[0], c->grid->geom.div_b[1], c->grid->geom.div_b[2], c->grid->n_leaves);
+  *hint_leaf = leaf;
+  *hint_n = n;
   return ensure_cell2leaf(c, c->grid.get());
 }
 
@@ -446,7 +453,7 @@ ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_
     HIP_TRY(hipSetDevice(h->tgt.device));
     HIP_TRY(hipStreamSynchronize(h->tgt.stream));
   }
-  const ndt_status s = gicp_build_index(&h->tgt, pts, n, stride_bytes);
+  const ndt_status s = gicp_build_index(&h->tgt, pts, n, stride_bytes, &h->hint_leaf[0], &h->hint_n[0]);
   if (s) return s;
   h->have_tgt = true;
   return NDT_OK;
@@ -461,7 +468,7 @@ ndt_status gicp_set_input_source(gicp_handle h, const void* pts, size_t n, size_
     HIP_TRY(hipSetDevice(h->tgt.device));
     HIP_TRY(hipStreamSynchronize(h->tgt.stream));
   }
-  const ndt_status s = gicp_build_index(&h->src, pts, n, stride_bytes);
+  const ndt_status s = gicp_build_index(&h->src, pts, n, stride_bytes, &h->hint_leaf[1], &h->hint_n[1]);
   if (s) return s;
   HIP_TRY(hipStreamSynchronize(h->src.stream));  // the index is read from tgt's stream from here on
   h->have_src = true;
