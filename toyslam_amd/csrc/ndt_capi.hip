@@ -945,7 +945,8 @@ ndt_status server_start(ndt_context* h) {
   HIP_TRY(h->server_counter.reserve(32 * (1 + ndt::kServerParts)));  // one shard counter per 128-B line
   HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * (1 + ndt::kServerParts) * sizeof(unsigned), h->stream));
   // one 512-thread block per CU at most: every block must be resident for the round to complete
-  int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + 511) / 512));
+  const int ppb = ndt::points_per_block(n);
+  int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + ppb - 1) / ppb));
   h->server_blocks = nblk;
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
@@ -2102,7 +2103,8 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   {  // device-side stamps of the LAST round (with Hessian), s_memrealtime ticks of 10 ns
     std::vector<unsigned long long> d(8 + 10 * 1024);
     HIP_TRY(hipMemcpy(d.data(), h->server_dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (h->source->k2_n() + 511) / 512));
+    const int ppb_diag = ndt::points_per_block(h->source->k2_n());
+    const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (h->source->k2_n() + ppb_diag - 1) / ppb_diag));
     unsigned long long got_min = ~0ull, got_max = 0, tk_min = ~0ull, tk_max = 0;
     for (int b = 0; b < nblk; b++) {
       got_min = std::min(got_min, d[8 + 2 * b]); got_max = std::max(got_max, d[8 + 2 * b]);

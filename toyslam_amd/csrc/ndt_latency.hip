@@ -28,7 +28,7 @@ namespace {
 template <int NNB, bool WANT_H, int TPB>
 __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                            double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                           double* __restrict__ out_row, unsigned long long seq) {
+                                                           double* __restrict__ out_row, unsigned long long seq, int ppb) {
   constexpr int kWaves = TPB / kWave, kParts = TPB / kEvalStride;
   __shared__ double lds[kWaves * 32];
   __shared__ double lds2[kParts * kEvalStride];
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
   // XCD-aware first tile (see xcd_chunk); larger scans continue grid-strided, which balances uneven
   // neighbour counts better than one contiguous range per block (measured: -8 % at 2M points)
-  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x, gridDim.x * TPB, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, xcd_chunk(blockIdx.x, gridDim.x) * TPB + threadIdx.x, gridDim.x * TPB, acc);
+  // ppb points per block (points_per_block(n)): small scans use only the first ppb lanes of a block, see there
+  const int first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, first, gridDim.x * ppb, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, first, gridDim.x * ppb, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
                                                             unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                                                             int param_pad, const float4* __restrict__ out_src,
                                                             float4* __restrict__ out_dst, int out_n, unsigned long long* dbg,
-                                                            int direct, float4* __restrict__ out_host) {
+                                                            int direct, float4* __restrict__ out_host, int ppb) {
   constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
   __shared__ double lds[kWaves * 32];
   __shared__ EvalParams sP;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   __shared__ int s_last;
   unsigned long long expect = first_seq;
   // this lane's first point of every round (see derivatives_body PRELOADED)
-  const int my_first = xcd_chunk(blockIdx.x, gridDim.x) * kServerTPB + static_cast<int>(threadIdx.x);
+  const int my_first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
   float4 my_pt = make_float4(0.f, 0.f, 0.f, 0.f);
   if (my_first < n) my_pt = src[my_first];
   unsigned terms_lo = 0, terms_hi = 0;  // this thread's row of kAngleTerms (threads 0..68 build the angle tables)
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
     // XCD-aware first tile (see xcd_chunk); larger scans continue grid-strided (better balance)
-    const int first = xcd_chunk(blockIdx.x, gridDim.x) * kServerTPB + tid, stride = gridDim.x * kServerTPB;
+    const int first = (tid < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + tid : n, stride = gridDim.x * ppb;
     const int limit = n;
     if (kind == 2) {
       // rare round (at most one per Newton iteration): keep its loop invariants from being hoisted
@@ -411,9 +413,19 @@ static int env_int(const char* name, int dflt) {
 }  // namespace
 
 constexpr int kFusedTPB = 512;
+// Points a block of the latency kernels works on.  A 512-thread block is eight waves, two per SIMD, and the body is
+// VALU-issue-bound: two waves on a SIMD take ~4.4 us where one takes ~2.9.  A scan small enough to leave most of the
+// chip empty anyway (the mapping nodes' real size: 16 k points = 32 full blocks on 256 CUs) therefore fills only the
+// first half of each block's lanes -- twice the blocks, every busy wave with a SIMD of its own.
+int points_per_block(int n) {
+  static const int forced = env_int("NDT_K2_PPB", 0);
+  if (forced == 256 || forced == 512) return forced;
+  return (n <= 65536) ? 256 : 512;
+}
 int fused_blocks(int n) {
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
-  size_t b = (static_cast<size_t>(n) + kFusedTPB - 1) / kFusedTPB;
+  const int ppb = points_per_block(n);
+  size_t b = (static_cast<size_t>(n) + ppb - 1) / ppb;
   if (b < 1) b = 1;
   if (b > static_cast<size_t>(cap)) b = cap;
   return static_cast<int>(b);
@@ -424,7 +436,7 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
                                     unsigned long long seq, hipStream_t stream) {
 #define NDT_LAUNCH_FUSED(NNB, H)                                                                                        \
   hipLaunchKernelGGL((k_derivatives_fused<NNB, H, kFusedTPB>), dim3(n_blocks), dim3(kFusedTPB), 0, stream, src, n, gv, P, \
-                     partials, counter, out_row, seq)
+                     partials, counter, out_row, seq, points_per_block(n))
   if (search == 0) {
     if (want_hessian) NDT_LAUNCH_FUSED(27, true); else NDT_LAUNCH_FUSED(27, false);
   } else if (search == 1) {
@@ -475,20 +487,21 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
                               unsigned long long* dbg, int direct, float4* out_host) {
+  const int ppb = points_per_block(n);
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 0)
     hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
   else if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
   else if (search == 3)
     hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
   else
     hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
   return hipGetLastError();
 }
 
