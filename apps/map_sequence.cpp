@@ -6,10 +6,16 @@
 // accumulate the global map (update_global_map :195-211).  What the node publishes as ROS messages is printed.
 // Scans are read ahead in the background while the GPU works on the previous one.
 //
-//   map_sequence <pcd_directory> [voxel_leaf_size (0.5)] [global_map_out.pcd]
+// With a fourth argument "rosbag" the loop is the other mapping node's (lidar_subscriber/src/ndt_rosbag_mapping_node.cpp:46-75,
+// with the scans of the directory standing in for the bag's messages): leaf 0.3 (:87), every registration starts from
+// the previous one's result (pres_transform, :63,127), its fitness score is printed (:130), a registration that did not
+// converge counts as identity (:137-140), and pose, trajectory and global map are updated after every scan (:64-68).
+//
+//   map_sequence <pcd_directory> [voxel_leaf_size (0.5 | 0.3)] [global_map_out.pcd | -] [rosbag]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ndt_mi355.h"
@@ -36,7 +42,8 @@ int main(int argc, char** argv) {
     std::printf("usage: map_sequence <pcd_directory> [voxel_leaf_size] [global_map_out.pcd]\n");
     return 0;
   }
-  const float voxel_leaf_size = argc > 2 ? static_cast<float>(std::atof(argv[2])) : 0.5f;  // :44
+  const bool rosbag = argc > 4 && std::strcmp(argv[4], "rosbag") == 0;
+  const float voxel_leaf_size = argc > 2 ? static_cast<float>(std::atof(argv[2])) : (rosbag ? 0.3f : 0.5f);  // :44 / rosbag :87
   ndt_handle h = nullptr;
   CHECK(ndt_create(0, &h));
   CHECK(ndt_set_resolution(h, 1.0f));  // initialize_parameters / initialize_ndt, :37-62
@@ -52,6 +59,7 @@ int main(int argc, char** argv) {
   const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<Pt> previous, current;      // clouds_[current_index_ - 1], clouds_[current_index_]
   std::vector<std::vector<float>> trajectory;  // trajectory_
+  std::vector<float> pose(identity, identity + 16), pres_transform(identity, identity + 16);  // rosbag node :33,95
   size_t loaded = 0;                      // clouds_.size()
   size_t registered = 0, not_converged = 0;
   double t_filter = 0, t_align = 0, t_map = 0;
@@ -99,10 +107,25 @@ int main(int argc, char** argv) {
         float T[16];
         int converged = 0, iterations = 0;
         double probability = 0;
-        CHECK(ndt_align(h, nullptr, T, &converged, &iterations, &probability, nullptr, 0));
+        CHECK(ndt_align(h, rosbag ? pres_transform.data() : nullptr, T, &converged, &iterations, &probability, nullptr, 0));
         t_align += since(t0);
         registered++;
-        if (converged) {
+        if (rosbag) {  // perform_registration :119-141, then :63-68
+          double fitness = 0;
+          CHECK(ndt_get_fitness_score(h, 1.7976931348623157e308, &fitness));
+          std::printf("fitness: %.9g (%d iterations%s)\n", fitness, iterations, converged ? "" : ", not converged");
+          if (!converged) {
+            not_converged++;
+            for (int i = 0; i < 16; i++) T[i] = identity[i];
+          }
+          pres_transform.assign(T, T + 16);
+          ndt_host_chain_pose(pose.data(), T, pose.data());
+          trajectory.push_back(pose);
+          t0 = clock::now();
+          int overflowed = 0;
+          CHECK(ndt_map_update(h, current.data(), current.size(), sizeof(Pt), 1, pose.data(), 0.5f, &overflowed));  // map_voxel, :88
+          t_map += since(t0);
+        } else if (converged) {
           char title[96];
           std::snprintf(title, sizeof(title), "Transform %zu to %zu: (%d iterations)", loaded - 2, loaded - 1, iterations);
           print_matrix(title, T);
@@ -131,7 +154,7 @@ int main(int argc, char** argv) {
   }
   std::printf("time: total %.2f ms  (prefilter %.2f, set inputs + align %.2f, map update %.2f; file reading overlapped)\n",
               since(t_begin), t_filter, t_align, t_map);
-  if (argc > 3 && map_points) {
+  if (argc > 3 && std::strcmp(argv[3], "-") != 0 && map_points) {
     std::vector<Pt> map(map_points);
     CHECK(ndt_map_get(h, map.data(), sizeof(Pt)));
     CHECK(ndt_pcd_write_xyz(argv[3], map.data(), map.size(), sizeof(Pt), 1));

@@ -189,3 +189,25 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
     got_map, _ = ndt.pcd_read_xyz(map_out)
     assert abs(len(got_map) - len(ref_map)) <= 0.005 * len(ref_map)  # poses differ in the last bits: a few voxels may flip
     assert "global map %d points" % len(got_map) in out
+
+    # the rosbag node's loop (ndt_rosbag_mapping_node.cpp:46-75,119-141) over the same scans: leaf 0.3, every registration
+    # starts from the previous result, fitness printed, pose / trajectory / map updated after every scan
+    from scipy.spatial import cKDTree
+    out = subprocess.check_output([exe, str(d), "0.3", "-", "rosbag"], text=True)
+    lines = out.splitlines()
+    traj = [np.array([[float(x) for x in lines[i + 1 + r].split()] for r in range(4)]) for i, ln in enumerate(lines) if ln.startswith("trajectory[")]
+    fit = [float(ln.split()[1]) for ln in lines if ln.startswith("fitness:")]
+    assert len(traj) == 3 and len(fit) == 3 and "registrations 3 (not converged 0)" in out
+    filt = [po.voxel_grid_filter(sc, 0.3)[0] for sc in scans]
+    pose, pres = np.eye(4, dtype=np.float32), None
+    for k in range(1, 4):
+        o = po.OracleNDT(resolution=1.0, step_size=0.1, trans_eps=0.01, max_iter=64, num_threads=8)
+        o.set_target(filt[k - 1])
+        o.set_source(filt[k])
+        r = o.align(guess=pres, want_cloud=True)
+        assert r["converged"]
+        d2 = cKDTree(filt[k - 1].astype(np.float64)).query(r["cloud"][:, :3].astype(np.float64))[0] ** 2
+        assert abs(fit[k - 1] - d2.mean()) <= 1e-3 * d2.mean(), (k, fit[k - 1], d2.mean())
+        pres = r["T"]
+        pose = ndt.host_chain_pose(pose, r["T"])
+        assert rot_err(traj[k - 1], pose) < 2e-4 and trans_err(traj[k - 1], pose) < 2e-3, k
