@@ -306,6 +306,31 @@ def main():
                     "what": "dense voxel lookup, per-thread accumulators instead of per-point result arrays, point "
                             "derivatives once per point, parallel f64 Hessian",
                     "speedup_of_gpu": value * med_o}
+        if args.workload == "batch":
+            # ---- roofline leg of the lock-step batch: one pass of the same step with a HIP event pair on the library's
+            # stream around the derivative kernels of every lock-step (ndt_profile_enable(1)); the algorithmic bytes are
+            # 8(d)'s per-evaluation figure x the scan evaluations those kernels served ----
+            reg.profile(1)
+            reg.profile_read(0)
+            step()
+            n_steps_timed, ms = reg.profile_read(0)
+            reg.profile(0)
+            stb = reg.stats()
+            n_scan_evals = stb["n_evals"] + stb["n_hessian_recomputes"]
+            bytes_total = n_scan_evals * algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"])
+            achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["scan_evaluations_per_step"] = n_scan_evals
+            out["mean_neighbors"] = stb["mean_neighbors"]
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_derivatives<DIRECT7> / k_batch_step (one launch per lock-step over every live scan; "
+                                         "+ k_hessian64 where a scan's line search iterated)",
+                               "avg_kernel_us": ms * 1e3 / max(n_steps_timed, 1), "launches_timed": n_steps_timed,
+                               "scan_evaluations": n_scan_evals,
+                               "algorithmic_bytes_per_scan_evaluation": algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"]),
+                               "kernel_time_share_of_step": ms / (dt / args.steps * 1e3),
+                               "how": "one hipEvent pair per lock-step on the library stream around the derivative kernels "
+                                      "(ndt_profile_enable(1)), one extra pass of the same step"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

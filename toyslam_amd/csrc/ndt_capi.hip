@@ -1810,6 +1810,10 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   static const bool batch_timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   double t_fill = 0, t_gpu = 0, t_feed = 0;
   int n_steps = 0;
+  // ndt_get_stats after a batch: scan evaluations (f32 kinds) / f64 Hessian recomputes of all scans, neighbours per point
+  std::vector<double> nn_row(n_scans, 0.0);
+  double nn_sum = 0, pts_sum = 0;
+  long long evals_f32 = 0, evals_h64 = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   for (;;) {
@@ -1854,6 +1858,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       const int* d_active = reinterpret_cast<const int*>(h->descs.p + n_scans);
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
+      if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
       if (mixed) {
         HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * n_scans, n_live, max_blocks, nblk_kind[0], h->partials.p, h->stream));
       } else {
@@ -1861,6 +1866,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
         if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + n_scans, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
         if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * n_scans, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
       }
+      if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
       if (h->allreduce) {
         HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
         if (h->allreduce_on_device) {
@@ -1900,12 +1906,29 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       }
     }
     const auto tb2 = now();
+    if (h->profiling && !degenerate) {  // ndt_profile_enable(h, 1): the derivative kernels of this lock-step (slot 0)
+      float ms = 0;
+      HIP_TRY(hipEventSynchronize(h->ev_b));
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+      h->prof_n[0]++;
+      h->prof_ms[0] += ms;
+    }
     pool.run(n_scans, [&](size_t k) {  // Newton / More-Thuente step of every live scan
       if (descs[k].kind == ndt::EVAL_NONE) return;
       ndt::EvalResult r;
-      unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, nullptr);
+      unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, &nn_row[k]);
       solvers[k].feed(r);
     });
+    for (size_t k = 0; k < n_scans; k++) {
+      if (descs[k].kind == ndt::EVAL_NONE) continue;
+      if (descs[k].kind == ndt::EVAL_HESSIAN_F64) {
+        evals_h64++;
+      } else {
+        evals_f32++;
+        nn_sum += nn_row[k];
+        pts_sum += static_cast<double>(offsets[k + 1] - offsets[k]);
+      }
+    }
     const auto tb3 = now();
     static const bool step_dump = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) >= 2; }();
     if (step_dump) std::fprintf(stderr, "[step %d] act H=%d noH=%d h64=%d blocks/scan=%d/%d/%d gpu=%.1fus\n", n_steps, n_act[0], n_act[1], n_act[2], nblk_kind[0], nblk_kind[1], nblk_kind[2], secs(tb1, tb2) * 1e6);
@@ -1917,6 +1940,9 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   if (batch_timing)
     std::fprintf(stderr, "[ndt batch timing] scans=%zu steps=%d fill=%.1fus gpu(launch+wait)=%.1fus feed=%.1fus per step\n", n_scans,
                  n_steps, t_fill / std::max(1, n_steps) * 1e6, t_gpu / std::max(1, n_steps) * 1e6, t_feed / std::max(1, n_steps) * 1e6);
+  h->n_evals = static_cast<int>(std::min<long long>(evals_f32, INT32_MAX));
+  h->n_hess = static_cast<int>(std::min<long long>(evals_h64, INT32_MAX));
+  h->mean_neighbors = pts_sum > 0 ? nn_sum / pts_sum : 0.0;
   for (size_t k = 0; k < n_scans; k++) {
     if (final_T) std::memcpy(final_T + 16 * k, solvers[k].final_T, 16 * sizeof(float));
     if (conv) conv[k] = solvers[k].converged ? 1 : 0;
