@@ -321,8 +321,16 @@ def main():
             achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out["scan_evaluations_per_step"] = n_scan_evals
             out["mean_neighbors"] = stb["mean_neighbors"]
+            traffic, traffic_src = None, None   # HBM bytes per lock-step from the committed PMC passes of the 64-scan command
+            try:
+                if args.batch == 64 and args.set == "U":
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_batch64_summary.json")))["derivative_kernels_hbm_bytes_per_lock_step"]
+                    traffic_src = "profiles/r01_batch64_summary.json (tools/profile_batch.sh)"
+            except Exception:
+                pass
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": bytes_total / max(n_steps_timed, 1),
                                "kernel": "k_derivatives<DIRECT7> / k_batch_step (one launch per lock-step over every live scan; "
                                          "+ k_hessian64 where a scan's line search iterated)",
                                "avg_kernel_us": ms * 1e3 / max(n_steps_timed, 1), "launches_timed": n_steps_timed,
