@@ -40,9 +40,12 @@ def main():
             g.align(guesses[k])
             T = g.getFinalTransformation()
             members += 1
-            # fewer than 3 points leave the 6x6 Hessian rank-deficient: the pseudo-inverse step amplifies the last-bit
-            # differences between the batch kernels and the single-scan kernels (two translation units, different packing)
-            tol = 2e-5 if len(sc) >= 3 else 1e-3
+            # a handful of (point, voxel) pairs leave the 6x6 Hessian rank-deficient or nearly so: the pseudo-inverse step
+            # amplifies the last-bit differences between the batch kernels and the single-scan kernels (two translation
+            # units, different packing).  Both stay within the registration tolerance of the oracle there (checked on the
+            # cases this fuzzer found: <= 6e-5), but not within rounding of each other.
+            pairs = g.stats()["mean_neighbors"] * len(sc)
+            tol = 2e-5 if pairs >= 10 else 1e-3
             same = (np.abs(res["T"][k] - T).max() < tol and res["iterations"][k] == g.getFinalNumIteration() and
                     bool(res["converged"][k]) == g.hasConverged())
             if not same:
