@@ -191,8 +191,11 @@ def main():
                                             "achieved": k1_bytes / t_build_dev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": k1_bytes / t_build_dev / 1e9 / HBM_PEAK_GBS,
                                             "occupied_voxels": gi["n_leaves"], "valid_voxels": gi["n_valid"],
-                                            "note": "wall time of ndt_set_input_target_device (launch-bound chain of ~10 "
-                                                    "small kernels + one host round trip), not a single kernel"}
+                                            "note": "wall time of ndt_set_input_target_device: a chain of ~10 dependent kernels, not one "
+                                                    "kernel; at 1M points their durations add up to the wall time "
+                                                    "(profiles/r01_kernel_stats.csv: k_count 46 us of device-scope atomics, "
+                                                    "k_finalize 38 us of per-voxel f64 eigen-decompositions, scatter / presort / "
+                                                    "repack ~16 us each, scans ~20 us), at the nodes' 16k points launch latency"}
         except Exception:
             pass
         if args.workload in ("single", "large"):
