@@ -541,6 +541,43 @@ def test_batch_equals_individual(mods, pair):
         assert rot_err(res["T"][k], ro["T"]) < ROT_TOL and trans_err(res["T"][k], ro["T"]) < TRANS_TOL
 
 
+def test_batch_stats_and_step_profile(mods, pair):
+    """What bench.py's batch roofline is computed from: after ndt_align_batch, ndt_get_stats counts the scan evaluations of all
+    members (the sum of what each member needs alone) and their mean neighbour count; with ndt_profile_enable(1) every lock-step's
+    derivative kernels are bracketed by one HIP event pair (slot 0) -- and timing them changes no result."""
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(14)
+    scans = [clouds.apply_T(np.linalg.inv(clouds.random_T(rng, 0.2, 0.5)), s[k::4].copy()) for k in range(4)]
+    g = ndt.NormalDistributionsTransform()
+    g.setTransformationEpsilon(0.01)
+    g.setMaximumIterations(40)
+    g.setInputTarget(t)
+    res = g.alignBatch(scans)
+    st = g.stats()
+    alone_evals = alone_hess = 0
+    longest = 0
+    for k in range(4):
+        g.setInputSource(scans[k])
+        g.align()
+        assert g.getFinalNumIteration() == res["iterations"][k]
+        sk = g.stats()
+        alone_evals += sk["n_evals"]
+        alone_hess += sk["n_hessian_recomputes"]
+        longest = max(longest, sk["n_evals"] + sk["n_hessian_recomputes"])
+    g.alignBatch(scans)
+    st = g.stats()
+    assert st["n_evals"] == alone_evals and st["n_hessian_recomputes"] == alone_hess
+    assert 0.5 < st["mean_neighbors"] <= 7.0
+    g.profile(1)
+    g.profile_read(0)
+    res2 = g.alignBatch(scans)
+    n_steps, ms = g.profile_read(0)
+    g.profile(0)
+    assert n_steps == longest and ms > 0  # lock-step: as many steps as the member with the longest request sequence
+    assert np.array_equal(res2["T"], res["T"]) and np.array_equal(res2["iterations"], res["iterations"])
+
+
 # ------------------------------------------------------------------ BASELINE size
 def test_full_size_properties(mods):
     """config[1]: 100 k-pt source vs 1 M-pt target, 1.0 m voxels, 30 Newton passes (max_iter 28, eps 0).
