@@ -103,7 +103,9 @@ ndt_status ndt_get_result(ndt_handle h, float* final_transformation, int* has_co
 /* Device pointer (n_source x float4) of the last align's transformed source. */
 ndt_status ndt_get_output_device(ndt_handle h, const void** d_cloud, size_t* n);
 /* Work counters of the last align: derivative evaluations E, f64 Hessian
- * recomputes, mean valid neighbours per point (h-bar) of the last evaluation. */
+ * recomputes, mean valid neighbours per point (h-bar) of the last evaluation.
+ * After ndt_align_batch: the scan evaluations / f64 recomputes of all members
+ * together and h-bar over all of their evaluations. */
 ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hessian_recomputes, double* mean_neighbors);
 
 /* calculateScore(cloud), ndt_omp_impl.hpp:935-983 (cloud is used as given). */
@@ -229,7 +231,8 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
 
 /* Live kernel timing with HIP events recorded on the handle's own stream (bench.py's roofline leg).
  * on = 1: ndt_align runs one launch per evaluation and brackets each with an event pair; kind 0 =
- *         derivatives with Hessian, 1 = without, 2 = f64 Hessian.
+ *         derivatives with Hessian, 1 = without, 2 = f64 Hessian.  ndt_align_batch brackets the
+ *         derivative kernels of every lock-step with one pair: kind 0, n_launches = lock-steps.
  * on = 2: ndt_align keeps its persistent kernel (one launch per registration, the kernel of the
  *         timed region) and brackets that launch with one event pair; kind 3.
  * Off (0) by default: the event records cost host time. */
