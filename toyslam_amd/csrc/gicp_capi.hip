@@ -1,10 +1,11 @@
-// gicp_capi.inl -- C-ABI glue of the GICP row (include/gicp_mi355.h).  Textually part of ndt_capi.hip
-// (included at its end): it reuses that unit's device pool, cloud upload and K1 grid build -- the
+// gicp_capi.hip -- C-ABI glue of the GICP row (include/gicp_mi355.h).  It reuses the NDT units' device pool,
+// cloud upload and K1 grid build (ndt_internal.hpp) -- the
 // voxel index K1 produces over a cloud is the search structure of GICP's nearest-neighbour queries.
 //
 // A gicp_context owns two ndt_contexts used purely as index holders: `tgt` (the GICP target as its
 // target cloud + grid) and `src` (the GICP *source* as ITS target cloud + grid, for the source's own
 // k-NN covariances).  All GICP kernels run on tgt's stream.
+#include "ndt_internal.hpp"
 
 namespace {
 

@@ -1,0 +1,728 @@
+// ndt_grid.hip -- cloud upload, bounding boxes, spatial ordering of scans, the K1 target grid build (VoxelGridCovariance::filter), the N1 voxel
+// filter, the N2 map accumulation, getFitnessScore, calculateScore and the grid inspection entry points.
+// (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
+#include "ndt_internal.hpp"
+
+namespace ndtc {
+
+// upload + repack to dense float4
+ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
+                        std::shared_ptr<DeviceCloud>& out) {
+  if (n > 0 && !pts) return fail(NDT_ERR_INVALID, "null point buffer");
+  if (stride < 12 || stride % 4) return fail(NDT_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
+  if (n > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "too many points");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  auto c = std::make_shared<DeviceCloud>();
+  HIP_TRY(c->pts.reserve(n));
+  c->n = n;
+  if (n) {
+    const void* d_src = pts;
+    if (!on_device) {
+      HIP_TRY(h->staging.reserve(n * stride));
+      HIP_TRY(hipMemcpyAsync(h->staging.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+      d_src = h->staging.p;
+    }
+    // repack and bounding boxes in one pass; the per-block rows come back behind the synchronisation
+    // the upload needs anyway (the caller's buffer must be free to go when this returns)
+    const int nb = static_cast<int>(std::min<size_t>(1024, (n + 255) / 256));
+    if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
+    // the kernel stores its per-block rows straight into pinned host memory (no D2H copy to queue)
+    HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, c->pts.p, h->bbox_rows, nb, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const float* mm = h->bbox_rows;
+    for (int b = 0; b < nb; b++)
+      for (int v = 0; v < 2; v++)
+        for (int k = 0; k < 3; k++) {
+          c->bb_min[v][k] = std::min(c->bb_min[v][k], mm[b * 12 + v * 6 + k]);
+          c->bb_max[v][k] = std::max(c->bb_max[v][k], mm[b * 12 + v * 6 + 3 + k]);
+        }
+  }
+  out = c;
+  return NDT_OK;
+}
+
+// bounding box of a dense float4 device cloud: taken from the upload when the cloud came through
+// upload_cloud (no kernel, no wait), else computed here (one kernel + one host round trip)
+
+BBox bbox_of(const DeviceCloud& c, int dense) {
+  BBox b;
+  const int v = dense ? 0 : 1;
+  for (int k = 0; k < 3; k++) {
+    b.mn[k] = c.bb_min[v][k];
+    b.mx[k] = c.bb_max[v][k];
+  }
+  return b;
+}
+ndt_status bbox_compute(ndt_context* h, const float4* d_pts, int n, int dense, BBox& out) {
+  const int nb = std::min(1024, (n + 255) / 256);
+  DevBuf<float> d_mm;
+  HIP_TRY(d_mm.reserve(static_cast<size_t>(nb) * 6));
+  HIP_TRY(ndt::launch_bbox(d_pts, n, dense, d_mm.p, nb, h->stream));
+  std::vector<float> mm(static_cast<size_t>(nb) * 6);
+  HIP_TRY(hipMemcpyAsync(mm.data(), d_mm.p, mm.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 3; k++) {
+    out.mn[k] = FLT_MAX;
+    out.mx[k] = -FLT_MAX;
+  }
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) {
+      out.mn[k] = std::min(out.mn[k], mm[b * 6 + k]);
+      out.mx[k] = std::max(out.mx[k], mm[b * 6 + 3 + k]);
+    }
+  return NDT_OK;
+}
+
+// Spatial ordering of a source range: counting sort by the cell of a lattice of pitch ~resolution
+// laid over the range's own bounding box (x fastest), stable inside a cell.  Rigid transforms
+// preserve locality, so whatever the pose, consecutive lanes of the derivative kernels land in
+// the same or adjacent target voxels.  Only the order of the f64 summation changes.
+ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitch, float4* d_out, size_t* n_out,
+                       const BBox* known_bbox) {
+  *n_out = 0;
+  if (n == 0) return NDT_OK;
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(n);
+  BBox bb;
+  if (known_bbox) bb = *known_bbox;
+  else { ndt_status sb = bbox_compute(h, d_pts, ni, 0, bb); if (sb) return sb; }
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point
+  ndt::GridGeom geo{};
+  for (;; pitch *= 2.0f) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      geo.leaf[k] = pitch;
+      geo.inv_leaf[k] = 1.0f / pitch;
+      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+      cells *= geo.div_b[k];
+    }
+    if (cells <= 4.0e6) break;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(d_pts, ni, 0, geo, key.p, rank.p, cell_count.p, st));
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  // the leaf count stays on the device (the kernels read it there): leaf arrays are sized for the
+  // worst case and the host learns the totals once, at the end, instead of in the middle
+  const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));
+  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *n_out = tot[0];
+  return NDT_OK;
+}
+
+// All scans of a batch in ONE count/scan/scatter pass: a common lattice over the batch's bounding
+// box, composite key scan * n_cells + cell.  The ordered points of scan k end up contiguous at
+// scan_starts[k] (non-finite points are dropped, so the segments are compacted).
+ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(c->n);
+  c->scan_counts.assign(n_scans, 0);
+  c->scan_starts.assign(n_scans + 1, 0);
+  const BBox bb = bbox_of(*c, 0);  // from the upload
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;
+  ndt::GridGeom geo{};
+  for (float pitch = h->resolution;; pitch *= 2.0f) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      geo.leaf[k] = pitch;
+      geo.inv_leaf[k] = 1.0f / pitch;
+      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+      cells *= geo.div_b[k];
+    }
+    if (cells * static_cast<double>(n_scans) <= 32.0e6) break;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  const long long total_cells = geo.n_cells * static_cast<long long>(n_scans);
+  std::vector<int> off(n_scans + 1);
+  size_t max_scan = 0;
+  for (size_t k = 0; k <= n_scans; k++) off[k] = static_cast<int>(offsets[k] - offsets[0]);
+  for (size_t k = 0; k < n_scans; k++) max_scan = std::max(max_scan, offsets[k + 1] - offsets[k]);
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx, d_off;
+  HIP_TRY(d_off.reserve(n_scans + 1));
+  HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n_scans + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(total_cells) + 1));
+  HIP_TRY(key.reserve(c->n));
+  HIP_TRY(rank.reserve(c->n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, (static_cast<size_t>(total_cells) + 1) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count_batch(c->pts.p, d_off.p, static_cast<int>(n_scans), static_cast<int>(max_scan), geo, key.p, rank.p,
+                                  cell_count.p, st));
+  // one extra (always empty) cell at the end so that its start offset is the grand total
+  const long long scan_cells = total_cells + 1;
+  const int n_tiles = ndt::scan_tiles(scan_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));  // read after the final synchronise
+  const size_t n_leaves = std::min<size_t>(c->n, static_cast<size_t>(scan_cells));  // upper bound; the count stays on the device
+  HIP_TRY(lut.reserve(static_cast<size_t>(scan_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(c->n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  // start offset of every scan's first cell (+ the sentinel cell = grand total)
+  std::vector<unsigned> starts(n_scans + 1);
+  HIP_TRY(hipMemcpy2DAsync(starts.data(), sizeof(unsigned), cell_count.p, static_cast<size_t>(geo.n_cells) * sizeof(unsigned),
+                           sizeof(unsigned), n_scans + 1, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+  HIP_TRY(ndt::launch_sort_gather(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p, st, totals.p));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (size_t k = 0; k < n_scans; k++) {
+    c->scan_starts[k] = starts[k];
+    c->scan_counts[k] = starts[k + 1] - starts[k];
+  }
+  c->scan_starts[n_scans] = starts[n_scans];
+  c->n_sorted = tot[0];
+  return NDT_OK;
+}
+
+ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
+  // Spatial ordering pays for itself only on big scans (measured: 5-6 us per evaluation at 100k points
+  // against a 1M-point target, nothing at <= 60k points where the voxel records stay in L2 anyway,
+  // for 85-170 us of ordering work).  NDT_SORT_SOURCE=0 / 1 forces it off / on; a lock-step batch is
+  // always ordered (its points are concatenated scan by scan).
+  static const int mode = [] { const char* v = getenv("NDT_SORT_SOURCE"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+  constexpr size_t kOrderFrom = 65536;
+  c->n_sorted = 0;
+  const bool enabled = mode < 0 ? (offsets != nullptr || c->n >= kOrderFrom) : mode != 0;
+  if (!enabled || c->n == 0) return NDT_OK;
+  HIP_TRY(c->sorted.reserve(c->n));
+  if (!offsets) {
+    size_t got = 0;
+    const BBox bb = bbox_of(*c, 0);
+    ndt_status s = order_range(h, c->pts.p, c->n, h->resolution, c->sorted.p, &got, &bb);
+    if (s) return s;
+    c->n_sorted = got;
+  } else {
+    ndt_status s = order_batch(h, c, offsets, n_scans);
+    if (s) return s;
+  }
+  return NDT_OK;
+}
+
+// VoxelGridCovariance::filter(true) on the GPU.
+ndt_status build_grid(ndt_context* h) {
+  if (!h->target) return fail(NDT_ERR_NO_INPUT, "no target");
+  auto g = std::make_shared<DeviceGrid>();
+  g->target = h->target;
+  g->resolution = h->resolution;
+  g->min_pts = h->min_pts;
+  g->eig_ratio = h->eig_ratio;
+  const int n = static_cast<int>(h->target->n);
+  ndt::GridGeom& geo = g->geom;
+  for (int k = 0; k < 3; k++) {
+    geo.leaf[k] = h->resolution;
+    geo.inv_leaf[k] = 1.0f / h->resolution;  // [PCL] VoxelGrid::setLeafSize
+  }
+  if (n == 0) {
+    h->grid = g;
+    return NDT_OK;
+  }
+  hipStream_t st = h->stream;
+  // ---- bbox
+  const BBox bb = bbox_of(*h->target, h->target_dense);  // computed during the upload: no kernel, no wait
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
+  if (!(min_p[0] <= max_p[0])) {  // no finite point at all
+    h->grid = g;
+    return NDT_OK;
+  }
+  // ---- geometry, voxel_grid_covariance_omp_impl.hpp:75-103
+  long long d[3];
+  for (int k = 0; k < 3; k++) d[k] = static_cast<long long>((max_p[k] - min_p[k]) * geo.inv_leaf[k]) + 1;
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
+    h->grid = g;  // the reference warns and leaves an empty grid (:79-84)
+    return fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
+  }
+  for (int k = 0; k < 3; k++) {
+    geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+    geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+    geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  if (geo.n_cells <= 0 || geo.n_cells > static_cast<long long>(std::numeric_limits<int32_t>::max()))
+    return fail(NDT_ERR_GRID_OVERFLOW, "voxel grid too large");
+
+  // ---- count
+  DevBuf<unsigned> cell_count, block_sums, rank;
+  DevBuf<int> key;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(h->target->pts.p, n, h->target_dense, geo, key.p, rank.p, cell_count.p, st));
+  // ---- scan
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(g->counts.reserve(4));  // [points binned, occupied voxels, candidate voxels (>= min_pts), valid voxels]
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, g->counts.p, st));
+  // The counts stay on the device: the later kernels read the voxel count there, the arrays are sized
+  // for the worst case, and the host fetches the four numbers only if somebody asks (grid_counts()).
+  // Two host round trips (~30 us each) less per target; nothing below waits for the GPU.
+  const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
+  const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
+  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(g->leaf_cell.reserve(max_leaves));
+  HIP_TRY(g->leaf_start.reserve(max_leaves));
+  HIP_TRY(g->leaf_count.reserve(max_leaves));
+  HIP_TRY(g->leaf_rec.reserve(max_leaves));
+  HIP_TRY(g->sorted_idx.reserve(n));
+  HIP_TRY(g->recs.reserve(max_cand));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->lut.p, g->leaf_cell.p,
+                                 g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
+  // ---- scatter + finalize
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
+  HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, sizeof(unsigned), st));
+  ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  DevBuf<float4> big_pts;  // scratch of the crowded-leaf path (k_presort_large)
+  if (!h->index_only) {
+    HIP_TRY(big_pts.reserve(n));
+    HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
+                                 static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
+                                 g->lut.p, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
+  }
+  // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
+  // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
+  g->counts_known = false;
+  g->empty = false;
+  h->grid = g;
+  return NDT_OK;
+}
+
+// occupied / candidate / valid voxel counts of a built grid (fetched from the device on first use)
+ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
+  if (g->counts_known || g->empty) return NDT_OK;
+  unsigned c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(c, g->counts.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  g->n_sorted = c[0];
+  g->n_leaves = c[1];
+  g->n_cand = c[2];
+  g->n_valid = c[3];
+  g->counts_known = true;
+  return NDT_OK;
+}
+
+// cell -> occupied-cell ordinal table of a built grid (the nearest-neighbour searches walk it), built on first use
+ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g) {
+  std::lock_guard<std::mutex> lock(g->fit_mu);
+  if (!g->have_cell2leaf) {
+    HIP_TRY(g->cell_range.reserve(static_cast<size_t>(g->geom.n_cells)));
+    HIP_TRY(hipMemsetAsync(g->cell_range.p, 0, static_cast<size_t>(g->geom.n_cells) * sizeof(uint2), h->stream));
+    const size_t n_rows = static_cast<size_t>(g->geom.div_b[1]) * static_cast<size_t>(g->geom.div_b[2]);
+    HIP_TRY(g->row_any.reserve(n_rows));
+    HIP_TRY(hipMemsetAsync(g->row_any.p, 0, n_rows * sizeof(int), h->stream));
+    HIP_TRY(ndt::launch_cell_ranges(g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, static_cast<int>(g->n_leaves), g->cell_range.p,
+                                    g->geom.div_b[0], g->row_any.p, h->stream));
+    HIP_TRY(g->cell_pts.reserve(g->target->n));
+    HIP_TRY(ndt::launch_gather_points(g->target->pts.p, g->sorted_idx.p, g->counts.p, static_cast<int>(g->target->n), g->cell_pts.p,
+                                      h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    g->have_cell2leaf = true;
+  }
+  return NDT_OK;
+}
+// slack of the shell bound: the build-time and search-time cell indices of a coordinate can differ
+// at cell borders by rounding (SURVEY 8a trap 2) -- a few ulps of the largest coordinate
+float index_slack(const DeviceGrid* g) {
+  float max_abs = 0.f;
+  for (int k = 0; k < 3; k++)
+    max_abs = std::max(max_abs, std::max(std::fabs(g->geom.min_b[k] * g->geom.leaf[k]), std::fabs((g->geom.max_b[k] + 1) * g->geom.leaf[k])));
+  return 1e-3f * g->resolution + 4e-6f * max_abs;
+}
+// the search structure over a built grid's target (after ensure_cell2leaf + grid_counts)
+void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix) {
+  ix.pts = g->target->pts.p;
+  ix.n = static_cast<int>(g->target->n);
+  ix.geom = g->geom;
+  ix.cell_range = g->cell_range.p;
+  ix.row_any = g->row_any.p;
+  ix.sorted_idx = g->sorted_idx.p;
+  ix.sorted_pts = g->cell_pts.p;
+  ix.n_sorted = static_cast<int>(g->n_sorted);
+  ix.slack = index_slack(g);
+}
+// [PCL] Registration::getFitnessScore of the dense device cloud d_src moved by T against h's target
+ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness) {
+  *fitness = std::numeric_limits<double>::max();  // nr == 0 in the reference
+  DeviceGrid* g = h->grid.get();
+  ndt_status s = grid_counts(h, g);
+  if (s) return s;
+  if (n == 0 || g->empty || g->n_sorted == 0) return NDT_OK;
+  s = ensure_cell2leaf(h, g);
+  if (s) return s;
+  s = ensure_host_rows(h, 1);
+  if (s) return s;
+  float T12[12];
+  colmajor_to_T12(T_colmajor, T12);
+  const int nblk = std::max(1, std::min(2048, (n + 31) / 32));  // 32 query teams per block
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  ndt::PointIndex ix;
+  fill_point_index(g, ix);
+  HIP_TRY(ndt::launch_fitness(d_src, n, T12, ix, max_range, nblk, h->partials.p, h->stream));
+  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->host_result[1] > 0) *fitness = h->host_result[0] / h->host_result[1];
+  return NDT_OK;
+}
+
+// ---- N1: voxel-grid centroid down-sample -----------------------------------
+// [PCL] VoxelGrid::applyFilter on a dense float4 device cloud: d_out (capacity n) receives one centroid
+// per occupied voxel in ascending voxel-index order; *overflow = the leaf is too small for the
+// bounding box and, as PCL does, the input was copied through.  Synchronises h->stream.
+ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
+                                      size_t* n_out, bool* overflow, const BBox* known_bbox) {
+  *n_out = 0;
+  *overflow = false;
+  if (n == 0) return NDT_OK;
+  hipStream_t st = h->stream;
+  const int ni = static_cast<int>(n);
+  // bbox -> geometry, exactly as VoxelGrid::applyFilter
+  BBox bb;
+  if (known_bbox) bb = *known_bbox;
+  else { ndt_status sb = bbox_compute(h, d_in, ni, is_dense, bb); if (sb) return sb; }
+  const float* min_p = bb.mn;
+  const float* max_p = bb.mx;
+  if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point: empty output
+  ndt::GridGeom geo{};
+  long long d[3];
+  for (int k = 0; k < 3; k++) {
+    geo.leaf[k] = leaf;
+    geo.inv_leaf[k] = 1.0f / leaf;
+    d[k] = static_cast<long long>((max_p[k] - min_p[k]) * geo.inv_leaf[k]) + 1;
+  }
+  if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
+    HIP_TRY(hipMemcpyAsync(d_out, d_in, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_out = n;
+    *overflow = true;
+    return NDT_OK;
+  }
+  for (int k = 0; k < 3; k++) {
+    geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
+    geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
+    geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
+  }
+  geo.mul[0] = 1;
+  geo.mul[1] = geo.div_b[0];
+  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
+  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
+  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(key.reserve(n));
+  HIP_TRY(rank.reserve(n));
+  HIP_TRY(hipMemsetAsync(cell_count.p, 0, static_cast<size_t>(geo.n_cells) * sizeof(unsigned), st));
+  HIP_TRY(ndt::launch_count(d_in, ni, is_dense, geo, key.p, rank.p, cell_count.p, st));
+  const int n_tiles = ndt::scan_tiles(geo.n_cells);
+  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+  HIP_TRY(totals.reserve(4));
+  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
+  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+  const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));  // upper bound; the count stays on the device
+  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
+  HIP_TRY(leaf_cell.reserve(n_leaves));
+  HIP_TRY(leaf_start.reserve(n_leaves));
+  HIP_TRY(leaf_count.reserve(n_leaves));
+  HIP_TRY(leaf_rec.reserve(n_leaves));
+  HIP_TRY(sorted_idx.reserve(n));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+                                 leaf_count.p, leaf_rec.p, st));
+  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+  DevBuf<float4> big_pts;  // scratch of the crowded-voxel path (k_presort_large)
+  HIP_TRY(big_pts.reserve(n));
+  HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p, big_pts.p));
+  unsigned tot[3];
+  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
+  *n_out = tot[1];
+  return NDT_OK;
+}
+
+}  // namespace ndtc
+
+extern "C" {
+
+static ndt_status set_target_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, bool on_device) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  h->target = c;
+  h->target_dense = is_dense ? 1 : 0;
+  return build_grid(h);  // init(), ndt_omp.h:276-283
+}
+ndt_status ndt_set_input_target(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
+  return set_target_impl(h, pts, n, stride, is_dense, false);
+}
+ndt_status ndt_set_input_target_device(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
+  return set_target_impl(h, pts, n, stride, is_dense, true);
+}
+static ndt_status set_source_impl(ndt_handle h, const void* pts, size_t n, size_t stride, bool on_device) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  s = order_cloud(h, c.get(), nullptr, 0);
+  if (s) return s;
+  h->source = c;
+  return NDT_OK;
+}
+ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t stride) {
+  return set_source_impl(h, pts, n, stride, false);
+}
+ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, size_t stride) {
+  return set_source_impl(h, pts, n, stride, true);
+}
+
+ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride, double* score) {
+  if (!h || !score) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, cloud, n, stride, false, c);
+  if (s) return s;
+  if (n == 0 || h->grid->empty) {
+    *score = n ? 0.0 : std::numeric_limits<double>::quiet_NaN();  // 0/0 in the reference
+    return NDT_OK;
+  }
+  s = ensure_host_rows(h, 1);
+  if (s) return s;
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  const int nblk = ndt::derivative_blocks(static_cast<int>(n), NDT_DIRECT1);
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(hipMemsetAsync(h->partials.p, 0, static_cast<size_t>(nblk) * ndt::kEvalStride * sizeof(double), h->stream));
+  HIP_TRY(ndt::launch_calc_score(c->pts.p, static_cast<int>(n), h->grid->view(), gs.d1, gs.d2, gs.d3, h->search, kd_radius2(h->resolution), nblk,
+                                 h->partials.p, h->stream));
+  HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *score = h->host_result[0] / static_cast<double>(n);
+  return NDT_OK;
+}
+
+ndt_status ndt_get_fitness_score(ndt_handle h, double max_range, double* fitness) {
+  if (!h || !fitness) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  return fitness_impl(h, h->source->pts.p, static_cast<int>(h->source->n), h->final_T, max_range, fitness);
+}
+
+static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf,
+                                    bool on_device, void* out, size_t out_stride, size_t* n_out) {
+  if (!h || !n_out || (n && !out) || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n_out = 0;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  if (s) return s;
+  if (n == 0) return NDT_OK;
+  DevBuf<float4> d_out_tmp;
+  float4* d_out = on_device ? static_cast<float4*>(out) : nullptr;
+  if (!on_device) {
+    HIP_TRY(d_out_tmp.reserve(n));
+    d_out = d_out_tmp.p;
+  }
+  size_t n_written = 0;
+  bool overflow = false;
+  const BBox bb = bbox_of(*c, is_dense);
+  s = voxel_filter_device(h, c->pts.p, n, is_dense, leaf, d_out, &n_written, &overflow, &bb);
+  if (s) return s;
+  if (!on_device && n_written) {
+    if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_out, sizeof(float4), sizeof(float4), n_written, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  *n_out = n_written;
+  if (overflow) return fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
+  return NDT_OK;
+}
+
+ndt_status ndt_voxel_grid_filter(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf, void* out,
+                                 size_t out_stride, size_t* n_out) {
+  return voxel_filter_impl(h, pts, n, stride, is_dense, leaf, false, out, out_stride, n_out);
+}
+ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t n, size_t stride, int is_dense, float leaf,
+                                        void* d_out, size_t* n_out) {
+  return voxel_filter_impl(h, d_pts, n, stride, is_dense, leaf, true, d_out, 16, n_out);
+}
+
+// ---- N2: global map accumulation --------------------------------------------
+// update_global_map of the mapping nodes (ndt_omp_mapping_node.cpp:195-211,
+// ndt_rosbag_mapping_node.cpp:146-161): transformPointCloud(scan, pose); global_map += it;
+// global_map = VoxelGrid(leaf).filter(global_map).  The map stays in HBM.
+static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, bool on_device,
+                                  const float* pose, float leaf, int* overflowed) {
+  if (!h || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (overflowed) *overflowed = 0;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, scan, n, stride, on_device, c);
+  if (s) return s;
+  const size_t total = h->map_n + n;
+  if (total > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "map too large");
+  if (total == 0) return NDT_OK;
+  // concatenation [map | transformed scan] (operator+= keeps the map's points first)
+  DevBuf<float4> cat;
+  HIP_TRY(cat.reserve(total));
+  if (h->map_n) HIP_TRY(hipMemcpyAsync(cat.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+  if (n) {
+    float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float T12[12];
+    colmajor_to_T12(pose ? pose : I, T12);
+    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, cat.p + h->map_n, h->stream, is_dense));
+  }
+  HIP_TRY(h->map_pts.reserve(total));
+  size_t n_new = 0;
+  bool overflow = false;
+  // the accumulated map is dense only if every scan was; PCL carries is_dense through operator+=
+  h->map_dense = (h->map_n == 0 ? 1 : h->map_dense) && is_dense;
+  s = voxel_filter_device(h, cat.p, total, h->map_dense, leaf, h->map_pts.p, &n_new, &overflow);
+  if (s) return s;
+  h->map_n = n_new;
+  if (overflowed) *overflowed = overflow ? 1 : 0;
+  return NDT_OK;
+}
+
+ndt_status ndt_map_clear(ndt_handle h) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  h->map_n = 0;
+  h->map_dense = 1;
+  return NDT_OK;
+}
+ndt_status ndt_map_update(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, const float* pose, float leaf,
+                          int* overflowed) {
+  return map_update_impl(h, scan, n, stride, is_dense, false, pose, leaf, overflowed);
+}
+ndt_status ndt_map_update_device(ndt_handle h, const void* d_scan, size_t n, size_t stride, int is_dense, const float* pose,
+                                 float leaf, int* overflowed) {
+  return map_update_impl(h, d_scan, n, stride, is_dense, true, pose, leaf, overflowed);
+}
+ndt_status ndt_map_size(ndt_handle h, size_t* n) {
+  if (!h || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n = h->map_n;
+  return NDT_OK;
+}
+ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride) {
+  if (!h || (h->map_n && !out)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+  if (h->map_n == 0) return NDT_OK;
+  HIP_TRY(hipMemcpy2DAsync(out, out_stride, h->map_pts.p, sizeof(float4), sizeof(float4), h->map_n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return NDT_OK;
+}
+ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts, size_t* n) {
+  if (!h || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->device_ready) HIP_TRY(hipStreamSynchronize(h->stream));
+  *d_pts = h->map_pts.p;
+  *n = h->map_n;
+  return NDT_OK;
+}
+void ndt_host_chain_pose(const float* pose, const float* transform, float* out) { ndt::chain_pose(pose, transform, out); }
+
+ndt_status ndt_grid_size(ndt_handle h, size_t* n_leaves, size_t* n_valid) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  if (!h->grid->empty) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = grid_counts(h, h->grid.get());
+    if (s) return s;
+  }
+  if (n_leaves) *n_leaves = h->grid->n_leaves;
+  if (n_valid) *n_valid = h->grid->n_valid;
+  return NDT_OK;
+}
+
+ndt_status ndt_grid_info(ndt_handle h, int* min_b, int* max_b, int* div_b) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  for (int k = 0; k < 3; k++) {
+    if (min_b) min_b[k] = h->grid->geom.min_b[k];
+    if (max_b) max_b[k] = h->grid->geom.max_b[k];
+    if (div_b) div_b[k] = h->grid->geom.div_b[k];
+  }
+  return NDT_OK;
+}
+
+// Re-runs the finalize pass in dump mode (the records and LUT it rewrites are
+// bit-identical, so sharing handles stay valid).
+ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mean, double* cov, double* icov,
+                         double* evals) {
+  if (!h || !h->grid) return fail(NDT_ERR_NO_INPUT, "no grid");
+  DeviceGrid* g = h->grid.get();
+  if (!g->empty) {
+    ndt_status sc = ensure_device(h);
+    if (!sc) sc = grid_counts(h, g);
+    if (sc) return sc;
+  }
+  const size_t V = g->n_leaves;
+  if (V == 0) return NDT_OK;
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  DevBuf<int> d_n;
+  DevBuf<double> d_mean, d_cov, d_icov, d_evals;
+  DevBuf<unsigned> d_cnt;
+  HIP_TRY(d_n.reserve(V));
+  HIP_TRY(d_mean.reserve(V * 3));
+  HIP_TRY(d_cov.reserve(V * 9));
+  HIP_TRY(d_icov.reserve(V * 9));
+  HIP_TRY(d_evals.reserve(V * 3));
+  HIP_TRY(d_cnt.reserve(1));
+  HIP_TRY(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned), h->stream));
+  ndt::FinalizeDump dump{d_n.p, d_mean.p, d_cov.p, d_icov.p, d_evals.p};
+  HIP_TRY(ndt::launch_finalize(g->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
+                               static_cast<int>(V), g->sorted_idx.p, g->min_pts, g->eig_ratio, g->recs.p, g->lut.p,
+                               d_cnt.p, dump, h->stream));
+  std::vector<int> cell(V);
+  HIP_TRY(hipMemcpyAsync(cell.data(), g->leaf_cell.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (nr_points) HIP_TRY(hipMemcpyAsync(nr_points, d_n.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (mean) HIP_TRY(hipMemcpyAsync(mean, d_mean.p, V * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (cov) HIP_TRY(hipMemcpyAsync(cov, d_cov.p, V * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (icov) HIP_TRY(hipMemcpyAsync(icov, d_icov.p, V * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (evals) HIP_TRY(hipMemcpyAsync(evals, d_evals.p, V * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (idx)
+    for (size_t i = 0; i < V; i++) idx[i] = cell[i];
+  return NDT_OK;
+}
+
+}  // extern "C"

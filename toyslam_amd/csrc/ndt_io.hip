@@ -1,0 +1,118 @@
+// ndt_io.hip -- PCD files, numbered scan sequences and PointCloud2-style repacking behind the C-ABI (row N3 of the scope table; host only).
+// (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
+#include "ndt_internal.hpp"
+
+extern "C" {
+
+// ---- N3: PCD files -------------------------------------------------------------
+ndt_status ndt_pcd_read_header(const char* path, size_t* n_points, int* n_fields, int* data_kind) {
+  if (!path) return fail(NDT_ERR_INVALID, "null path");
+  std::string err;
+  try {
+    if (ndt::pcd_read_header(path, n_points, n_fields, data_kind, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {  // nothing C++ crosses the C boundary
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
+  return NDT_OK;
+}
+ndt_status ndt_pcd_read_xyz(const char* path, void* out, size_t capacity_points, size_t stride_bytes, size_t* n_points,
+                            int* is_dense) {
+  if (!path || (capacity_points && !out) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  std::string err;
+  try {
+    if (ndt::pcd_read_xyz(path, out, capacity_points, stride_bytes, n_points, is_dense, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
+  return NDT_OK;
+}
+ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t stride_bytes, int binary) {
+  if (!path || (n && !pts) || stride_bytes < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  std::string err;
+  try {
+    if (ndt::pcd_write_xyz(path, pts, n, stride_bytes, binary, err)) return fail(NDT_ERR_INVALID, err);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("PCD: ") + e.what());
+  }
+  return NDT_OK;
+}
+
+// ---- N3: numbered scans of a directory, read ahead into page-locked buffers -------------------
+struct ndt_pcd_sequence {
+  std::unique_ptr<ndt::PcdSequence> seq;
+};
+
+ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out) {
+  if (!directory || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  // page-locked when a device is there (the scans go straight into ndt_set_input_* / ndt_voxel_grid_filter uploads),
+  // pageable otherwise -- reading files needs no GPU
+  const bool pinned = usable_devices() > 0;
+  auto alloc = [pinned](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+    return nullptr;
+  };
+  auto seq = new ndt_pcd_sequence();
+  if (pinned)
+    seq->seq.reset(new ndt::PcdSequence(directory, alloc, [](void* p) { (void)hipHostFree(p); }));
+  else
+    seq->seq.reset(new ndt::PcdSequence(directory, [](size_t bytes) { return std::malloc(bytes); }, [](void* p) { std::free(p); }));
+  *out = seq;
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_poll(ndt_pcd_sequence_handle s, size_t loaded_clouds, size_t* n_new_files) {
+  if (!s) return fail(NDT_ERR_INVALID, "null");
+  std::string err;
+  try {
+    const int n = s->seq->poll(loaded_clouds, err);
+    if (n < 0) return fail(NDT_ERR_INVALID, err);
+    if (n_new_files) *n_new_files = static_cast<size_t>(n);
+  } catch (const std::exception& e) {
+    return fail(NDT_ERR_INVALID, std::string("directory listing: ") + e.what());
+  }
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, size_t* n, int* is_dense, int* file_number) {
+  if (!s || !pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt::PcdSequence::Scan scan;
+  std::string err;
+  const int rc = s->seq->next(scan, err);
+  *pts = scan.pts;
+  *n = scan.n;
+  if (is_dense) *is_dense = scan.is_dense;
+  if (file_number) *file_number = scan.file_number;
+  if (rc == 2) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
+}
+
+void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s) { delete s; }
+
+int ndt_host_extract_file_number(const char* file_stem) { return file_stem ? ndt::extract_file_number(file_stem) : -1; }
+
+ndt_status ndt_host_repack_fields(const void* data, size_t n, size_t point_step, size_t off_x, size_t off_y, size_t off_z,
+                                  void* out_xyz1, int* is_dense) {
+  if ((n && (!data || !out_xyz1)) || point_step < 12) return fail(NDT_ERR_INVALID, "bad arguments");
+  for (size_t off : {off_x, off_y, off_z})
+    if (off + sizeof(float) > point_step) return fail(NDT_ERR_INVALID, "field offset outside the point record");
+  const unsigned char* src = static_cast<const unsigned char*>(data);
+  float* dst = static_cast<float*>(out_xyz1);
+  bool finite = true;
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char* rec = src + i * point_step;
+    float v[3];
+    std::memcpy(&v[0], rec + off_x, sizeof(float));  // unaligned-safe
+    std::memcpy(&v[1], rec + off_y, sizeof(float));
+    std::memcpy(&v[2], rec + off_z, sizeof(float));
+    finite = finite && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]);
+    dst[4 * i] = v[0];
+    dst[4 * i + 1] = v[1];
+    dst[4 * i + 2] = v[2];
+    dst[4 * i + 3] = 1.0f;
+  }
+  if (is_dense) *is_dense = finite ? 1 : 0;
+  return NDT_OK;
+}
+
+}  // extern "C"
