@@ -1,44 +1,151 @@
 #!/usr/bin/env python3
 """bench.py -- scan registrations/sec of the MI355X NDT core (BASELINE.json metric).
 
-A "step" is ONE registration (pcl::Registration::align) of one synthetic 100k-point source scan
-against a 1M-point target whose voxel grid is already resident in HBM -- exactly the region
-ndt_omp/apps/align.cpp:20-29 times -- at 1.0 m voxels, DIRECT7, with the Newton loop pinned to
-30 outer passes (max_iterations 28, transformation_epsilon 0: ndt_omp_impl.hpp:158-164 then runs
-max_iterations + 2 passes).  configs[1] of BASELINE.json.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|single|mapbuild|batch|large|pyramid]
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--set U|S] [--workload single|batch]
+N = 1 (default workload "single" = BASELINE configs[1], the configuration the metric is quoted on):
+  a "step" is ONE registration (pcl::Registration::align) of one synthetic 100k-point source scan against
+  a 1M-point target whose voxel grid is already resident in HBM -- exactly the region
+  ndt_omp/apps/align.cpp:20-29 times -- at 1.0 m voxels, DIRECT7, with the Newton loop pinned to 30 outer
+  passes (max_iterations 28, transformation_epsilon 0: ndt_omp_impl.hpp:158-164 then runs max_iterations + 2
+  passes).
+N > 1 (default workload "mapbuild" = BASELINE configs[3]): 512 source scans of 100k points against the one
+  shared 1M-point target, the scans split over the ranks by toyslam_amd.dist.shard_range, the target grid
+  replicated per GPU; a "step" is one lock-step batch registration (ndt_align_batch_device) of every rank's
+  share, i.e. 512 registrations.  Registrations of different scans are independent, so there is no collective
+  in the data path; total work is fixed as N grows ("scaling": "strong").  After the timed region the same
+  batch is run once more in the literal north_star form -- every rank steps all 512 Newton / More-Thuente
+  state machines, ONE RCCL all-reduce of the zero-padded [512][32] f64 rows per lock-step, issued from C++
+  on the library's stream (ndt_comm_*) -- and reported as "lockstep_allreduce".
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): registrations of different scans are
-independent, so every rank registers its own scan against its own replica of the target grid with
-no collective in the data path ("scaling": "weak"); value = N*K / max-over-ranks time.
+Launch: the driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment).  Started plainly with --gpus N > 1 and no
+WORLD_SIZE, this file spawns the N ranks itself (child processes, before anything touches the GPU -- never an
+exec) and relays rank 0's JSON line.
 
 Rank 0 prints ONE JSON line.  Extra legs on rank 0 (outside the timed region):
-  roofline     -- average duration of the dominant kernel (k_eval_server: one persistent launch per
-                  registration) from HIP events on the library's own stream, over a second pass of
-                  the same steps; algorithmic bytes = evaluations served x bytes per evaluation.
-  cpu_baseline -- the oracle (oracle/, a faithful OpenMP port of the reference's algorithm; the real
-                  pclomp cannot be built here) on the same inputs on the host cores (N = 1 only).
+  roofline     -- average duration of the dominant kernel from HIP events on the library's own stream over a
+                  second pass of the same steps; algorithmic bytes = SURVEY 8(d)'s per-evaluation figure x the
+                  evaluations the launch served.
+  cpu_baseline -- the oracle (oracle/, a faithful OpenMP port of the reference's algorithm; the real pclomp
+                  cannot be built here: no PCL / Eigen in the image) on the same inputs on the host cores, at all
+                  physical cores and at 16 threads, plus an optimised CPU variant (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "scan registrations/sec (100k-pt src vs 1M-pt target, 30 Newton iters)"
-M_TARGET, N_SOURCE, RESOLUTION, MAX_ITER, EPS = 1000000, 100000, 1.0, 28, 0.0
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MAX_ITER, EPS = 28, 0.0
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--set", default="U", choices=["U", "S"], help="U = uniform box (headline), S = surface scene")
+    ap.add_argument("--workload", default="auto",
+                    choices=["auto", "single", "mapbuild", "batch", "large", "pyramid", "selftest"],
+                    help="auto = single at N = 1, mapbuild at N > 1; single = configs[1]; mapbuild = configs[3] (--scans "
+                         "scans split over the ranks); batch = --batch scans per GPU; large = configs[2] (2M-pt source "
+                         "vs 10M-pt target, 0.5 m voxels, --extent m scene); pyramid = configs[4] (2.0 -> 1.0 -> 0.5 m "
+                         "on a streamed sequence of 2M-pt PCD scans); selftest = launcher / rendezvous check without a GPU")
+    ap.add_argument("--scans", type=int, default=512, help="total scans of the mapbuild workload (configs[3]: 512)")
+    ap.add_argument("--batch", type=int, default=64, help="scans per GPU for --workload batch")
+    ap.add_argument("--extent", type=float, default=400.0, help="scene size of --workload large / pyramid (SURVEY 8(d): 400 m)")
+    ap.add_argument("--seq-scans", type=int, default=16, help="scans of the streamed sequence of --workload pyramid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mapbuild-leg", action="store_true", help="N = 1 single: skip the 512-scan map-build leg")
+    ap.add_argument("--no-lockstep-leg", action="store_true", help="N > 1 mapbuild: skip the RCCL lock-step leg")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the selftest)")
+    ap.add_argument("--dry-run", action="store_true", help="self-launch only: print the per-rank environment plan and exit")
+    return ap.parse_args(argv)
+
+
+# =====================================================================================================
+# self-launch: python bench.py --gpus N with no WORLD_SIZE -> N child ranks (never an exec: a process
+# that has touched the GPU must not be replaced, and the parent never touches it)
+# =====================================================================================================
+def rank_environments(n, port, base_env=None):
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base_env is None else base_env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+        e.setdefault("OMP_NUM_THREADS", "4")
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    port = free_port()
+    envs = rank_environments(args.gpus, port)
+    if args.dry_run:
+        plan = [{k: e[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} for e in envs]
+        print(json.dumps({"launcher": "self", "n_ranks": args.gpus, "ranks": plan,
+                          "command": [sys.executable, os.path.abspath(__file__)] + argv}))
+        return 0
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    rc = max(abs(c) for c in rcs)
+    if rc or not lines:
+        sys.stderr.write("bench.py self-launch: rank exit codes %s\n" % rcs)
+    return rc if rc else (0 if lines else 1)
+
+
+# =====================================================================================================
+# helpers
+# =====================================================================================================
 def algorithmic_bytes_per_eval(n_points, mean_neighbors):
     """16 B point + 7 x 4 B voxel-slot probes + 36 B per valid neighbour record."""
     return n_points * (16 + 7 * 4 + 36 * mean_neighbors)
+
+
+def host_info():
+    """CPU model string, logical CPUs this process may use, physical cores among them."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cpus = sorted(os.sched_getaffinity(0))
+    cores = set()
+    for c in cpus:
+        try:
+            pkg = open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read().strip()
+            core = open("/sys/devices/system/cpu/cpu%d/topology/core_id" % c).read().strip()
+            cores.add((pkg, core))
+        except OSError:
+            cores.add(("?", str(c)))
+    return {"cpu_model": model, "logical_cpus": len(cpus), "physical_cores": len(cores)}
 
 
 def bind_near_gpu(local_rank):
@@ -64,49 +171,157 @@ def bind_near_gpu(local_rank):
         return None
 
 
+def committed_profile(name):
+    """Newest committed profiles/rNN_<name> (PMC passes cannot run inside this process: they need rocprofv3)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
+    if not c:
+        return None, None
+    try:
+        return json.load(open(c[-1])), os.path.relpath(c[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def median_time(fn, n=5):
+    import numpy as np
+    ts = []
+    for _ in range(n):
+        ta = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - ta)
+    return float(np.median(ts))
+
+
+def timed_oracle(po, tgt, src, resolution, threads, optimised, budget_s):
+    """The oracle's align() on the workload: 1 warm-up (also the parity reference) + up to 5 timed runs within budget_s."""
+    import numpy as np
+    o = po.OracleNDT(resolution=resolution, search_method=po.DIRECT7, num_threads=threads, trans_eps=EPS, max_iter=MAX_ITER,
+                     optimised=optimised)
+    tb = time.perf_counter()
+    o.set_target(tgt)
+    tb = time.perf_counter() - tb
+    o.set_source(src)
+    r = o.align()
+    times = []
+    deadline = time.perf_counter() + budget_s
+    while len(times) < 5 and (not times or time.perf_counter() < deadline):
+        ta = time.perf_counter()
+        o.align()
+        times.append(time.perf_counter() - ta)
+    med = float(np.median(times))
+    return med, len(times), tb, r
+
+
+def near_T_gt(T, T_gt, rot=2e-3, trans=2e-2):
+    """Did a registration end at the known transform?  (set U carries 2 cm of noise per point and no structure but its
+    sampling: the estimate lands within millimetres, not at the oracle-parity tolerance.)"""
+    import numpy as np
+    return bool(np.abs(T[:3, :3] - T_gt[:3, :3]).max() < rot and np.abs(T[:3, 3] - T_gt[:3, 3]).max() < trans)
+
+
+def mapbuild_scans(clouds, tgt, lo, hi, n_source):
+    """Scans lo..hi-1 of the configs[3] workload (clouds.mapbuild_scan: seeds depend on the scan number only)."""
+    scans, T_gts = [], []
+    for k in range(lo, hi):
+        s, T = clouds.mapbuild_scan(tgt, k, n_source)
+        scans.append(s)
+        T_gts.append(T)
+    return scans, T_gts
+
+
+# =====================================================================================================
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--set", default="U", choices=["U", "S"], help="U = uniform box (headline), S = surface scene")
-    ap.add_argument("--workload", default="single", choices=["single", "batch", "large"],
-                    help="single = configs[1] (headline); batch = configs[3] shape per GPU; "
-                         "large = configs[2]: 2M-pt source vs 10M-pt target, 0.5 m voxels")
-    ap.add_argument("--batch", type=int, default=64, help="scans per GPU for --workload batch (config 4 shape)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    workload = args.workload
+    if workload == "auto":
+        workload = "single" if world == 1 else "mapbuild"
+    steps = args.steps if args.steps is not None else {"single": 50, "large": 10, "mapbuild": 3, "batch": 5, "pyramid": 1, "selftest": 3}[workload]
+    warmup = args.warmup if args.warmup is not None else {"single": 5, "large": 2, "mapbuild": 1, "batch": 1, "pyramid": 0, "selftest": 0}[workload]
+
+    import numpy as np
     import torch
     dist = None
+    use_gpu = workload != "selftest"
     if world > 1:
         import torch.distributed as dist
+        backend = args.backend or ("nccl" if use_gpu else "gloo")
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    elif use_gpu and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-
-    binding = bind_near_gpu(local_rank) if torch.cuda.is_available() else None
-
-    from toyslam_amd import clouds, ndt
 
     def barrier():
-        if torch.cuda.is_available():
+        if use_gpu and torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if (use_gpu and dist.get_backend() == "nccl") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if (use_gpu and dist.get_backend() == "nccl") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    from toyslam_amd import dist as nd
+
+    # ---- launcher / rendezvous self-test (CPU, gloo): what a SCALE run exercises before any kernel ----
+    if workload == "selftest":
+        lo, hi = nd.shard_range(args.scans, rank, world)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            time.sleep(0.001 * (hi - lo) / max(1, args.scans) * world)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        covered = sum_over_ranks(hi - lo)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher selftest", "value": steps * args.scans / dt, "unit": "scans/s", "n_gpus": 0,
+                              "world_size": world, "steps": steps, "warmup": warmup, "scans_covered": covered,
+                              "backend": dist.get_backend() if dist is not None else None}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    binding = bind_near_gpu(local_rank) if torch.cuda.is_available() else None
+    from toyslam_amd import clouds, ndt
+
     # ---- inputs (synthetic, seeded; resident in HBM before the timed region) ----
-    global M_TARGET, N_SOURCE, RESOLUTION
-    if args.workload == "large":
+    M_TARGET, N_SOURCE, RESOLUTION = 1000000, 100000, 1.0
+    if workload in ("large", "pyramid"):
         M_TARGET, N_SOURCE, RESOLUTION = 10000000, 2000000, 0.5
-    if args.workload == "large":   # configs[2]: surface scene of 200 x 200 m (at 400 m a 10M-pt map is too sparse for 0.5 m voxels: most hold < 6 points)
-        tgt = clouds.target_surfaces(M_TARGET, extent=200.0, n_boxes=120)
+        # SURVEY 8(d) config 3: the set-S generator scaled to 400 x 400 m (--extent; round 1 measured a 200 m scene with
+        # 120 boxes, kept as --extent 200)
+        tgt = clouds.target_surfaces(M_TARGET, extent=args.extent, n_boxes=60 if args.extent >= 300 else 120)
     else:
         tgt = clouds.target_uniform(M_TARGET) if args.set == "U" else clouds.target_surfaces(M_TARGET)
+
+    if workload == "pyramid":
+        out = run_pyramid(args, ndt, clouds, tgt, local_rank, steps, warmup, binding)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
+
     reg = ndt.NormalDistributionsTransform(device=local_rank)
     reg.setResolution(RESOLUTION)
     reg.setNeighborhoodSearchMethod(ndt.DIRECT7)
@@ -115,75 +330,95 @@ def main():
     t0 = time.perf_counter()
     reg.setInputTarget(tgt)
     t_build_first = time.perf_counter() - t0
-
-    def best_of(fn, n=5):
-        ts = []
-        for _ in range(n):
-            ta = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - ta)
-        return float(np.median(ts))
-    t_build = best_of(lambda: reg.setInputTarget(tgt))                 # host buffer: H2D over PCIe + grid build
+    t_build = median_time(lambda: reg.setInputTarget(tgt))                 # host buffer: H2D over PCIe + grid build
     tgt_dev = torch.from_numpy(np.c_[tgt, np.ones(len(tgt), np.float32)]).cuda()
     torch.cuda.synchronize()
-    t_build_dev = best_of(lambda: reg.setInputTargetDevice(tgt_dev.data_ptr(), len(tgt), 16))  # cloud already in HBM
+    t_build_dev = median_time(lambda: reg.setInputTargetDevice(tgt_dev.data_ptr(), len(tgt), 16))  # cloud already in HBM
 
-    if args.workload in ("single", "large"):
+    T_gts = None
+    if workload in ("single", "large"):
         src = clouds.source_from_target(tgt, N_SOURCE, seed=clouds.SEED + 1 + 7 * rank)
         reg.setInputSource(src)
-        t_source = best_of(lambda: reg.setInputSource(src))           # H2D + spatial ordering of the scan
+        t_source = median_time(lambda: reg.setInputSource(src))           # H2D + spatial ordering of the scan
 
         def step():
             reg.align()
-        regs_per_step = 1
+        regs_per_step_global = world  # replicas: every rank registers its own scan
+        scaling = "weak"
     else:
-        rng = np.random.default_rng(clouds.SEED + 100 + rank)
-        scans = []
-        for k in range(args.batch):
-            T = clouds.random_T(rng, 0.5, 2.0)
-            scans.append(clouds.source_from_target(tgt, N_SOURCE, T_gt=T, seed=clouds.SEED + 1000 * rank + k))
-        cat = np.ascontiguousarray(np.concatenate(scans, axis=0))
+        if workload == "mapbuild":
+            lo, hi = nd.shard_range(args.scans, rank, world)
+            regs_per_step_global = args.scans
+            scaling = "strong"
+        else:
+            lo, hi = rank * args.batch, (rank + 1) * args.batch
+            regs_per_step_global = args.batch * world
+            scaling = "weak"
+        scans, T_gts = mapbuild_scans(clouds, tgt, lo, hi, N_SOURCE)
+        n_local = hi - lo
+        cat = np.ascontiguousarray(np.concatenate(scans, axis=0)) if scans else np.zeros((0, 3), np.float32)
+        del scans
         dev = torch.from_numpy(np.c_[cat, np.ones(len(cat), np.float32)]).cuda()
-        offsets = np.arange(args.batch + 1, dtype=np.uintp) * N_SOURCE
+        del cat
+        offsets = np.arange(n_local + 1, dtype=np.uintp) * N_SOURCE
+        last = {}
 
         def step():
-            reg.alignBatch(device_ptr=dev.data_ptr(), offsets=offsets, stride_bytes=16)
-        regs_per_step = args.batch
+            if n_local:
+                last["res"] = reg.alignBatch(device_ptr=dev.data_ptr(), offsets=offsets, stride_bytes=16)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local)
+
+    # every rank: did its registrations end at the known T_gt?  (summed over ranks; outside the timed region)
+    recovered = None
+    if T_gts is not None:
+        ok = 0
+        if T_gts:
+            Ts = last["res"]["T"]
+            for k, Tg in enumerate(T_gts):
+                ok += int(near_T_gt(Ts[k], Tg))
+        recovered = int(sum_over_ranks(ok))
+    per_rank_regs = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.zeros(world, dtype=torch.float64, device="cuda")
+        mine[rank] = (steps * (len(T_gts) if T_gts is not None else 1)) / dt_local
+        dist.all_reduce(mine)
+        per_rank_regs = [float(x) for x in mine.tolist()]
 
     out = None
     if rank == 0:
-        st = reg.stats() if args.workload in ("single", "large") else {}
-        T_timed = reg.getFinalTransformation() if args.workload in ("single", "large") else None
-        it_timed = reg.getFinalNumIteration() if args.workload in ("single", "large") else None
-        value = world * args.steps * regs_per_step / dt
+        value = steps * regs_per_step_global / dt
+        names = {
+            "single": "single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes (max_iterations 28, epsilon 0), set " + args.set,
+            "large": "single 2M-pt source vs 10M-pt target (surface scene, %g m), 0.5 m voxels, DIRECT7, 30 Newton passes" % args.extent,
+            "mapbuild": "map-build: %d x 100k-pt sources vs one shared 1M-pt target, scans split over %d GPU(s), lock-step batch per GPU, set %s" % (args.scans, world, args.set),
+            "batch": "map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set),
+        }
         out = {
-            "metric": METRIC, "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes "
-                                    "(max_iterations 28, epsilon 0), set " + args.set) if args.workload == "single" else
-                       ("single 2M-pt source vs 10M-pt target (surface scene, 200 m), 0.5 m voxels, DIRECT7, 30 Newton passes")
-                       if args.workload == "large" else
-                       ("map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set)),
-                       "target_points": M_TARGET, "source_points": N_SOURCE, "resolution_m": RESOLUTION,
-                       "search": "DIRECT7", "outer_passes": MAX_ITER + 2, "sharding": "one scan stream per GPU, target grid replicated"},
+            "metric": METRIC, "value": value, "unit": "registrations/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": names[workload], "target_points": M_TARGET, "source_points": N_SOURCE, "resolution_m": RESOLUTION,
+                       "search": "DIRECT7", "outer_passes": MAX_ITER + 2,
+                       "sharding": ("scans split over the ranks (dist.shard_range), target grid replicated, no collective in the data path"
+                                    if workload in ("mapbuild", "batch") else "one scan stream per GPU, target grid replicated")},
+            "world_size": world, "collective_backend": (dist.get_backend() if dist is not None else None),
+            "per_rank_registrations_per_s": per_rank_regs,
             "host_binding": binding, "target_build_ms": t_build * 1e3,
             "target_build_roofline": None, "target_build_device_resident_ms": t_build_dev * 1e3,
             "target_build_first_call_ms": t_build_first * 1e3,
         }
+        if recovered is not None:
+            out["registrations_ending_at_T_gt"] = recovered
+            out["registrations_per_step"] = regs_per_step_global
         try:  # K1 against its own roof (M x 16 B read + V x 64 B of records written)
             gi = reg.grid_counts()
             k1_bytes = M_TARGET * 16 + gi["n_leaves"] * 64
@@ -191,161 +426,289 @@ def main():
                                             "achieved": k1_bytes / t_build_dev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": k1_bytes / t_build_dev / 1e9 / HBM_PEAK_GBS,
                                             "occupied_voxels": gi["n_leaves"], "valid_voxels": gi["n_valid"],
-                                            "note": "wall time of ndt_set_input_target_device: a chain of ~10 dependent kernels, not one "
-                                                    "kernel; at 1M points their durations add up to the wall time "
-                                                    "(profiles/r01_kernel_stats.csv: k_count 46 us of device-scope atomics, "
-                                                    "k_finalize 38 us of per-voxel f64 eigen-decompositions, scatter / presort / "
-                                                    "repack ~16 us each, scans ~20 us), at the nodes' 16k points launch latency"}
+                                            "note": "wall time of ndt_set_input_target_device (cloud already in HBM), all of its kernels"}
         except Exception:
             pass
-        if args.workload in ("single", "large"):
-            out["set_source_ms"] = t_source * 1e3
-            out["registrations_per_s_incl_target_build_and_source_upload"] = 1.0 / (dt / args.steps + t_build + t_source)
-            out["evaluations_per_registration"] = st["n_evals"]
-            out["f64_hessian_recomputes"] = st["n_hessian_recomputes"]
-            out["mean_neighbors"] = st["mean_neighbors"]
-            # ---- roofline leg: HIP events on the library's stream, second pass of the same steps ----
-            # The kernel of the timed region is k_eval_server: ONE launch per registration that serves
-            # every evaluation of it.  ndt_profile_enable(2) brackets that launch with an event pair.
-            n_rep = min(args.steps, 10)
-            reg.profile(2)
-            reg.profile_read(3)
-            for _ in range(n_rep):
-                reg.align()
-            n_launch, ms = reg.profile_read(3)
-            st2 = reg.stats()
-            # ... and, for reference, the same device code as one launch per evaluation (profile mode 1)
-            reg.profile(1)
-            reg.profile_read(0)
-            for _ in range(n_rep):
-                reg.align()
-            n_eval_launch, ms_eval = reg.profile_read(0)
-            reg.profile(0)
-            hbar = st2["mean_neighbors"]
-            avg_s = ms * 1e-3 / max(n_launch, 1)
-            bytes_per_eval = algorithmic_bytes_per_eval(N_SOURCE, hbar)
-            evals_per_launch = st2["n_evals"] + st2["n_hessian_recomputes"]
-            bytes_per_launch = evals_per_launch * bytes_per_eval
-            achieved = bytes_per_launch / avg_s / 1e9
-            # HBM traffic of the same kernel from the committed PMC passes of this command
-            # (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; unit KB; gfx950
-            # correction 2 x FETCH_SIZE, MI355X_MICROARCH.md "HBM") -- not collectable live here.
-            traffic, traffic_src = None, None
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_profile_summary.json")))
-                for name, c in prof["pmc"].items():
-                    if "k_eval_server<7>" in name and args.workload == "single":
-                        traffic = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
-                        traffic_src = "profiles/r01_profile_summary.json"
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
-                                         "their reductions, the f64 Hessian recompute and the output transform)",
-                               "avg_kernel_us": avg_s * 1e6, "launches_timed": n_launch,
-                               "evaluations_per_launch": evals_per_launch,
-                               "algorithmic_bytes_per_evaluation": bytes_per_eval,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "mean_neighbors": hbar,
-                               "how": "one hipEvent pair on the library stream around the kernel of each registration "
-                                      "(ndt_profile_enable(2)), in a second pass of the same steps",
-                               "per_evaluation_kernel": {
-                                   "kernel": "k_derivatives_fused<DIRECT7, hessian>: the same device code as one launch "
-                                             "per evaluation (ndt_profile_enable(1))",
-                                   "avg_event_us": ms_eval * 1e3 / max(n_eval_launch, 1), "launches_timed": n_eval_launch,
-                                   "achieved_GBs": bytes_per_eval / (ms_eval * 1e-3 / max(n_eval_launch, 1)) / 1e9}}
-            out["us_per_evaluation_in_timed_region"] = dt / args.steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
-            out["registration_algorithmic_GBs"] = (st["n_evals"] + st["n_hessian_recomputes"]) * bytes_per_eval / (dt / args.steps) / 1e9
-            # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
-            if world == 1 and not args.no_cpu_baseline and args.workload == "single":
-                from oracle import pyoracle as po
-                # the GPU box exposes every host core, but one GPU's share of it is 16 (and the port
-                # does not scale past that: its zero-fill/ordered-reduce/f64-Hessian parts are serial)
-                cores = min(16, len(os.sched_getaffinity(0)))
-                o = po.OracleNDT(resolution=RESOLUTION, search_method=po.DIRECT7, num_threads=cores,
-                                 trans_eps=EPS, max_iter=MAX_ITER)
-                tb = time.perf_counter()
-                o.set_target(tgt)
-                tb = time.perf_counter() - tb
-                o.set_source(src)
-                r = o.align()  # warm-up, also the parity reference
-                times = []
-                budget = time.perf_counter() + 20.0
-                while len(times) < 5 and (not times or time.perf_counter() < budget):
-                    ta = time.perf_counter()
-                    o.align()
-                    times.append(time.perf_counter() - ta)
-                med = float(np.median(times))
-                T = T_timed  # result of the timed region's last registration
-                out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
-                                       "sample": "%d full registrations of the same workload (median), after 1 warm-up; "
-                                                 "align only, target grid resident" % len(times),
-                                       "ms_per_registration": med * 1e3, "target_build_ms": tb * 1e3,
-                                       "evaluations": r["n_evals"], "host_cores_visible": len(os.sched_getaffinity(0))}
-                out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T[:3, :3] - r["T"][:3, :3]).max()),
-                                           "trans_max_abs_m": float(np.abs(T[:3, 3] - r["T"][:3, 3]).max()),
-                                           "iterations_gpu": it_timed, "iterations_oracle": r["iterations"],
-                                           "evals_gpu": st["n_evals"], "evals_oracle": r["n_evals"]}
-                out["speedup_vs_cpu_baseline"] = value / (1.0 / med)
-                # also an OPTIMISED CPU variant, so that the ratio is not inflated by the
-                # reference's own inefficiencies (rb-tree voxel lookup, N x 344 B scratch allocated, zeroed
-                # and summed per evaluation, serial f64 Hessian).  Same arithmetic per neighbour.
-                oo = po.OracleNDT(resolution=RESOLUTION, search_method=po.DIRECT7, num_threads=cores,
-                                  trans_eps=EPS, max_iter=MAX_ITER, optimised=True)
-                oo.set_target(tgt)
-                oo.set_source(src)
-                ro = oo.align()
-                times = []
-                budget = time.perf_counter() + 10.0
-                while len(times) < 5 and (not times or time.perf_counter() < budget):
-                    ta = time.perf_counter()
-                    oo.align()
-                    times.append(time.perf_counter() - ta)
-                med_o = float(np.median(times))
-                out["cpu_baseline_optimised"] = {
-                    "value": 1.0 / med_o, "unit": "registrations/s", "cores": cores, "kind": "port-optimised",
-                    "sample": "%d full registrations (median) of the same workload" % len(times),
-                    "ms_per_registration": med_o * 1e3, "evaluations": ro["n_evals"],
-                    "what": "dense voxel lookup, per-thread accumulators instead of per-point result arrays, point "
-                            "derivatives once per point, parallel f64 Hessian",
-                    "speedup_of_gpu": value * med_o}
-        if args.workload == "batch":
-            # ---- roofline leg of the lock-step batch: one pass of the same step with a HIP event pair on the library's
-            # stream around the derivative kernels of every lock-step (ndt_profile_enable(1)); the algorithmic bytes are
-            # 8(d)'s per-evaluation figure x the scan evaluations those kernels served ----
-            reg.profile(1)
-            reg.profile_read(0)
-            step()
-            n_steps_timed, ms = reg.profile_read(0)
-            reg.profile(0)
-            stb = reg.stats()
-            n_scan_evals = stb["n_evals"] + stb["n_hessian_recomputes"]
-            bytes_total = n_scan_evals * algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"])
-            achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            out["scan_evaluations_per_step"] = n_scan_evals
-            out["mean_neighbors"] = stb["mean_neighbors"]
-            traffic, traffic_src = None, None   # HBM bytes per lock-step from the committed PMC passes of the 64-scan command
-            try:
-                if args.batch == 64 and args.set == "U":
-                    traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_batch64_summary.json")))["derivative_kernels_hbm_bytes_per_lock_step"]
-                    traffic_src = "profiles/r01_batch64_summary.json (tools/profile_batch.sh)"
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "algorithmic_bytes_per_launch": bytes_total / max(n_steps_timed, 1),
-                               "kernel": "k_derivatives<DIRECT7> / k_batch_step (one launch per lock-step over every live scan; "
-                                         "+ k_hessian64 where a scan's line search iterated)",
-                               "avg_kernel_us": ms * 1e3 / max(n_steps_timed, 1), "launches_timed": n_steps_timed,
-                               "scan_evaluations": n_scan_evals,
-                               "algorithmic_bytes_per_scan_evaluation": algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"]),
-                               "kernel_time_share_of_step": ms / (dt / args.steps * 1e3),
-                               "how": "one hipEvent pair per lock-step on the library stream around the derivative kernels "
-                                      "(ndt_profile_enable(1)), one extra pass of the same step"}
+
+    if workload in ("single", "large"):
+        if rank == 0:
+            single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value)
+    else:
+        batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps, dt, N_SOURCE, dev if n_local else None, offsets, lo, hi,
+                   T_gts, torch)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# =====================================================================================================
+# legs of the single-scan workloads (rank 0, outside the timed region)
+# =====================================================================================================
+def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value):
+    import numpy as np
+    st = reg.stats()
+    T_timed = reg.getFinalTransformation()
+    it_timed = reg.getFinalNumIteration()
+    out["set_source_ms"] = t_source * 1e3
+    out["registrations_per_s_incl_target_build_and_source_upload"] = 1.0 / (dt / steps + t_build + t_source)
+    out["evaluations_per_registration"] = st["n_evals"]
+    out["f64_hessian_recomputes"] = st["n_hessian_recomputes"]
+    out["mean_neighbors"] = st["mean_neighbors"]
+    out["final_vs_T_gt"] = {"rot_max_abs": float(np.abs(T_timed[:3, :3] - clouds.T_GT_DEFAULT[:3, :3]).max()),
+                            "trans_max_abs_m": float(np.abs(T_timed[:3, 3] - clouds.T_GT_DEFAULT[:3, 3]).max())}
+    # ---- roofline leg: HIP events on the library's stream, second pass of the same steps ----
+    # The kernel of the timed region is k_eval_server: ONE launch per registration that serves
+    # every evaluation of it.  ndt_profile_enable(2) brackets that launch with an event pair.
+    n_rep = min(steps, 10)
+    reg.profile(2)
+    reg.profile_read(3)
+    for _ in range(n_rep):
+        reg.align()
+    n_launch, ms = reg.profile_read(3)
+    st2 = reg.stats()
+    # ... and, for reference, the same device code as one launch per evaluation (profile mode 1)
+    reg.profile(1)
+    reg.profile_read(0)
+    for _ in range(n_rep):
+        reg.align()
+    n_eval_launch, ms_eval = reg.profile_read(0)
+    reg.profile(0)
+    hbar = st2["mean_neighbors"]
+    avg_s = ms * 1e-3 / max(n_launch, 1)
+    bytes_per_eval = algorithmic_bytes_per_eval(N_SOURCE, hbar)
+    evals_per_launch = st2["n_evals"] + st2["n_hessian_recomputes"]
+    bytes_per_launch = evals_per_launch * bytes_per_eval
+    achieved = bytes_per_launch / avg_s / 1e9
+    # HBM traffic and VALU issue of the same kernel: PMC counters need rocprofv3 around the process, so they cannot be
+    # collected inside this run; the figures of the newest committed profile of this command are attached under
+    # *_committed_profile keys and `traffic` stays null.
+    committed = {}
+    if workload == "single":
+        prof, src_name = committed_profile("profile_summary.json")
+        try:
+            for name, c in (prof or {}).get("pmc", {}).items():
+                if "k_eval_server<7>" in name and "FETCH_SIZE" in c:
+                    committed["traffic_committed_profile"] = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
+                    committed["traffic_committed_profile_source"] = src_name + " (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, KB, 2 x FETCH_SIZE on gfx950)"
+        except Exception:
+            pass
+        valu, valu_name = committed_profile("pmc_valu.json")
+        try:
+            per_wave = valu["server"]["SQ_INSTS_VALU_per_wave_per_evaluation"]
+            waves = valu["server"]["waves"]
+            insts_per_launch = per_wave * waves * evals_per_launch
+            committed["valu_issue_frac_committed_profile"] = insts_per_launch / avg_s / VALU_PEAK_WAVE_INSTS_PER_S
+            committed["valu_issue_frac_source"] = valu_name + " (SQ_INSTS_VALU per wave per evaluation x waves x evaluations of this run / this run's kernel time / (1024 SIMDs x 2.4 GHz / 4))"
+        except Exception:
+            pass
+    out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                       "kernel": "k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
+                                 "their reductions, the f64 Hessian recompute and the output transform)",
+                       "avg_kernel_us": avg_s * 1e6, "launches_timed": n_launch,
+                       "evaluations_per_launch": evals_per_launch,
+                       "algorithmic_bytes_per_evaluation": bytes_per_eval,
+                       "algorithmic_bytes_per_launch": bytes_per_launch, "mean_neighbors": hbar,
+                       "how": "one hipEvent pair on the library stream around the kernel of each registration "
+                              "(ndt_profile_enable(2)), in a second pass of the same steps",
+                       "per_evaluation_kernel": {
+                           "kernel": "k_derivatives_fused<DIRECT7, hessian>: the same device code as one launch "
+                                     "per evaluation (ndt_profile_enable(1))",
+                           "avg_event_us": ms_eval * 1e3 / max(n_eval_launch, 1), "launches_timed": n_eval_launch,
+                           "achieved_GBs": bytes_per_eval / (ms_eval * 1e-3 / max(n_eval_launch, 1)) / 1e9}}
+    out["roofline"].update(committed)
+    out["us_per_evaluation_in_timed_region"] = dt / steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
+    out["registration_algorithmic_GBs"] = (st["n_evals"] + st["n_hessian_recomputes"]) * bytes_per_eval / (dt / steps) / 1e9
+
+    # ---- configs[3] on this one GPU: the denominator of the 8-GPU map-build comparison ----
+    if world == 1 and workload == "single" and not args.no_mapbuild_leg:
+        try:
+            import torch
+            scans, T_gts = mapbuild_scans(clouds, tgt, 0, args.scans, N_SOURCE)
+            cat = np.ascontiguousarray(np.concatenate(scans, axis=0))
+            del scans
+            dev = torch.from_numpy(np.c_[cat, np.ones(len(cat), np.float32)]).cuda()
+            del cat
+            offsets = np.arange(args.scans + 1, dtype=np.uintp) * N_SOURCE
+            res = reg.alignBatch(device_ptr=dev.data_ptr(), offsets=offsets, stride_bytes=16)  # warm-up
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            n_mb = 2
+            for _ in range(n_mb):
+                res = reg.alignBatch(device_ptr=dev.data_ptr(), offsets=offsets, stride_bytes=16)
+            torch.cuda.synchronize()
+            tm = (time.perf_counter() - ta) / n_mb
+            ok = sum(int(near_T_gt(res["T"][k], T_gts[k])) for k in range(args.scans))
+            out["mapbuild_1gpu"] = {"workload": "configs[3] on one GPU: %d x 100k-pt sources vs the same target, one lock-step batch" % args.scans,
+                                    "value": args.scans / tm, "unit": "registrations/s", "ms_per_step": tm * 1e3, "steps": n_mb,
+                                    "registrations_ending_at_T_gt": ok}
+            del dev
+        except Exception as e:  # never lose the headline line to an auxiliary leg
+            out["mapbuild_1gpu"] = {"error": repr(e)}
+
+    # ---- CPU baseline leg (N = 1 only): the oracle on the same inputs ----
+    if world == 1 and not args.no_cpu_baseline and workload == "single":
+        from oracle import pyoracle as po
+        hi_ = host_info()
+        out["host"] = hi_
+        phys = max(1, hi_["physical_cores"])
+        # faithful port at all physical cores and at 16 threads (one GPU's share of an 8-GPU host)
+        med, n_t, tb, r = timed_oracle(po, tgt, src, RESOLUTION, phys, False, 12.0)
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": phys, "kind": "port",
+                               "sample": "%d full registrations of the same workload (median), after 1 warm-up; align only, target grid resident" % n_t,
+                               "ms_per_registration": med * 1e3, "target_build_ms": tb * 1e3, "evaluations": r["n_evals"],
+                               "cpu_model": hi_["cpu_model"], "threads": phys, "host_logical_cpus": hi_["logical_cpus"]}
+        out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T_timed[:3, :3] - r["T"][:3, :3]).max()),
+                                   "trans_max_abs_m": float(np.abs(T_timed[:3, 3] - r["T"][:3, 3]).max()),
+                                   "iterations_gpu": it_timed, "iterations_oracle": r["iterations"],
+                                   "evals_gpu": st["n_evals"], "evals_oracle": r["n_evals"]}
+        best_cpu = 1.0 / med
+        if phys != 16:
+            t16 = min(16, hi_["logical_cpus"])
+            med16, n16, _, _ = timed_oracle(po, tgt, src, RESOLUTION, t16, False, 10.0)
+            out["cpu_baseline_16_threads"] = {"value": 1.0 / med16, "unit": "registrations/s", "cores": t16, "threads": t16, "kind": "port",
+                                              "sample": "%d full registrations (median)" % n16, "ms_per_registration": med16 * 1e3}
+            best_cpu = max(best_cpu, 1.0 / med16)
+        # also an OPTIMISED CPU variant, so that the ratio is not inflated by the reference's own
+        # inefficiencies (rb-tree voxel lookup, N x 344 B scratch allocated, zeroed and summed per evaluation,
+        # serial f64 Hessian).  Same arithmetic per neighbour.
+        opt = {}
+        for thr in sorted({phys, min(16, hi_["logical_cpus"])}):
+            med_o, n_o, _, ro = timed_oracle(po, tgt, src, RESOLUTION, thr, True, 6.0)
+            opt[thr] = {"value": 1.0 / med_o, "ms_per_registration": med_o * 1e3, "threads": thr, "runs": n_o, "evaluations": ro["n_evals"]}
+            best_cpu = max(best_cpu, 1.0 / med_o)
+        best_thr = max(opt, key=lambda t: opt[t]["value"])
+        out["cpu_baseline_optimised"] = {
+            "value": opt[best_thr]["value"], "unit": "registrations/s", "cores": best_thr, "threads": best_thr, "kind": "port-optimised",
+            "sample": "%d full registrations (median) of the same workload, best of the thread counts tried" % opt[best_thr]["runs"],
+            "ms_per_registration": opt[best_thr]["ms_per_registration"], "by_threads": opt, "cpu_model": hi_["cpu_model"],
+            "what": "dense voxel lookup, per-thread accumulators instead of per-point result arrays, point "
+                    "derivatives once per point, parallel f64 Hessian"}
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        out["speedup_vs_best_cpu_variant"] = value / best_cpu
+
+
+# =====================================================================================================
+# legs of the batch workloads: roofline of the batch kernels (rank 0) and the RCCL lock-step form (all ranks)
+# =====================================================================================================
+def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps, dt, N_SOURCE, dev, offsets, lo, hi, T_gts, torch):
+    import numpy as np
+    n_local = hi - lo
+    if rank == 0 and n_local:
+        # one pass of the same step with a HIP event pair on the library's stream around the derivative kernels of every
+        # lock-step (ndt_profile_enable(1)); the algorithmic bytes are 8(d)'s per-evaluation figure x the scan evaluations served
+        reg.profile(1)
+        reg.profile_read(0)
+        step()
+        n_steps_timed, ms = reg.profile_read(0)
+        reg.profile(0)
+        stb = reg.stats()
+        n_scan_evals = stb["n_evals"] + stb["n_hessian_recomputes"]
+        bytes_total = n_scan_evals * algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"])
+        achieved = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["scan_evaluations_per_step_rank0"] = n_scan_evals
+        out["mean_neighbors"] = stb["mean_neighbors"]
+        committed = {}
+        prof, src_name = committed_profile("batch64_summary.json")
+        if prof and n_local == 64 and args.set == "U":
+            committed = {"traffic_committed_profile": prof.get("derivative_kernels_hbm_bytes_per_lock_step"),
+                         "traffic_committed_profile_source": src_name}
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_total / max(n_steps_timed, 1),
+                           "kernel": "k_derivatives<DIRECT7> / k_batch_step (one launch per lock-step over every live scan of rank 0's share; "
+                                     "+ k_hessian64 where a scan's line search iterated)",
+                           "avg_kernel_us": ms * 1e3 / max(n_steps_timed, 1), "launches_timed": n_steps_timed,
+                           "scan_evaluations": n_scan_evals, "scans_on_rank0": n_local,
+                           "algorithmic_bytes_per_scan_evaluation": algorithmic_bytes_per_eval(N_SOURCE, stb["mean_neighbors"]),
+                           "kernel_time_share_of_step": ms / (dt / steps * 1e3),
+                           "how": "one hipEvent pair per lock-step on the library stream around the derivative kernels "
+                                  "(ndt_profile_enable(1)), one extra pass of the same step"}
+        out["roofline"].update(committed)
+    # ---- the literal north_star form: scans sharded, ONE RCCL all-reduce of the [n_scans][32] f64 rows per lock-step ----
+    if workload == "mapbuild" and world > 1 and not args.no_lockstep_leg:
+        result = {}
+        done = threading.Event()
+
+        def watchdog():  # a collective that never completes must not take the measured line down with it
+            if not done.wait(180.0):
+                if rank == 0:
+                    out["lockstep_allreduce"] = {"error": "timed out after 180 s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            uid = torch.zeros(ndt.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.from_numpy(np.frombuffer(ndt.comm_get_unique_id(), dtype=np.uint8).copy())
+            uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            kw = dict(device_ptr=dev.data_ptr() if dev is not None else 0, offsets=offsets, stride_bytes=16,
+                      first_scan=lo, total_scans=args.scans)
+            res = reg.alignBatchSharded(**kw)  # warm-up (communicator set-up, first collective)
+            torch.cuda.synchronize()
+            dist.barrier()
+            ta = time.perf_counter()
+            res = reg.alignBatchSharded(**kw)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tl = time.perf_counter() - ta
+            t = torch.tensor([tl], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ok = 0
+            for k, Tg in enumerate(T_gts):
+                ok += int(near_T_gt(res["T"][lo + k], Tg))
+            okt = torch.tensor([float(ok)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(okt)
+            cs = reg.commStats()
+            result = {"value": args.scans / float(t.item()), "unit": "registrations/s", "ms_per_step": float(t.item()) * 1e3,
+                      "registrations_ending_at_T_gt": int(okt.item()), "lock_steps": cs["collectives"],
+                      "allreduce_doubles_per_lock_step": args.scans * 32, "rccl_world_size": cs["world"],
+                      "what": "every rank steps all %d solvers; rows of the scans a rank does not own are zero; one in-place "
+                              "ncclAllReduce(sum) of the [%d][32] f64 buffer per lock-step on the library stream (C++, ndt_comm_*)" % (args.scans, args.scans)}
+            reg.commDestroy()
+        except Exception as e:
+            result = {"error": repr(e)}
+        done.set()
+        if rank == 0:
+            out["lockstep_allreduce"] = result
+
+
+# =====================================================================================================
+# configs[4]: multi-resolution NDT (2.0 -> 1.0 -> 0.5 m) on a streamed sequence of 2M-pt PCD scans
+# =====================================================================================================
+def run_pyramid(args, ndt, clouds, tgt, device, steps, warmup, binding):
+    import tempfile
+    import numpy as np
+    from toyslam_amd import pyramid
+    n_scans, n_src = args.seq_scans, 2000000
+    tmp = tempfile.mkdtemp(prefix="ndt_seq_")
+    T_gts = pyramid.write_sequence(tmp, tgt, n_scans, n_src)
+    pyr = pyramid.Pyramid(levels=(2.0, 1.0, 0.5), device=device)
+    t0 = time.perf_counter()
+    pyr.setInputTarget(tgt)
+    t_build = time.perf_counter() - t0
+    best = None
+    for _ in range(max(1, warmup + steps)):
+        r = pyr.run_sequence(tmp)
+        if best is None or r["seconds"] < best["seconds"]:
+            best = r
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    ok = sum(int(np.abs(T[:3, :3] - Tg[:3, :3]).max() < 5e-4 and np.abs(T[:3, 3] - Tg[:3, 3]).max() < 2e-2) for T, Tg in zip(best["T"], T_gts))
+    return {"metric": "scans/sec (2M-pt scans, 2.0->1.0->0.5 m pyramid vs 10M-pt target, streamed PCD sequence)",
+            "value": n_scans / best["seconds"], "unit": "scans/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": best["seconds"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[4]: %d x 2M-pt PCD scans streamed from disk (read-ahead thread, page-locked buffers), "
+                                   "three resident grids 2.0 / 1.0 / 0.5 m over one 10M-pt target (%g m scene), each level's result the "
+                                   "next level's guess" % (n_scans, args.extent)},
+            "per_level_ms": best["per_level_ms"], "upload_ms_per_scan": best["upload_ms"], "wait_for_file_ms_per_scan": best["wait_ms"],
+            "grids_build_ms": t_build * 1e3, "scans_ending_at_T_gt": ok, "evaluations_per_scan": best["evals_per_scan"],
+            "host_binding": binding}
 
 
 if __name__ == "__main__":

@@ -84,6 +84,11 @@ ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t 
 /* Same, for clouds already resident in HBM (device pointers on the handle's device). */
 ndt_status ndt_set_input_target_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense);
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+/* One uploaded (and spatially ordered) source cloud serving several handles on the same device, the way ndt_clone
+ * shares it: `dst` registers the cloud `src` holds.  The levels of a multi-resolution pyramid (BASELINE configs[4]:
+ * 2.0 -> 1.0 -> 0.5 m grids over one target, one handle per grid) take every scan from one upload this way, and a
+ * second donor handle can upload the next scan on its own stream meanwhile. */
+ndt_status ndt_share_input_source(ndt_handle dst, ndt_handle src);
 
 /* ---- registration --------------------------------------------------------
  * pcl::Registration::align(output, guess) -> computeTransformation
@@ -198,11 +203,41 @@ ndt_status ndt_align_batch_device(ndt_handle h, const void* d_pts, const size_t*
                                   size_t stride_bytes, const float* guesses, float* final_transformations,
                                   int* has_converged, int* final_num_iteration, double* transformation_probability);
 
-/* Optional exchange step for multi-GPU lock-step batches / point-sharded scans:
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------
+ * The reference is a single process (ndt_omp_impl.hpp:206 is its only parallel construct); this is the exchange step
+ * north_star adds.  Registrations of different scans are independent, so ndt_align_batch* on every rank over its own
+ * share of the scans needs NO collective (what bench.py measures at N > 1).  Two uses of a communicator remain:
+ *  - ndt_align_batch_sharded*: the literal lock-step form -- the batch has total_scans scans, this rank holds scans
+ *    [first_scan, first_scan + n_local) (offsets: n_local + 1 entries into ITS points); every rank steps all
+ *    total_scans Newton / More-Thuente state machines, rows of the scans a rank does not hold are zero, and ONE in-place
+ *    SUM all-reduce of the [total_scans][NDT_EVAL_STRIDE] f64 buffer per lock-step gives every rank every row.
+ *    guesses and the per-scan outputs have total_scans entries and come out identical on every rank.
+ *  - ndt_align with a communicator set: the source cloud each rank holds is a SHARD of one big scan (target replicated);
+ *    the 32-f64 row of every evaluation is all-reduced, so all ranks walk the same registration.
+ * The collective is issued from C++ on the handle's own stream (no host synchronisation around it); librccl is loaded
+ * on first use.  ndt_comm_get_unique_id (rank 0) wraps ncclGetUniqueId; the caller carries the NDT_COMM_ID_BYTES to
+ * the other ranks (MPI, a file, torch.distributed ...), then every rank calls ndt_comm_init_rank on its own device. */
+#define NDT_COMM_ID_BYTES 128
+ndt_status ndt_comm_get_unique_id(void* id_out /* NDT_COMM_ID_BYTES */);
+ndt_status ndt_comm_init_rank(ndt_handle h, const void* id, int rank, int world_size);
+ndt_status ndt_comm_destroy(ndt_handle h);
+/* rank / world size of the handle's communicator (-1 / 0 without one), collectives issued since ndt_comm_init_rank,
+ * lock-steps of the last ndt_align_batch* call (any may be NULL) */
+ndt_status ndt_comm_stats(ndt_handle h, int* rank, int* world_size, long long* n_collectives, int* lock_steps);
+ndt_status ndt_align_batch_sharded(ndt_handle h, const void* pts, const size_t* offsets /* n_local+1 */, size_t n_local,
+                                   size_t first_scan, size_t total_scans, size_t stride_bytes,
+                                   const float* guesses /* total_scans*16 or NULL */, float* final_transformations /* total_scans*16 */,
+                                   int* has_converged, int* final_num_iteration, double* transformation_probability);
+ndt_status ndt_align_batch_sharded_device(ndt_handle h, const void* d_pts, const size_t* offsets, size_t n_local,
+                                          size_t first_scan, size_t total_scans, size_t stride_bytes, const float* guesses,
+                                          float* final_transformations, int* has_converged, int* final_num_iteration,
+                                          double* transformation_probability);
+
+/* Caller-supplied exchange step (tests over gloo; any collective library the caller already has):
  * after every fused evaluation the packed [n_rows][NDT_EVAL_STRIDE] f64 result
  * buffer is handed to `fn` for an in-place SUM all-reduce across ranks
- * (RCCL on the device buffer when `on_device` != 0, host buffer otherwise).
- * fn returns 0 on success. */
+ * (the device buffer when `on_device` != 0, a host copy otherwise).  Not stream-ordered: the library synchronises
+ * around the call.  A communicator set with ndt_comm_init_rank takes precedence.  fn returns 0 on success. */
 #define NDT_EVAL_STRIDE 32 /* score, g[6], H upper-tri[21], n_neighbors, 3 spare */
 typedef int (*ndt_allreduce_fn)(void* buf, size_t n_doubles, int on_device, void* user);
 ndt_status ndt_set_allreduce(ndt_handle h, ndt_allreduce_fn fn, void* user, int on_device);

@@ -14,6 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 NDT_OK, NDT_ERR_INVALID, NDT_ERR_NO_DEVICE, NDT_ERR_HIP, NDT_ERR_GRID_OVERFLOW, NDT_ERR_NO_INPUT, NDT_ERR_COMM = range(7)
 KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 EVAL_STRIDE = 32
+COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 EVAL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "ndt_set_input_source": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
     "ndt_set_input_target_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int]),
     "ndt_set_input_source_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "ndt_share_input_source": (C.c_int, [vp, vp]),
     "ndt_align": (C.c_int, [vp, fp, fp, ip, ip, dp, vp, C.c_size_t]),
     "ndt_get_result": (C.c_int, [vp, fp, ip, ip, dp]),
     "ndt_get_output_device": (C.c_int, [vp, C.POINTER(vp), szp]),
@@ -83,6 +85,12 @@ SIGNATURES = {
     "ndt_align_batch": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_align_batch_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int]),
+    "ndt_align_batch_sharded": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
+    "ndt_align_batch_sharded_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
+    "ndt_comm_get_unique_id": (C.c_int, [vp]),
+    "ndt_comm_init_rank": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "ndt_comm_destroy": (C.c_int, [vp]),
+    "ndt_comm_stats": (C.c_int, [vp, ip, ip, C.POINTER(C.c_longlong), ip]),
     "ndt_eval": (C.c_int, [vp, dp, dp, dp, dp, dp]),
     "ndt_eval_with_matrix": (C.c_int, [vp, fp, dp, dp, dp, dp, dp]),
     "ndt_eval_hessian_f64": (C.c_int, [vp, dp, dp]),

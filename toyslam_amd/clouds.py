@@ -169,3 +169,11 @@ def random_T(rng, max_t=0.5, max_deg=2.0):
     t = rng.uniform(-max_t, max_t, 3)
     r = np.deg2rad(rng.uniform(-max_deg, max_deg, 3))
     return make_T(t, r)
+
+
+def mapbuild_scan(target, k, n=100000, max_t=0.5, max_deg=2.0):
+    """Scan k of the map-build workload (BASELINE configs[3]): n target points + noise moved by its
+    own T_gt,k drawn U(+-0.5 m, +-2 deg).  Seeds depend on k only, so the workload is the same however it is split over
+    ranks.  -> (scan, T_gt)"""
+    T = random_T(np.random.default_rng(SEED + 100 + k), max_t, max_deg)
+    return source_from_target(target, n, T_gt=T, seed=SEED + 1000 + 2 * k), T

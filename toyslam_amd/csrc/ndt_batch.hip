@@ -2,6 +2,9 @@
 // (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
 #include "ndt_internal.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is dlopen'ed (no link-time dependency)
+
 namespace ndtc {
 
 // Small spinning worker pool for the per-step host work of a lock-step batch (one Newton /
@@ -59,33 +62,171 @@ class StepPool {
 
 }  // namespace ndtc
 
+// ---- RCCL over xGMI (one process per GPU) -------------------------------------------------------------
+// librccl is loaded on first use (dlopen by soname: inside a process that already holds an RCCL -- e.g. PyTorch's --
+// the loader hands back that same copy, bound to the same HIP runtime this library is bound to).
+namespace ndtc {
+
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+
+static Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      const char* e = dlerror();
+      r.error = std::string("cannot load librccl: ") + (e ? e : "?");
+      return;
+    }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) r.error = "librccl lacks an expected symbol";
+  });
+  return r.error.empty() ? &r : nullptr;
+}
+
+static ndt_status rccl_fail(const char* what, ncclResult_t e) {
+  Rccl* r = rccl();
+  return fail(NDT_ERR_COMM, std::string(what) + " failed: " + (r ? r->GetErrorString(e) : "librccl unavailable"));
+}
+
+void comm_release(ndt_context* h) {
+  if (!h->comm) return;
+  if (Rccl* r = rccl()) (void)r->CommDestroy(static_cast<ncclComm_t>(h->comm));
+  h->comm = nullptr;
+  h->comm_rank = 0;
+  h->comm_world = 1;
+}
+
+// in-place SUM of n f64 on the handle's stream (stream-ordered: nothing waits on the host)
+ndt_status comm_allreduce(ndt_context* h, double* d_buf, size_t n) {
+  Rccl* r = rccl();
+  if (!r || !h->comm) return fail(NDT_ERR_COMM, "no communicator");
+  const ncclResult_t e = r->AllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, static_cast<ncclComm_t>(h->comm), h->stream);
+  if (e != ncclSuccess) return rccl_fail("ncclAllReduce", e);
+  h->comm_collectives++;
+  return NDT_OK;
+}
+
+// waits until slot 31 of every listed row of the pinned result block carries `seq`
+template <class LiveFn>
+static ndt_status poll_rows(ndt_context* h, size_t n_rows, unsigned long long seq, const LiveFn& live) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (size_t k = 0; k < n_rows; k++) {
+    if (!live(k)) continue;
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result + k * ndt::kEvalStride) + (ndt::kEvalStride - 1);
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+          return fail(NDT_ERR_HIP, "batch step finished without publishing its results");
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+          return fail(NDT_ERR_HIP, "timed out waiting for the batch step");
+      }
+    }
+  }
+  return NDT_OK;
+}
+
+}  // namespace ndtc
+
 extern "C" {
 
 // ---- batch ---------------------------------------------------------------
-static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
+// Lock-step registration of `total` scans of which this rank holds scans [first, first + n_local) (plain batch:
+// first = 0, n_local = total).  Every rank steps all `total` Newton / More-Thuente state machines; a rank evaluates
+// only the scans it holds, the rows of the others stay zero, and ONE in-place SUM all-reduce of the [total][32] f64
+// buffer per lock-step gives every rank every row (the exchange step of north_star's map-build mode).
+static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* offsets, size_t n_local, size_t stride,
                                    bool on_device, const float* guesses, float* final_T, int* conv, int* iters,
-                                   double* tprob) {
+                                   double* tprob, size_t first = 0, size_t total = 0) {
   if (!h || !offsets) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");
-  if (n_scans == 0) return NDT_OK;
-  if (n_scans > 65535) return fail(NDT_ERR_INVALID, "at most 65535 scans per batch");
-  for (size_t k = 0; k < n_scans; k++)
+  const bool sharded = total != 0;
+  if (!sharded) total = n_local;
+  if (first + n_local > total) return fail(NDT_ERR_INVALID, "scan range outside the batch");
+  const bool exchange = h->comm != nullptr || h->allreduce != nullptr;
+  if (sharded && n_local != total && !exchange)
+    return fail(NDT_ERR_COMM, "a sharded batch needs a communicator (ndt_comm_init_rank) or an all-reduce hook");
+  if (total == 0) return NDT_OK;
+  if (total > 65535) return fail(NDT_ERR_INVALID, "at most 65535 scans per batch");
+  for (size_t k = 0; k < n_local; k++)
     if (offsets[k + 1] < offsets[k]) return fail(NDT_ERR_INVALID, "offsets must be non-decreasing");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
   std::shared_ptr<DeviceCloud> cloud;
-  const unsigned char* base = static_cast<const unsigned char*>(pts) + offsets[0] * stride;
-  const size_t total = offsets[n_scans] - offsets[0];
-  ndt_status s = upload_cloud(h, base, total, stride, on_device, cloud);
+  const size_t n_pts = n_local ? offsets[n_local] - offsets[0] : 0;
+  const unsigned char* base = n_local ? static_cast<const unsigned char*>(pts) + offsets[0] * stride : nullptr;
+  s = upload_cloud(h, base, n_pts, stride, on_device, cloud);
   if (s) return s;
-  s = order_cloud(h, cloud.get(), offsets, n_scans);
-  if (s) return s;
+  if (n_local) {
+    s = order_cloud(h, cloud.get(), offsets, n_local);
+    if (s) return s;
+  }
   const bool use_sorted = cloud->n_sorted > 0 && !cloud->scan_counts.empty();
   const float4* batch_pts = use_sorted ? cloud->sorted.p : cloud->pts.p;
-  s = ensure_host_rows(h, n_scans);
+  s = ensure_host_rows(h, total);
   if (s) return s;
+  HIP_TRY(h->batch_out.reserve(total * ndt::kEvalStride));
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
-  std::vector<ndt::ScanSolver> solvers(n_scans);
+  auto is_local = [&](size_t g) { return g >= first && g < first + n_local; };
+
+  // one exchange of the packed rows: device buffer -> [all-reduce] -> pinned host rows (every row, tagged with seq)
+  auto exchange_rows = [&](const std::function<bool(size_t)>& live) -> ndt_status {
+    if (h->comm) {
+      ndt_status sc = comm_allreduce(h, h->batch_out.p, total * ndt::kEvalStride);
+      if (sc) return sc;
+      const unsigned long long seq = ++h->eval_seq;
+      HIP_TRY(ndt::launch_publish_rows(h->batch_out.p, static_cast<int>(total), h->host_result, seq, h->stream));
+      return poll_rows(h, total, seq, live);
+    }
+    // caller-supplied collective (host tests over gloo; torch.distributed on the device buffer): not stream-ordered
+    if (h->allreduce_on_device) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->allreduce(h->batch_out.p, total * ndt::kEvalStride, 1, h->allreduce_user)) return fail(NDT_ERR_COMM, "allreduce callback failed");
+    }
+    HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, total * ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->allreduce_on_device && h->allreduce(h->host_result, total * ndt::kEvalStride, 0, h->allreduce_user))
+      return fail(NDT_ERR_COMM, "allreduce callback failed");
+    return NDT_OK;
+  };
+
+  // every rank needs every scan's point count (transformation_probability = score / N): one exchange up front
+  std::vector<size_t> counts(total, 0);
+  for (size_t k = 0; k < n_local; k++) counts[first + k] = offsets[k + 1] - offsets[k];
+  if (sharded && exchange) {
+    std::vector<double> rows(total * ndt::kEvalStride, 0.0);
+    for (size_t k = 0; k < n_local; k++) rows[(first + k) * ndt::kEvalStride] = static_cast<double>(counts[first + k]);
+    HIP_TRY(hipMemcpyAsync(h->batch_out.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // `rows` is pageable and goes out of scope
+    s = exchange_rows([](size_t) { return true; });
+    if (s) return s;
+    for (size_t g = 0; g < total; g++) counts[g] = static_cast<size_t>(h->host_result[g * ndt::kEvalStride]);
+  }
+
+  std::vector<ndt::ScanSolver> solvers(total);
   // per-step descriptors live in pinned host memory: the H2D copies are then truly asynchronous
-  const size_t pinned_need = n_scans * sizeof(ndt::ScanDesc) + 4 * n_scans * sizeof(int);  // + per-kind and all-kinds active lists
+  const size_t pinned_need = total * sizeof(ndt::ScanDesc) + 4 * total * sizeof(int);  // + per-kind and all-kinds active lists
   if (pinned_need > h->batch_pinned_bytes) {
     if (h->batch_pinned) (void)hipHostFree(h->batch_pinned);
     h->batch_pinned = nullptr;
@@ -94,22 +235,27 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     h->batch_pinned_bytes = pinned_need;
   }
   ndt::ScanDesc* descs = static_cast<ndt::ScanDesc*>(h->batch_pinned);
-  int* active = reinterpret_cast<int*>(descs + n_scans);
+  int* active = reinterpret_cast<int*>(descs + total);
+  std::vector<int> live_kind(total, ndt::EVAL_NONE);  // what every scan's solver asked for this step, local or not
   size_t max_n = 0;
-  for (size_t k = 0; k < n_scans; k++) {
-    const size_t cnt = offsets[k + 1] - offsets[k];
-    solvers[k].start(guesses ? guesses + 16 * k : nullptr, cnt, solver_params(h));
-    descs[k].offset = static_cast<int>(use_sorted ? cloud->scan_starts[k] : offsets[k] - offsets[0]);
-    descs[k].count = static_cast<int>(use_sorted ? cloud->scan_counts[k] : cnt);
-    descs[k].pad = 0;
-    max_n = std::max(max_n, cnt);
+  for (size_t g = 0; g < total; g++) {
+    solvers[g].start(guesses ? guesses + 16 * g : nullptr, counts[g], solver_params(h));
+    descs[g].offset = 0;
+    descs[g].count = 0;
+    descs[g].pad = 0;
+    descs[g].kind = ndt::EVAL_NONE;
+    if (is_local(g)) {
+      const size_t k = g - first;
+      descs[g].offset = static_cast<int>(use_sorted ? cloud->scan_starts[k] : offsets[k] - offsets[0]);
+      descs[g].count = static_cast<int>(use_sorted ? cloud->scan_counts[k] : counts[g]);
+      max_n = std::max(max_n, counts[g]);
+    }
   }
   // rows of partials reserved per scan; the blocks actually used per scan follow the number of
   // scans that want the same kind of evaluation in a step (few active scans -> more blocks each)
   const int max_blocks = ndt::derivative_blocks(static_cast<int>(max_n), h->search);
   constexpr int kBlockBudget = 4096;
-  HIP_TRY(h->partials.reserve(n_scans * max_blocks * ndt::kEvalStride));
-  HIP_TRY(h->batch_out.reserve(n_scans * ndt::kEvalStride));
+  HIP_TRY(h->partials.reserve(total * max_blocks * ndt::kEvalStride));
   HIP_TRY(h->descs.reserve((pinned_need + sizeof(ndt::ScanDesc) - 1) / sizeof(ndt::ScanDesc)));  // descriptors + the 3 active lists
   const ndt::GridView gv = h->grid->view();
   const bool degenerate = h->grid->empty;
@@ -118,12 +264,12 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     if (v) return std::max(1, atoi(v));
     return static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
   }();
-  StepPool pool(n_scans >= 32 ? n_host_threads : 1);
+  StepPool pool(total >= 32 ? n_host_threads : 1);
   static const bool batch_timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   double t_fill = 0, t_gpu = 0, t_feed = 0;
   int n_steps = 0;
   // ndt_get_stats after a batch: scan evaluations (f32 kinds) / f64 Hessian recomputes of all scans, neighbours per point
-  std::vector<double> nn_row(n_scans, 0.0);
+  std::vector<double> nn_row(total, 0.0);
   double nn_sum = 0, pts_sum = 0;
   long long evals_f32 = 0, evals_h64 = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -131,90 +277,70 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   for (;;) {
     const auto tb0 = now();
     int n_act[3] = {0, 0, 0};
-    for (size_t k = 0; k < n_scans; k++) {
-      if (solvers[k].done()) {
-        descs[k].kind = ndt::EVAL_NONE;
-        continue;
-      }
-      const int kind = solvers[k].request().kind;
-      descs[k].kind = kind;
-      active[kind * n_scans + n_act[kind]++] = static_cast<int>(k);
+    int n_live_all = 0;
+    for (size_t g = 0; g < total; g++) {
+      descs[g].kind = ndt::EVAL_NONE;
+      live_kind[g] = ndt::EVAL_NONE;
+      if (solvers[g].done()) continue;
+      const int kind = solvers[g].request().kind;
+      live_kind[g] = kind;
+      n_live_all++;
+      if (!is_local(g)) continue;  // somebody else's scan: its row arrives with the exchange
+      descs[g].kind = kind;
+      active[kind * total + n_act[kind]++] = static_cast<int>(g);
     }
-    if (n_act[0] + n_act[1] + n_act[2] == 0) break;
+    if (n_live_all == 0) break;
     int nblk_kind[3];
     for (int c = 0; c < 3; c++) nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / std::max(1, n_act[c])));
     // scans asking for different kinds in the same step: one launch over all of them
     const int n_live = n_act[0] + n_act[1] + n_act[2];
     const bool mixed = (n_act[0] != n_live && n_act[1] != n_live && n_act[2] != n_live) && ndt::derivative_variant() == 0;
     if (mixed) {
-      int* all = active + 3 * n_scans;
+      int* all = active + 3 * total;
       int m = 0;
       for (int c = 0; c < 3; c++) {
         nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / n_live));
-        for (int i = 0; i < n_act[c]; i++) all[m++] = active[c * n_scans + i];
+        for (int i = 0; i < n_act[c]; i++) all[m++] = active[c * total + i];
       }
     }
-    pool.run(n_scans, [&](size_t k) {  // per-scan parameter tables (sin/cos, pose -> matrix)
-      if (descs[k].kind == ndt::EVAL_NONE) return;
-      const ndt::EvalRequest& rq = solvers[k].request();
-      descs[k].pad = nblk_kind[descs[k].kind];
-      if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, kd_radius2(h->resolution), descs[k].P64);
-      else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[k].P);
+    pool.run(total, [&](size_t g) {  // per-scan parameter tables (sin/cos, pose -> matrix)
+      if (descs[g].kind == ndt::EVAL_NONE) return;
+      const ndt::EvalRequest& rq = solvers[g].request();
+      descs[g].pad = nblk_kind[descs[g].kind];
+      if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, kd_radius2(h->resolution), descs[g].P64);
+      else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[g].P);
     });
     const auto tb1 = now();
     if (degenerate) {
-      std::memset(h->host_result, 0, n_scans * ndt::kEvalStride * sizeof(double));
+      std::memset(h->host_result, 0, total * ndt::kEvalStride * sizeof(double));
     } else {
       // one H2D copy: descriptors and the three active lists are contiguous in the pinned block
       HIP_TRY(hipMemcpyAsync(h->descs.p, descs, pinned_need, hipMemcpyHostToDevice, h->stream));
-      const int* d_active = reinterpret_cast<const int*>(h->descs.p + n_scans);
+      const int* d_active = reinterpret_cast<const int*>(h->descs.p + total);
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};
+      if (exchange) HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, total * ndt::kEvalStride * sizeof(double), h->stream));
       if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
       if (mixed) {
-        HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * n_scans, n_live, max_blocks, nblk_kind[0], h->partials.p, h->stream));
+        HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * total, n_live, max_blocks, nblk_kind[0], h->partials.p, h->stream));
       } else {
         if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, d_active, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));
-        if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + n_scans, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
-        if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * n_scans, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
+        if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + total, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
+        if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * total, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
       }
       if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-      if (h->allreduce) {
-        HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->batch_out.p, h->stream));
-        if (h->allreduce_on_device) {
-          HIP_TRY(hipStreamSynchronize(h->stream));
-          if (h->allreduce(h->batch_out.p, n_scans * ndt::kEvalStride, 1, h->allreduce_user))
-            return fail(NDT_ERR_COMM, "allreduce callback failed");
-        }
-        HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, n_scans * ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (!h->allreduce_on_device) {
-          if (h->allreduce(h->host_result, n_scans * ndt::kEvalStride, 0, h->allreduce_user))
-            return fail(NDT_ERR_COMM, "allreduce callback failed");
-        }
+      if (exchange) {
+        // rows of this rank's live scans; everything else stays zero for the SUM
+        if (n_live) HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(total), h->descs.p, h->batch_out.p, h->stream));
+        s = exchange_rows([&](size_t g) { return live_kind[g] != ndt::EVAL_NONE; });
+        if (s) return s;
       } else {
         // the reduce kernel writes every live scan's row and then its sequence word (slot 31)
         // straight into pinned host memory; poll those instead of a D2H copy + stream synchronise
         const unsigned long long seq = ++h->eval_seq;
-        HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(n_scans), h->descs.p, h->host_result, h->stream, seq));
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        for (size_t k = 0; k < n_scans; k++) {
-          if (descs[k].kind == ndt::EVAL_NONE) continue;
-          volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_result + k * ndt::kEvalStride) + (ndt::kEvalStride - 1);
-          while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFF) == 0) {
-              if (hipStreamQuery(h->stream) != hipErrorNotReady) {
-                HIP_TRY(hipStreamSynchronize(h->stream));
-                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
-                return fail(NDT_ERR_HIP, "batch step finished without publishing its results");
-              }
-              if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-                return fail(NDT_ERR_HIP, "timed out waiting for the batch step");
-            }
-          }
-        }
+        HIP_TRY(ndt::launch_reduce(h->partials.p, max_blocks, static_cast<int>(total), h->descs.p, h->host_result, h->stream, seq));
+        s = poll_rows(h, total, seq, [&](size_t g) { return live_kind[g] != ndt::EVAL_NONE; });
+        if (s) return s;
       }
     }
     const auto tb2 = now();
@@ -225,20 +351,20 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       h->prof_n[0]++;
       h->prof_ms[0] += ms;
     }
-    pool.run(n_scans, [&](size_t k) {  // Newton / More-Thuente step of every live scan
-      if (descs[k].kind == ndt::EVAL_NONE) return;
+    pool.run(total, [&](size_t g) {  // Newton / More-Thuente step of every live scan
+      if (live_kind[g] == ndt::EVAL_NONE) return;
       ndt::EvalResult r;
-      unpack_row(h->host_result + k * ndt::kEvalStride, descs[k].kind != ndt::EVAL_NO_HESSIAN, r, &nn_row[k]);
-      solvers[k].feed(r);
+      unpack_row(h->host_result + g * ndt::kEvalStride, live_kind[g] != ndt::EVAL_NO_HESSIAN, r, &nn_row[g]);
+      solvers[g].feed(r);
     });
-    for (size_t k = 0; k < n_scans; k++) {
-      if (descs[k].kind == ndt::EVAL_NONE) continue;
-      if (descs[k].kind == ndt::EVAL_HESSIAN_F64) {
+    for (size_t g = 0; g < total; g++) {
+      if (live_kind[g] == ndt::EVAL_NONE) continue;
+      if (live_kind[g] == ndt::EVAL_HESSIAN_F64) {
         evals_h64++;
       } else {
         evals_f32++;
-        nn_sum += nn_row[k];
-        pts_sum += static_cast<double>(offsets[k + 1] - offsets[k]);
+        nn_sum += nn_row[g];
+        pts_sum += static_cast<double>(counts[g]);
       }
     }
     const auto tb3 = now();
@@ -250,16 +376,17 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     n_steps++;
   }
   if (batch_timing)
-    std::fprintf(stderr, "[ndt batch timing] scans=%zu steps=%d fill=%.1fus gpu(launch+wait)=%.1fus feed=%.1fus per step\n", n_scans,
+    std::fprintf(stderr, "[ndt batch timing] scans=%zu (local %zu) steps=%d fill=%.1fus gpu(launch+wait)=%.1fus feed=%.1fus per step\n", total, n_local,
                  n_steps, t_fill / std::max(1, n_steps) * 1e6, t_gpu / std::max(1, n_steps) * 1e6, t_feed / std::max(1, n_steps) * 1e6);
   h->n_evals = static_cast<int>(std::min<long long>(evals_f32, INT32_MAX));
   h->n_hess = static_cast<int>(std::min<long long>(evals_h64, INT32_MAX));
   h->mean_neighbors = pts_sum > 0 ? nn_sum / pts_sum : 0.0;
-  for (size_t k = 0; k < n_scans; k++) {
-    if (final_T) std::memcpy(final_T + 16 * k, solvers[k].final_T, 16 * sizeof(float));
-    if (conv) conv[k] = solvers[k].converged ? 1 : 0;
-    if (iters) iters[k] = solvers[k].nr_iterations;
-    if (tprob) tprob[k] = solvers[k].trans_probability;
+  h->batch_lock_steps = n_steps;
+  for (size_t g = 0; g < total; g++) {
+    if (final_T) std::memcpy(final_T + 16 * g, solvers[g].final_T, 16 * sizeof(float));
+    if (conv) conv[g] = solvers[g].converged ? 1 : 0;
+    if (iters) iters[g] = solvers[g].nr_iterations;
+    if (tprob) tprob[g] = solvers[g].trans_probability;
   }
   return NDT_OK;
 }
@@ -272,12 +399,75 @@ ndt_status ndt_align_batch_device(ndt_handle h, const void* pts, const size_t* o
                                   const float* guesses, float* final_T, int* conv, int* iters, double* tprob) {
   return align_batch_impl(h, pts, offsets, n_scans, stride, true, guesses, final_T, conv, iters, tprob);
 }
+ndt_status ndt_align_batch_sharded(ndt_handle h, const void* pts, const size_t* offsets, size_t n_local, size_t first_scan,
+                                   size_t total_scans, size_t stride, const float* guesses, float* final_T, int* conv, int* iters,
+                                   double* tprob) {
+  if (total_scans == 0) return fail(NDT_ERR_INVALID, "total_scans must be > 0");
+  return align_batch_impl(h, pts, offsets, n_local, stride, false, guesses, final_T, conv, iters, tprob, first_scan, total_scans);
+}
+ndt_status ndt_align_batch_sharded_device(ndt_handle h, const void* d_pts, const size_t* offsets, size_t n_local, size_t first_scan,
+                                          size_t total_scans, size_t stride, const float* guesses, float* final_T, int* conv,
+                                          int* iters, double* tprob) {
+  if (total_scans == 0) return fail(NDT_ERR_INVALID, "total_scans must be > 0");
+  return align_batch_impl(h, d_pts, offsets, n_local, stride, true, guesses, final_T, conv, iters, tprob, first_scan, total_scans);
+}
 
 ndt_status ndt_set_allreduce(ndt_handle h, ndt_allreduce_fn fn, void* user, int on_device) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   h->allreduce = fn;
   h->allreduce_user = user;
   h->allreduce_on_device = on_device;
+  return NDT_OK;
+}
+
+// ---- communicator ------------------------------------------------------------------------------------
+ndt_status ndt_comm_get_unique_id(void* id_out) {
+  if (!id_out) return fail(NDT_ERR_INVALID, "null id buffer");
+  static_assert(sizeof(ncclUniqueId) == NDT_COMM_ID_BYTES, "NDT_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+  Rccl* r = rccl();
+  if (!r) return fail(NDT_ERR_COMM, "librccl is not available");
+  ncclUniqueId id;
+  const ncclResult_t e = r->GetUniqueId(&id);
+  if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
+  std::memcpy(id_out, &id, sizeof(id));
+  return NDT_OK;
+}
+
+ndt_status ndt_comm_init_rank(ndt_handle h, const void* id, int rank, int world_size) {
+  if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  Rccl* r = rccl();
+  if (!r) return fail(NDT_ERR_COMM, "librccl is not available");
+  comm_release(h);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t c = nullptr;
+  const ncclResult_t e = r->CommInitRank(&c, world_size, uid, rank);  // on the handle's device (set by ensure_device)
+  if (e != ncclSuccess) return rccl_fail("ncclCommInitRank", e);
+  h->comm = c;
+  h->comm_rank = rank;
+  h->comm_world = world_size;
+  h->comm_collectives = 0;
+  return NDT_OK;
+}
+
+ndt_status ndt_comm_destroy(ndt_handle h) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (h->device_ready) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  comm_release(h);
+  return NDT_OK;
+}
+
+ndt_status ndt_comm_stats(ndt_handle h, int* rank, int* world_size, long long* n_collectives, int* lock_steps) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (rank) *rank = h->comm ? h->comm_rank : -1;
+  if (world_size) *world_size = h->comm ? h->comm_world : 0;
+  if (n_collectives) *n_collectives = h->comm_collectives;
+  if (lock_steps) *lock_steps = h->batch_lock_steps;
   return NDT_OK;
 }
 

@@ -68,14 +68,14 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   ndt_status s = ensure_host_rows(h, 1);
   if (s) return s;
-  if (h->source->n == 0 || n == 0 || h->grid->empty) {  // nothing contributes
+  if (h->grid->empty || ((h->source->n == 0 || n == 0) && !h->comm)) {  // nothing contributes (an empty SHARD still joins the collective)
     std::memset(&res, 0, sizeof(res));
     if (nn_total) *nn_total = 0;
     return NDT_OK;
   }
   static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
   static const bool fuse = [] { const char* v = getenv("NDT_K2_FUSED"); return v ? atoi(v) != 0 : true; }();
-  const bool fused = fuse && spin_wait && rq.kind != ndt::EVAL_HESSIAN_F64 && ndt::derivative_variant() == 0 && !h->allreduce;
+  const bool fused = fuse && spin_wait && rq.kind != ndt::EVAL_HESSIAN_F64 && ndt::derivative_variant() == 0 && !h->allreduce && !h->comm;
   const int nblk = fused ? ndt::fused_blocks(n) : ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   if (!h->ticket.p) {
@@ -108,7 +108,16 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     // host memory; poll it instead of paying a stream synchronisation per evaluation.
     if (!fused) {
       seq = ++h->eval_seq;
-      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream, seq));
+      if (h->comm) {
+        // point-sharded scan: this rank's row -> in-place SUM over the ranks (RCCL, same stream) -> pinned host row
+        HIP_TRY(h->batch_out.reserve(ndt::kEvalStride));
+        HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->batch_out.p, h->stream));
+        ndt_status sc = comm_allreduce(h, h->batch_out.p, ndt::kEvalStride);
+        if (sc) return sc;
+        HIP_TRY(ndt::launch_publish_rows(h->batch_out.p, 1, h->host_result, seq, h->stream));
+      } else {
+        HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream, seq));
+      }
     }
     const auto tp1 = std::chrono::steady_clock::now();
     h->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
@@ -131,7 +140,15 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     if (fused) pub_gather(h->host_pub, h->host_result);
     h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
   } else {
-    if (!fused) HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+    if (!fused && h->comm) {
+      HIP_TRY(h->batch_out.reserve(ndt::kEvalStride));
+      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->batch_out.p, h->stream));
+      ndt_status sc = comm_allreduce(h, h->batch_out.p, ndt::kEvalStride);
+      if (sc) return sc;
+      HIP_TRY(hipMemcpyAsync(h->host_result, h->batch_out.p, ndt::kEvalStride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else if (!fused) {
+      HIP_TRY(ndt::launch_reduce(h->partials.p, nblk, 1, nullptr, h->host_result, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (fused) {
       if (!pub_ready(h->host_pub, seq)) return fail(NDT_ERR_HIP, "evaluation finished without publishing its result");
@@ -144,7 +161,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     h->prof_n[rq.kind]++;
     h->prof_ms[rq.kind] += ms;
   }
-  if (h->allreduce) {  // point-sharded scan: sum the packed row across ranks
+  if (h->allreduce && !h->comm) {  // point-sharded scan, caller-supplied collective: sum the packed row across ranks
     if (h->allreduce(h->host_result, ndt::kEvalStride, 0, h->allreduce_user))
       return fail(NDT_ERR_COMM, "allreduce callback failed");
   }
@@ -316,14 +333,27 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   ndt_status s = check_ready(h);
   if (s) return s;
   ndt::ScanSolver solver;
-  solver.start(guess, h->source->n, solver_params(h));
+  size_t n_total = h->source->n;
+  if (h->comm) {  // point-sharded scan: transformation_probability = score / N over ALL shards
+    ndt_status sc = ensure_host_rows(h, 1);
+    if (sc) return sc;
+    HIP_TRY(h->batch_out.reserve(ndt::kEvalStride));
+    double row[ndt::kEvalStride] = {static_cast<double>(h->source->n)};
+    HIP_TRY(hipMemcpyAsync(h->batch_out.p, row, sizeof(row), hipMemcpyHostToDevice, h->stream));
+    sc = comm_allreduce(h, h->batch_out.p, ndt::kEvalStride);
+    if (sc) return sc;
+    HIP_TRY(hipMemcpyAsync(row, h->batch_out.p, sizeof(row), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    n_total = static_cast<size_t>(row[0]);
+  }
+  solver.start(guess, n_total, solver_params(h));
   double nn = 0;
   const ndt::Gauss gs_align = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   struct ServerGuard {  // whatever path leaves align, the server is told to exit
     ndt_context* c;
     ~ServerGuard() { if (c->server_running) (void)server_stop(c); }
   } server_guard{h};
-  const bool use_server = (h->persistent < 0 ? server_enabled() : h->persistent != 0) && !h->profiling && !h->allreduce && ndt::derivative_variant() == 0 &&
+  const bool use_server = (h->persistent < 0 ? server_enabled() : h->persistent != 0) && !h->profiling && !h->allreduce && !h->comm && ndt::derivative_variant() == 0 &&
                           h->source->k2_n() > 0 && !h->grid->empty;
   // the caller wants the aligned cloud on the host: the server's last command writes it into page-locked memory as well
   h->server_out_host = nullptr;
@@ -377,7 +407,7 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   h->trans_probability = solver.trans_probability;
   h->n_evals = solver.n_evals;
   h->n_hess = solver.n_hess;
-  h->mean_neighbors = h->source->n ? nn / static_cast<double>(h->source->n) : 0.0;
+  h->mean_neighbors = n_total ? nn / static_cast<double>(n_total) : 0.0;
   // the aligned cloud = source transformed by the last trial's matrix (trans_cloud of :833/:878)
   const int n = static_cast<int>(h->source->n);
   bool wrote_host_copy = false;

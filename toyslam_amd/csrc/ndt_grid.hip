@@ -520,6 +520,22 @@ ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, 
   return set_source_impl(h, pts, n, stride, true);
 }
 
+ndt_status ndt_share_input_source(ndt_handle dst, ndt_handle src) {
+  if (!dst || !src) return fail(NDT_ERR_INVALID, "null handle");
+  if (!src->source) return fail(NDT_ERR_NO_INPUT, "the donor handle has no input source");
+  if (dst == src) return NDT_OK;
+  if (dst->device != src->device) return fail(NDT_ERR_INVALID, "handles on different devices");
+  // the cloud was uploaded and ordered on the donor's stream; what `dst` still runs on its old source must be over
+  // before that cloud can go back to the pool
+  HIP_TRY(hipSetDevice(src->device));
+  if (src->device_ready) HIP_TRY(hipStreamSynchronize(src->stream));
+  ndt_status s = ensure_device(dst);
+  if (s) return s;
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  dst->source = src->source;
+  return NDT_OK;
+}
+
 ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride, double* score) {
   if (!h || !score) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");

@@ -222,6 +222,11 @@ struct DeviceGrid {
 }  // namespace ndtc
 using namespace ndtc;
 
+struct ndt_context;
+namespace ndtc {
+void comm_release(ndt_context* h);  // ndt_batch.hip
+}
+
 struct ndt_context {
   int device = 0;
   bool device_ready = false;
@@ -293,8 +298,14 @@ struct ndt_context {
   ndt_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int allreduce_on_device = 0;
+  // native RCCL communicator (ndt_comm_*, ndt_batch.hip): sharded lock-step batches, point-sharded scans
+  void* comm = nullptr;  // ncclComm_t
+  int comm_rank = 0, comm_world = 1;
+  long long comm_collectives = 0;
+  int batch_lock_steps = 0;  // lock-steps of the last ndt_align_batch*
 
   ~ndt_context() {
+    ndtc::comm_release(this);
     if (stream) {  // nothing of this handle may still be running when its buffers go back to the pool
       (void)hipSetDevice(device);
       (void)hipStreamSynchronize(stream);
@@ -358,6 +369,8 @@ void server_finish(ndt_context* h, const float* T_colmajor);
 ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt::Gauss& gs, ndt::EvalResult& res,
                            double* nn_total, bool* served);
 bool server_enabled();
+// ---- ndt_batch.hip
+ndt_status comm_allreduce(ndt_context* h, double* d_buf, size_t n_doubles);
 void server_mark(ndt_context* h, bool running);
 
 // tagged publication row (ndt_kernels.hip publish_row_tagged): 64 words, each (half of a value << 32) |

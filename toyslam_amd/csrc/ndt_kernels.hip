@@ -836,6 +836,15 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce(const double* __restr
   }
 }
 
+// Rows of the exchange buffer (after the all-reduce of a sharded lock-step) -> the pinned host block the host polls:
+// every row, then its sequence word in slot 31 (publish_row).
+__global__ __launch_bounds__(kWave) void k_publish_rows(const double* __restrict__ rows, double* __restrict__ out,
+                                                       unsigned long long seq) {
+  const size_t r = blockIdx.x;
+  const double v = (threadIdx.x < kEvalStride - 1) ? rows[r * kEvalStride + threadIdx.x] : 0.0;
+  publish_row(out + r * kEvalStride, v, seq);
+}
+
 // transformed source cloud ("output" of align), w = 1.  dense = 0: [PCL] transformPointCloud leaves
 // non-finite points as they are.
 __global__ __launch_bounds__(kBlock) void k_transform(const float4* __restrict__ src, int n, EvalParams P,
@@ -1194,6 +1203,12 @@ hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const 
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
                          hipStream_t stream, unsigned long long seq) {
   hipLaunchKernelGGL(k_reduce, dim3(n_scans), dim3(kReduceThreads), 0, stream, partials, n_blocks, descs, out, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_publish_rows(const double* d_rows, int n_rows, double* host_rows, unsigned long long seq, hipStream_t stream) {
+  if (n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_publish_rows, dim3(n_rows), dim3(kWave), 0, stream, d_rows, host_rows, seq);
   return hipGetLastError();
 }
 

@@ -157,6 +157,8 @@ hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const 
 // host memory polled by the host; slot kEvalStride-1 of each row then receives `seq` (u64) last.
 hipError_t launch_reduce(const double* partials, int n_blocks, int n_scans, const ScanDesc* descs, double* out,
                          hipStream_t stream, unsigned long long seq = 0);
+// n_rows x kEvalStride doubles of device memory -> pinned host rows, each followed by `seq` in slot kEvalStride-1
+hipError_t launch_publish_rows(const double* d_rows, int n_rows, double* host_rows, unsigned long long seq, hipStream_t stream);
 // all live scans of a lock-step batch step in one launch, kinds mixed (descs[scan].kind, .pad = rows written)
 hipError_t launch_batch_step(const float4* src, const GridView& gv, int search, const ScanDesc* descs, const int* active,
                              int n_active, int max_blocks, int n_blocks, double* partials, hipStream_t stream);

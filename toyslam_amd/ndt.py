@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import DIRECT1, DIRECT7, DIRECT26, KDTREE, NdtError, check  # noqa: F401
+from ._lib import COMM_ID_BYTES, DIRECT1, DIRECT7, DIRECT26, KDTREE, NdtError, check  # noqa: F401
 
 
 def _f(a):
@@ -250,6 +250,57 @@ class NormalDistributionsTransform:
         return dict(T=np.stack([_from_colmajor(T[k]) for k in range(B)]), converged=conv.astype(bool),
                     iterations=it, trans_probability=tp)
 
+    def alignBatchSharded(self, clouds=None, first_scan=0, total_scans=None, guesses=None, device_ptr=None, offsets=None,
+                          stride_bytes=16):
+        """The lock-step batch with the scans sharded over ranks (ndt_align_batch_sharded*): this rank holds scans
+        [first_scan, first_scan + n_local) of total_scans; needs a communicator (commInitRank) or an all-reduce hook.
+        Outputs cover all total_scans scans and are identical on every rank."""
+        if clouds is not None:
+            cat = _cloud(np.concatenate(clouds, axis=0)) if clouds else np.zeros((0, 4), np.float32)
+            offsets = np.zeros(len(clouds) + 1, dtype=np.uintp)
+            offsets[1:] = np.cumsum([c.shape[0] for c in clouds])
+            ptr, stride, fn = cat.ctypes.data, cat.shape[1] * 4, self._L.ndt_align_batch_sharded
+        else:
+            offsets = np.ascontiguousarray(offsets, dtype=np.uintp)
+            ptr, stride, fn = C.c_void_p(device_ptr), stride_bytes, self._L.ndt_align_batch_sharded_device
+        n_local = len(offsets) - 1
+        B = int(total_scans if total_scans is not None else n_local)
+        g = None
+        if guesses is not None:
+            g = np.ascontiguousarray(np.stack([_colmajor(x) for x in guesses]))
+            assert g.shape[0] == B
+        T = np.zeros((B, 16), dtype=np.float32)
+        conv = np.zeros(B, dtype=np.int32)
+        it = np.zeros(B, dtype=np.int32)
+        tp = np.zeros(B, dtype=np.float64)
+        check(fn(self._h, ptr, offsets.ctypes.data_as(C.POINTER(C.c_size_t)), n_local, int(first_scan), B, stride,
+                 _f(g) if g is not None else None, _f(T), _i(conv), _i(it), _d(tp)))
+        return dict(T=np.stack([_from_colmajor(T[k]) for k in range(B)]), converged=conv.astype(bool),
+                    iterations=it, trans_probability=tp)
+
+    # ---- multi-GPU: native RCCL communicator (ndt_comm_*) -----------------------------
+    def commInitRank(self, unique_id, rank, world_size):
+        """unique_id: the COMM_ID_BYTES bytes rank 0 got from comm_get_unique_id()."""
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(self._L.ndt_comm_init_rank(self._h, C.cast(buf, C.c_void_p), int(rank), int(world_size)))
+
+    def commDestroy(self):
+        check(self._L.ndt_comm_destroy(self._h))
+
+    def commStats(self):
+        r, w, ls = C.c_int(0), C.c_int(0), C.c_int(0)
+        n = C.c_longlong(0)
+        check(self._L.ndt_comm_stats(self._h, C.byref(r), C.byref(w), C.byref(n), C.byref(ls)))
+        return dict(rank=r.value, world=w.value, collectives=n.value, lock_steps=ls.value)
+
+    def shareInputSource(self, donor):
+        """Register the source cloud `donor` has uploaded (ndt_share_input_source)."""
+        check(self._L.ndt_share_input_source(self._h, donor._h))
+
+    def setInputSourceRaw(self, host_ptr, n, stride_bytes=16):
+        """setInputSource from a raw host pointer (e.g. the page-locked buffer of a PcdSequence scan)."""
+        check(self._L.ndt_set_input_source(self._h, C.c_void_p(host_ptr), n, stride_bytes))
+
     def setAllreduce(self, fn, on_device=False):
         """fn(buffer_address, n_doubles, on_device) -> 0 on success; None removes the hook."""
         if fn is None:
@@ -350,6 +401,13 @@ class NormalDistributionsTransform:
         check(self._L.ndt_grid_info(self._h, _i(mb), _i(xb), _i(db)))
         return dict(idx=idx, n=npts, mean=mean, cov=cov, icov=icov, evals=evals, min_b=mb, max_b=xb, div_b=db,
                     n_valid=nv.value)
+
+
+def comm_get_unique_id():
+    """ncclGetUniqueId through the C-ABI (rank 0): COMM_ID_BYTES bytes to carry to every rank."""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    check(_lib.lib().ndt_comm_get_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf.raw)
 
 
 # ---- host-only scalar pieces (no GPU needed) ---------------------------------------
@@ -480,6 +538,15 @@ class PcdSequence:
             return None
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 4))
         return a[:, :3].copy(), bool(dense.value), num.value
+
+    def next_raw(self):
+        """-> (host address of n x (x, y, z, 1.0f) records, n, is_dense, file_number) or None.  The records sit in one of
+        the sequence's two (page-locked) buffers and stay valid until the following call of next / next_raw."""
+        p, n, dense, num = C.c_void_p(), C.c_size_t(0), C.c_int(1), C.c_int(-1)
+        check(self._L.ndt_pcd_sequence_next(self._h, C.byref(p), C.byref(n), C.byref(dense), C.byref(num)))
+        if not p.value:
+            return None
+        return p.value, n.value, bool(dense.value), num.value
 
 
 def repack_fields(data, n, point_step, off_x=0, off_y=4, off_z=8):
