@@ -7,8 +7,8 @@ N = 1 (default workload "single" = BASELINE configs[1], the configuration the me
   a "step" is ONE registration (pcl::Registration::align) of one synthetic 100k-point source scan against
   a 1M-point target whose voxel grid is already resident in HBM -- exactly the region
   ndt_omp/apps/align.cpp:20-29 times -- at 1.0 m voxels, DIRECT7, with the Newton loop pinned to 30 outer
-  passes (max_iterations 28, transformation_epsilon 0: ndt_omp_impl.hpp:158-164 then runs max_iterations + 2
-  passes).
+  passes (max_iterations 28, transformation_epsilon 1e-9 as SURVEY 8(d) fixes the work: ndt_omp_impl.hpp:158-164
+  then runs max_iterations + 2 passes).
 N > 1 (default workload "mapbuild" = BASELINE configs[3]): 512 source scans of 100k points against the one
   shared 1M-point target, the scans split over the ranks by toyslam_amd.dist.shard_range, the target grid
   replicated per GPU; a "step" is one lock-step batch registration (ndt_align_batch_device) of every rank's
@@ -44,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "scan registrations/sec (100k-pt src vs 1M-pt target, 30 Newton iters)"
-MAX_ITER, EPS = 28, 0.0
+MAX_ITER, EPS = 28, 1e-9  # max_iterations_ = 28, transformation_epsilon_ = 1e-9 => 30 outer passes (trap 9)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 
@@ -397,7 +397,7 @@ def main():
     if rank == 0:
         value = steps * regs_per_step_global / dt
         names = {
-            "single": "single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes (max_iterations 28, epsilon 0), set " + args.set,
+            "single": "single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes (max_iterations 28, epsilon 1e-9), set " + args.set,
             "large": "single 2M-pt source vs 10M-pt target (surface scene, %g m), 0.5 m voxels, DIRECT7, 30 Newton passes" % args.extent,
             "mapbuild": "map-build: %d x 100k-pt sources vs one shared 1M-pt target, scans split over %d GPU(s), lock-step batch per GPU, set %s" % (args.scans, world, args.set),
             "batch": "map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set),

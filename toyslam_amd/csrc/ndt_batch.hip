@@ -351,6 +351,13 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       h->prof_n[0]++;
       h->prof_ms[0] += ms;
     }
+    static const int trace_scan = [] { const char* v = getenv("NDT_BATCH_TRACE"); return v ? atoi(v) : -1; }();
+    if (trace_scan >= 0 && static_cast<size_t>(trace_scan) < total && live_kind[trace_scan] != ndt::EVAL_NONE) {
+      const ndt::EvalRequest& rq = solvers[trace_scan].request();
+      const double* row = h->host_result + static_cast<size_t>(trace_scan) * ndt::kEvalStride;
+      std::fprintf(stderr, "[trace] kind %d p %.17g %.17g %.17g %.17g %.17g %.17g -> score %.17g g0 %.17g g5 %.17g H00 %.17g nn %.17g\n", static_cast<int>(rq.kind),
+                   rq.p[0], rq.p[1], rq.p[2], rq.p[3], rq.p[4], rq.p[5], row[0], row[1], row[6], row[7], row[28]);
+    }
     pool.run(total, [&](size_t g) {  // Newton / More-Thuente step of every live scan
       if (live_kind[g] == ndt::EVAL_NONE) return;
       ndt::EvalResult r;

@@ -391,6 +391,12 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
       if (s) return s;
     }
     if (counts_neighbors) nn = nn_step;
+    static const bool trace = [] { const char* v = getenv("NDT_ALIGN_TRACE"); return v && atoi(v) != 0; }();
+    if (trace) {
+      const ndt::EvalRequest& rq = solver.request();
+      std::fprintf(stderr, "[trace] kind %d p %.17g %.17g %.17g %.17g %.17g %.17g -> score %.17g g0 %.17g g5 %.17g H00 %.17g nn %.17g\n", static_cast<int>(rq.kind),
+                   rq.p[0], rq.p[1], rq.p[2], rq.p[3], rq.p[4], rq.p[5], r.score, r.g[0], r.g[5], r.H[0], nn_step);
+    }
     const auto ts0 = std::chrono::steady_clock::now();
     solver.feed(r);
     h->t_solver += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
