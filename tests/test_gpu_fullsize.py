@@ -72,7 +72,7 @@ def test_config2_full_size_follows_the_oracle(mods, cfg_b, large_golden):
     assert g.getFinalNumIteration() == gold["iterations"] == 30
     st = g.stats()
     assert st["n_evals"] == gold["n_evals"] and st["n_hessian_recomputes"] == gold["n_hessian_recomputes"]
-    assert g.getTransformationProbability() == pytest.approx(gold["trans_probability"], rel=1e-6)
+    assert g.getTransformationProbability() == pytest.approx(gold["trans_probability"], rel=2e-5)  # score / N at a pose equal to ~1e-7
     # bit-identical re-run
     g.align()
     assert np.array_equal(T1, g.getFinalTransformation())

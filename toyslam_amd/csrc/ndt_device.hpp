@@ -181,8 +181,6 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __
   }
 }
 
-constexpr int kLutRejected = 0x40000000;  // LUT flag: voxel has a record but nr_points == -1
-
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
 // XCD-aware work assignment for the latency kernels.  Workgroups are dispatched round-robin over the 8
@@ -194,6 +192,53 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfi
 __device__ __forceinline__ int xcd_chunk(int b, int nb) {
   const int x = b & 7, q = nb >> 3, r = nb & 7;
   return x * q + min(x, r) + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// Packed f32 arithmetic, written out by hand (VOP3P, two f32 lanes per instruction).
+//
+// The per-point math below is the same in both kernel translation units and in every kernel that
+// includes this header: every product, sum and fused multiply-add is spelled out (no contraction left
+// to the compiler, `#pragma clang fp contract(off)` wherever plain operators are used), so the f32
+// results do not depend on the unit's flags or on how a kernel is scheduled -- the batch kernels and
+// the single-scan kernels return the same per-point values bit for bit and differ only in the order
+// of their f64 sums.  op_sel / op_sel_hi pick, per source, which half of its register pair feeds the
+// low and the high lane: a value is broadcast from whichever half of a pair it lives in, for free.
+//   b0lo / b0hi: source 0 is broadcast from its low / high half; sources 1, 2 are taken lane-wise.
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// (the builtins below compile to exactly one v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 each, the broadcasts to
+// op_sel bits of that instruction -- checked in the ISA; no contraction can happen across them)
+__device__ __forceinline__ f2 bc_lo(f2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ f2 bc_hi(f2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_fma_b0lo(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(bc_lo(a), b, c); }
+__device__ __forceinline__ f2 pk_fma_b0hi(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(bc_hi(a), b, c); }
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ f2 pk_mul_b0lo(f2 a, f2 b) {
+#pragma clang fp contract(off)
+  return bc_lo(a) * b;
+}
+__device__ __forceinline__ f2 pk_mul_b0hi(f2 a, f2 b) {
+#pragma clang fp contract(off)
+  return bc_hi(a) * b;
+}
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float mul1(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add1(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
 }
 
 // ---------------------------------------------------------------------------
@@ -231,38 +276,50 @@ __device__ __forceinline__ void xform_point(const float* T, float x, float y, fl
   oz = ez + dz;
 }
 
-// voxel coordinate while SEARCHING: floor(x / leaf), _impl.hpp:379-381 (division, trap 2)
+// voxel coordinate while SEARCHING: floor(x / leaf), _impl.hpp:379-381 (division, trap 2).  For power-of-two
+// leaves the product with the (then exact) reciprocal is the same f32 number as the quotient.
 __device__ __forceinline__ void search_ijk(const GridGeom& g, float x, float y, float z, int& i, int& j, int& k) {
-  i = static_cast<int>(floorf(__fdiv_rn(x, g.leaf[0])));
-  j = static_cast<int>(floorf(__fdiv_rn(y, g.leaf[1])));
-  k = static_cast<int>(floorf(__fdiv_rn(z, g.leaf[2])));
+  if (g.pow2) {  // uniform
+#pragma clang fp contract(off)
+    i = static_cast<int>(floorf(x * g.inv_leaf[0]));
+    j = static_cast<int>(floorf(y * g.inv_leaf[1]));
+    k = static_cast<int>(floorf(z * g.inv_leaf[2]));
+  } else {
+    i = static_cast<int>(floorf(__fdiv_rn(x, g.leaf[0])));
+    j = static_cast<int>(floorf(__fdiv_rn(y, g.leaf[1])));
+    k = static_cast<int>(floorf(__fdiv_rn(z, g.leaf[2])));
+  }
 }
 
-// record index of voxel (i+dx, j+dy, k+dz) or -1  (_impl.hpp:382-399)
-__device__ __forceinline__ int probe(const GridView& gv, int i, int j, int k, int dx, int dy, int dz) {
-  const int ci = i + dx, cj = j + dy, ck = k + dz;
-  if (ci < gv.g.min_b[0] || ci > gv.g.max_b[0] || cj < gv.g.min_b[1] || cj > gv.g.max_b[1] || ck < gv.g.min_b[2] ||
-      ck > gv.g.max_b[2])
-    return -1;
-  const int cell = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
-  const int e = gv.lut[cell];
-  return (e & kLutRejected) ? -1 : e;  // -1 has the bit set too
+// within one cell of the bounding box: every neighbour cell of the 3x3x3 block then lies inside the padded
+// look-up table (border kLutBorder = 2), and far-away points cost nothing
+__device__ __forceinline__ bool near_grid(const GridGeom& g, int i, int j, int k) {
+  return static_cast<unsigned>(i - g.min_b[0] + 1) <= static_cast<unsigned>(g.div_b[0] + 1) &&
+         static_cast<unsigned>(j - g.min_b[1] + 1) <= static_cast<unsigned>(g.div_b[1] + 1) &&
+         static_cast<unsigned>(k - g.min_b[2] + 1) <= static_cast<unsigned>(g.div_b[2] + 1);
+}
+// index of voxel (i, j, k) in the padded look-up table (valid for near_grid points and their neighbour cells)
+__device__ __forceinline__ unsigned lut_index(const GridGeom& g, int i, int j, int k) {
+  return static_cast<unsigned>(i - g.min_b[0] + kLutBorder) + static_cast<unsigned>(j - g.min_b[1] + kLutBorder) * static_cast<unsigned>(g.pmul[1]) +
+         static_cast<unsigned>(k - g.min_b[2] + kLutBorder) * static_cast<unsigned>(g.pmul[2]);
+}
+__device__ __forceinline__ int lut_offset(const GridGeom& g, int dx, int dy, int dz) { return dx + dy * g.pmul[1] + dz * g.pmul[2]; }
+
+// record index (>= 0) of voxel (i+dx, j+dy, k+dz) if the DIRECT searches may use it, else negative
+// (_impl.hpp:382-399: outside the box, empty, fewer than min_points_per_voxel points, or rejected)
+__device__ __forceinline__ int probe(const GridView& gv, unsigned centre, int dx, int dy, int dz) {
+  return gv.lut[centre + static_cast<unsigned>(lut_offset(gv.g, dx, dy, dz))];
 }
 
 // KDTREE: record index of voxel (i+dx, ...) if it is in the centroid cloud (valid or rejected) and
 // its f32 centroid is closer than the radius -- radiusSearch, voxel_grid_covariance_omp.h:476-505,
 // [FLANN] L2_Simple accumulated in f32, RadiusResultSet keeps dist < r^2.  Else -1.
-__device__ __forceinline__ int probe_kd(const GridView& gv, int i, int j, int k, int dx, int dy, int dz, float x, float y,
+__device__ __forceinline__ int probe_kd(const GridView& gv, unsigned centre, int dx, int dy, int dz, float x, float y,
                                         float z, float r2) {
-  const int ci = i + dx, cj = j + dy, ck = k + dz;
-  if (ci < gv.g.min_b[0] || ci > gv.g.max_b[0] || cj < gv.g.min_b[1] || cj > gv.g.max_b[1] || ck < gv.g.min_b[2] ||
-      ck > gv.g.max_b[2])
-    return -1;
-  const int cell = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
-  const int e = gv.lut[cell];
-  if (e < 0) return -1;
-  const int rix = e & ~kLutRejected;
-  const float4 c = reinterpret_cast<const float4*>(gv.recs + rix)[3];  // centroid x,y,z, n
+  const int e = gv.lut[centre + static_cast<unsigned>(lut_offset(gv.g, dx, dy, dz))];
+  if (e == kLutEmpty) return -1;
+  const int rix = (e >= 0) ? e : -(e + 2);
+  const float4 c = gv.centroids[rix];
   float d;
   {
 #pragma clang fp contract(off)
@@ -274,117 +331,67 @@ __device__ __forceinline__ int probe_kd(const GridView& gv, int i, int j, int k,
   return (d < r2) ? rix : -1;
 }
 
-// coarse reject so that i+d cannot overflow and far-away points cost nothing
-__device__ __forceinline__ bool near_grid(const GridGeom& g, int i, int j, int k) {
-  return i >= g.min_b[0] - 1 && i <= g.max_b[0] + 1 && j >= g.min_b[1] - 1 && j <= g.max_b[1] + 1 && k >= g.min_b[2] - 1 &&
-         k <= g.max_b[2] + 1;
-}
-
 struct RecRegs {
   double mx, my, mz;
-  float c00, c01, c02, c11, c12, c22;
+  f2 p0, p1, p2, p3;  // (c00,c01) (c01,c11) (c02,c12) (c11,c22)
 };
 __device__ __forceinline__ RecRegs load_rec(const VoxelRec* __restrict__ recs, int r) {
   const float4* p = reinterpret_cast<const float4*>(recs + r);
   const float4 a = p[0], b = p[1], c = p[2];
+  const float2 d = *reinterpret_cast<const float2*>(p + 3);
   RecRegs o;
   o.mx = __hiloint2double(__float_as_int(a.y), __float_as_int(a.x));
   o.my = __hiloint2double(__float_as_int(a.w), __float_as_int(a.z));
   o.mz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
-  o.c00 = b.z; o.c01 = b.w; o.c02 = c.x; o.c11 = c.y; o.c12 = c.z; o.c22 = c.w;
+  o.p0 = f2{b.z, b.w};
+  o.p1 = f2{c.x, c.y};
+  o.p2 = f2{c.z, c.w};
+  o.p3 = f2{d.x, d.y};
   return o;
 }
 
-// per-point pieces of computePointDerivatives (f32, ndt_omp_impl.hpp:398-440):
-// xj = j_ang * x (8), xh = h_ang * x (15)
-struct PointDeriv {
-  float j[8];
-  float h[15];
+// Per-evaluation coefficient tables of computePointDerivatives (ndt_omp_impl.hpp:398-440) in the pair layout the
+// packed math consumes.  With v = (x, y, z) the point, row r of j_ang / h_ang gives  j_r = j_ang[r] . v,
+// h_r = h_ang[r] . v; pair (r, r') of the table holds (M[r][c], M[r'][c]) for c = 0, 1, 2:
+//   jp: (j2,j5) (j3,j6) (j4,j7) (j0,j1)                       -- columns 1, 2 of B = dR/d(angle) x, then column 0
+//   hp: (h0,h2) (h1,h3) (h6,h9) (h7,h10) (h8,h11) (h4,h5) (h12,h13) ; h14 on its own
+struct PackedTables {
+  f2 jp[3][4];
+  f2 hp[3][7];
+  float h14[3];
+  float pad_;
 };
-template <class P>
-__device__ __forceinline__ void point_derivatives(const P& prm, float x, float y, float z, PointDeriv& d, bool want_h) {
-#pragma unroll
-  for (int r = 0; r < 8; r++) d.j[r] = (prm.j[r][0] * x + prm.j[r][1] * y) + prm.j[r][2] * z;
-  if (want_h) {
-#pragma unroll
-    for (int r = 0; r < 15; r++) d.h[r] = (prm.h[r][0] * x + prm.h[r][1] * y) + prm.h[r][2] * z;
-  }
+static_assert(sizeof(PackedTables) == 70 * sizeof(float), "PackedTables is addressed as 70 floats");
+// float index inside PackedTables of element e of the row tables (e < 24: j[e / 3][e % 3]; else h[(e - 24) / 3][(e - 24) % 3])
+__device__ __constant__ unsigned char kPackPos[69] = {6, 14, 22, 7, 15, 23, 0, 8, 16, 2, 10, 18, 4, 12, 20, 1, 9, 17, 3, 11, 19, 5, 13, 21, 24, 38, 52, 26, 40, 54, 25, 39, 53, 27, 41, 55, 34, 48, 62, 35, 49, 63, 28, 42, 56, 30, 44, 58, 32, 46, 60, 29, 43, 57, 31, 45, 59, 33, 47, 61, 36, 50, 64, 37, 51, 65, 66, 67, 68};
+// EvalParams (row tables j[8][3], h[15][3]) -> PackedTables, one element per thread
+__device__ __forceinline__ void pack_tables(const EvalParams& P, PackedTables& t, int tid, int nthreads) {
+  const float* src = &P.j[0][0];  // j[8][3] and h[15][3] are contiguous: 69 floats
+  float* dst = reinterpret_cast<float*>(&t);
+  for (int e = tid; e < 69; e += nthreads) dst[kPackPos[e]] = src[e];
 }
 
-// updateDerivatives (ndt_omp_impl.hpp:484-537) for one (point, voxel) pair.
-// f32 arithmetic in the reference's operation order with the structural zeros
-// of J_E / H_E skipped (those products are exact zeros there); f64 accumulation.
-// acc: [0]=score [1..6]=gradient [7..27]=Hessian upper triangle [28]=neighbour count
+// per-point pieces of computePointDerivatives (f32), in pairs
+struct PointDeriv {
+  f2 jp[4];   // (j2,j5) (j3,j6) (j4,j7) (j0,j1)
+  f2 hp[7];   // (h0,h2) (h1,h3) (h6,h9) (h7,h10) (h8,h11) (h4,h5) (h12,h13)
+  float h14;
+};
 template <bool WANT_H>
-__device__ __forceinline__ void accumulate_neighbor(double (&acc)[kNumAcc], const PointDeriv& d, float x0, float x1,
-                                                    float x2, const RecRegs& r, double d1, float d2) {
-  // xc = x'^T C   (x_trans4 * c_inv4)
-  const float xc0 = (x0 * r.c00 + x1 * r.c01) + x2 * r.c02;
-  const float xc1 = (x0 * r.c01 + x1 * r.c11) + x2 * r.c12;
-  const float xc2 = (x0 * r.c02 + x1 * r.c12) + x2 * r.c22;
-  const float q = (x0 * xc0 + x1 * xc1) + x2 * xc2;
-  float e = expf(-d2 * q * 0.5f);                              // :499
-  const float score_inc = static_cast<float>(-d1 * static_cast<double>(e));  // :501
-  e = d2 * e;                                                  // :503
-  if (e > 1.0f || e < 0.0f || e != e) return;                  // :506-507 (adds nothing, not even the score)
-  e = static_cast<float>(static_cast<double>(e) * d1);         // :510
-  acc[0] += static_cast<double>(score_inc);
-  acc[28] += 1.0;
-
-  // CJ = C * J_E columns 3..5 (columns 0..2 are the columns of C)
-  const float* j = d.j;
-  const float cj03 = r.c01 * j[0] + r.c02 * j[1], cj13 = r.c11 * j[0] + r.c12 * j[1], cj23 = r.c12 * j[0] + r.c22 * j[1];
-  const float cj04 = (r.c00 * j[2] + r.c01 * j[3]) + r.c02 * j[4];
-  const float cj14 = (r.c01 * j[2] + r.c11 * j[3]) + r.c12 * j[4];
-  const float cj24 = (r.c02 * j[2] + r.c12 * j[3]) + r.c22 * j[4];
-  const float cj05 = (r.c00 * j[5] + r.c01 * j[6]) + r.c02 * j[7];
-  const float cj15 = (r.c01 * j[5] + r.c11 * j[6]) + r.c12 * j[7];
-  const float cj25 = (r.c02 * j[5] + r.c12 * j[6]) + r.c22 * j[7];
-  // g = x'^T CJ
-  float g[6];
-  g[0] = xc0; g[1] = xc1; g[2] = xc2;
-  g[3] = (x0 * cj03 + x1 * cj13) + x2 * cj23;
-  g[4] = (x0 * cj04 + x1 * cj14) + x2 * cj24;
-  g[5] = (x0 * cj05 + x1 * cj15) + x2 * cj25;
+__device__ __forceinline__ void point_derivatives(const PackedTables& t, float x, float y, float z, PointDeriv& d) {
+  const f2 xy = f2{x, y}, zz = f2{z, z};
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc[1 + k] += static_cast<double>(e * g[k]);  // :515
-
+  for (int q = 0; q < 4; q++) d.jp[q] = pk_fma_b0lo(zz, t.jp[2][q], pk_fma_b0hi(xy, t.jp[1][q], pk_mul_b0lo(xy, t.jp[0][q])));
   if (WANT_H) {
-    // JCJ(b,a) = J_E[:,b] . CJ[:,a]   needed for a <= b
-    const float CJ[3][6] = {{r.c00, r.c01, r.c02, cj03, cj04, cj05},
-                            {r.c01, r.c11, r.c12, cj13, cj14, cj15},
-                            {r.c02, r.c12, r.c22, cj23, cj24, cj25}};
-    // x'^T C H_E blocks (symmetric 3x3 in the angle indices): a b c / b d e / c e f
-    const float* h = d.h;
-    const float xa = xc1 * h[0] + xc2 * h[1];
-    const float xb = xc1 * h[2] + xc2 * h[3];
-    const float xcc = xc1 * h[4] + xc2 * h[5];
-    const float xd = (xc0 * h[6] + xc1 * h[7]) + xc2 * h[8];
-    const float xe = (xc0 * h[9] + xc1 * h[10]) + xc2 * h[11];
-    const float xf = (xc0 * h[12] + xc1 * h[13]) + xc2 * h[14];
-    const float xH[3][3] = {{xa, xb, xcc}, {xb, xd, xe}, {xcc, xe, xf}};
-    int idx = 7;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-#pragma unroll
-      for (int jj = i; jj < 6; jj++) {
-        // JCJ(jj, i)
-        float jcj;
-        if (jj < 3) jcj = CJ[jj][i];
-        else if (jj == 3) jcj = j[0] * CJ[1][i] + j[1] * CJ[2][i];
-        else if (jj == 4) jcj = (j[2] * CJ[0][i] + j[3] * CJ[1][i]) + j[4] * CJ[2][i];
-        else jcj = (j[5] * CJ[0][i] + j[6] * CJ[1][i]) + j[7] * CJ[2][i];
-        const float xh = (i >= 3) ? xH[i - 3][jj - 3] : 0.0f;
-        const float term = e * (((-d2 * g[i]) * g[jj] + xh) + jcj);  // :529-531
-        acc[idx++] += static_cast<double>(term);
-      }
-    }
+    for (int q = 0; q < 7; q++) d.hp[q] = pk_fma_b0lo(zz, t.hp[2][q], pk_fma_b0hi(xy, t.hp[1][q], pk_mul_b0lo(xy, t.hp[0][q])));
+    d.h14 = fma1(z, t.h14[2], fma1(y, t.h14[1], mul1(x, t.h14[0])));
   }
 }
 
 // ---------------------------------------------------------------------------
-// Factored form of updateDerivatives.  With xc = C x' (C symmetric) the reference's per-neighbour
-// quantities are
+// updateDerivatives (ndt_omp_impl.hpp:484-537) in factored form.  With xc = C x' (C symmetric) the
+// reference's per-neighbour quantities are
 //   gradient_k     += e * (xc . J_k)
 //   hessian(i,j)   += e * ( -d2 (xc . J_i)(xc . J_j) + xc . HE_ij + J_j^T C J_i )
 // and J_k, HE_ij depend on the POINT only.  Everything is therefore linear in two small
@@ -393,89 +400,122 @@ __device__ __forceinline__ void accumulate_neighbor(double (&acc)[kNumAcc], cons
 //   A  = sum_n e_n (C_n - d2 xc_n xc_n^T)    (3x3 symmetric, 6)
 // which are accumulated over the <= 7 neighbours of a point (f32), after which
 //   gradient = J^T xe ,  hessian = J^T A J + [xe . HE_ij]   are formed ONCE per point and added to
-// the f64 accumulators.  ~60 instead of ~350 VALU instructions per neighbour; the f32 rounding of
-// the per-point sums differs from the reference's per-neighbour rounding by O(1e-7) relative per
-// point (same order as its own f32 noise), far inside the parity tolerance.
+// the f64 accumulators.  The f32 rounding of the per-point sums differs from the reference's
+// per-neighbour rounding by O(1e-7) relative per point (same order as its own f32 noise), far
+// inside the parity tolerance; e itself follows the reference's f32 / f64 cast sequence (:499-510).
+// acc: [0]=score [1..6]=gradient [7..27]=Hessian upper triangle [28]=neighbour count
 // ---------------------------------------------------------------------------
 struct PointAcc {
-  float xe0, xe1, xe2;
-  float a00, a01, a02, a11, a12, a22;
+  f2 xe01;    // (xe0, xe1)
+  f2 xe2_;    // (xe2, -)
+  f2 a0001;   // (a00, a01)
+  f2 a0212;   // (a02, a12)
+  f2 a1122;   // (a11, a22)
+  double score;
+  int nn;
 };
+__device__ __forceinline__ PointAcc point_acc_zero() {
+  PointAcc pa;
+  pa.xe01 = f2{0.f, 0.f};
+  pa.xe2_ = f2{0.f, 0.f};
+  pa.a0001 = f2{0.f, 0.f};
+  pa.a0212 = f2{0.f, 0.f};
+  pa.a1122 = f2{0.f, 0.f};
+  pa.score = 0.0;
+  pa.nn = 0;
+  return pa;
+}
 
 template <bool WANT_H>
-__device__ __forceinline__ void accumulate_neighbor_factored(double& score, double& nn, PointAcc& pa, float x0, float x1,
-                                                             float x2, const RecRegs& r, double d1, float d2) {
-  const float xc0 = (x0 * r.c00 + x1 * r.c01) + x2 * r.c02;
-  const float xc1 = (x0 * r.c01 + x1 * r.c11) + x2 * r.c12;
-  const float xc2 = (x0 * r.c02 + x1 * r.c12) + x2 * r.c22;
-  const float q = (x0 * xc0 + x1 * xc1) + x2 * xc2;
-  float e = expf(-d2 * q * 0.5f);                                            // :499
+__device__ __forceinline__ void accumulate_neighbor_factored(PointAcc& pa, float x0, float x1, float x2, const RecRegs& r,
+                                                             double d1, float d2) {
+  const f2 x01 = f2{x0, x1}, x2b = f2{x2, x2};
+  // (xc0, xc1) = x0 (c00,c01) + x1 (c01,c11) + x2 (c02,c12) ;  xc2 = x0 c02 + x1 c12 + x2 c22
+  const f2 xc01 = pk_fma_b0lo(x2b, r.p2, pk_fma_b0hi(x01, r.p1, pk_mul_b0lo(x01, r.p0)));
+  const f2 u = pk_mul(x01, r.p2);
+  const float xc2 = fma1(x2, r.p3.y, add1(u.x, u.y));
+  const f2 v = pk_mul(x01, xc01);
+  const float q = fma1(x2, xc2, add1(v.x, v.y));
+  float e = expf(mul1(mul1(-d2, q), 0.5f));                                  // :499
   const float score_inc = static_cast<float>(-d1 * static_cast<double>(e));  // :501
-  e = d2 * e;                                                                // :503
-  if (e > 1.0f || e < 0.0f || e != e) return;                                // :506-507
+  e = mul1(d2, e);                                                           // :503
+  if (e > 1.0f || e < 0.0f || e != e) return;                                // :506-507 (adds nothing, not even the score)
   e = static_cast<float>(static_cast<double>(e) * d1);                       // :510
-  score += static_cast<double>(score_inc);
-  nn += 1.0;
-  pa.xe0 += e * xc0;
-  pa.xe1 += e * xc1;
-  pa.xe2 += e * xc2;
+  pa.score += static_cast<double>(score_inc);
+  pa.nn += 1;
+  const f2 em = f2{e, mul1(-d2, e)};  // (e, -d2 e)
+  pa.xe01 = pk_fma_b0lo(em, xc01, pa.xe01);
+  pa.xe2_.x = fma1(e, xc2, pa.xe2_.x);
   if (WANT_H) {
-    const float t0 = (-d2 * e) * xc0, t1 = (-d2 * e) * xc1, t2 = (-d2 * e) * xc2;
-    pa.a00 += e * r.c00 + t0 * xc0;
-    pa.a01 += e * r.c01 + t0 * xc1;
-    pa.a02 += e * r.c02 + t0 * xc2;
-    pa.a11 += e * r.c11 + t1 * xc1;
-    pa.a12 += e * r.c12 + t1 * xc2;
-    pa.a22 += e * r.c22 + t2 * xc2;
+    const f2 t01 = pk_mul_b0hi(em, xc01);  // -d2 e (xc0, xc1)
+    const float t2 = mul1(em.y, xc2);
+    const f2 xc2b = f2{xc2, xc2};
+    pa.a0001 = pk_fma_b0lo(t01, xc01, pk_fma_b0lo(em, r.p0, pa.a0001));  // += e (c00,c01) + t0 (xc0,xc1)
+    pa.a0212 = pk_fma(t01, xc2b, pk_fma_b0lo(em, r.p2, pa.a0212));       // += e (c02,c12) + (t0,t1) xc2
+    pa.a1122.x = fma1(t01.y, xc01.y, fma1(e, r.p3.x, pa.a1122.x));       // += e c11 + t1 xc1
+    pa.a1122.y = fma1(t2, xc2, fma1(e, r.p3.y, pa.a1122.y));             // += e c22 + t2 xc2
   }
 }
 
 // J_E = [ I3 | B ],  B columns: (0, j0, j1), (j2, j3, j4), (j5, j6, j7)   (ndt_omp_impl.hpp:407-414)
 template <bool WANT_H>
 __device__ __forceinline__ void finish_point(double (&acc)[kNumAcc], const PointAcc& pa, const PointDeriv& d) {
-  const float* j = d.j;
-  const float B[3][3] = {{0.0f, j[2], j[5]}, {j[0], j[3], j[6]}, {j[1], j[4], j[7]}};
-  acc[1] += static_cast<double>(pa.xe0);
-  acc[2] += static_cast<double>(pa.xe1);
-  acc[3] += static_cast<double>(pa.xe2);
-  acc[4] += static_cast<double>(pa.xe1 * B[1][0] + pa.xe2 * B[2][0]);
-  acc[5] += static_cast<double>((pa.xe0 * B[0][1] + pa.xe1 * B[1][1]) + pa.xe2 * B[2][1]);
-  acc[6] += static_cast<double>((pa.xe0 * B[0][2] + pa.xe1 * B[1][2]) + pa.xe2 * B[2][2]);
+  const f2 xe01 = pa.xe01, xe2 = pa.xe2_;
+  const f2 jp0 = d.jp[0], jp1 = d.jp[1], jp2 = d.jp[2], jp3 = d.jp[3];
+  acc[0] += pa.score;
+  acc[28] += static_cast<double>(pa.nn);
+  acc[1] += static_cast<double>(xe01.x);
+  acc[2] += static_cast<double>(xe01.y);
+  acc[3] += static_cast<double>(xe2.x);
+  // g3 = xe1 j0 + xe2 j1 ; (g4, g5) = xe0 (j2,j5) + xe1 (j3,j6) + xe2 (j4,j7)
+  acc[4] += static_cast<double>(fma1(xe2.x, jp3.y, mul1(xe01.y, jp3.x)));
+  const f2 g45 = pk_fma_b0lo(xe2, jp2, pk_fma_b0hi(xe01, jp1, pk_mul_b0lo(xe01, jp0)));
+  acc[5] += static_cast<double>(g45.x);
+  acc[6] += static_cast<double>(g45.y);
   if (WANT_H) {
-    const float A[3][3] = {{pa.a00, pa.a01, pa.a02}, {pa.a01, pa.a11, pa.a12}, {pa.a02, pa.a12, pa.a22}};
-    float AB[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      AB[r][0] = A[r][1] * B[1][0] + A[r][2] * B[2][0];
-#pragma unroll
-      for (int c = 1; c < 3; c++) AB[r][c] = (A[r][0] * B[0][c] + A[r][1] * B[1][c]) + A[r][2] * B[2][c];
-    }
-    // x-block of H_E: a b c / b d e / c e f  with a=(0,h0,h1) b=(0,h2,h3) c=(0,h4,h5) d=(h6,h7,h8) ...
-    const float* h = d.h;
-    const float xa = pa.xe1 * h[0] + pa.xe2 * h[1];
-    const float xb = pa.xe1 * h[2] + pa.xe2 * h[3];
-    const float xcc = pa.xe1 * h[4] + pa.xe2 * h[5];
-    const float xd = (pa.xe0 * h[6] + pa.xe1 * h[7]) + pa.xe2 * h[8];
-    const float xe = (pa.xe0 * h[9] + pa.xe1 * h[10]) + pa.xe2 * h[11];
-    const float xf = (pa.xe0 * h[12] + pa.xe1 * h[13]) + pa.xe2 * h[14];
-    const float X[3][3] = {{xa, xb, xcc}, {xb, xd, xe}, {xcc, xe, xf}};
+    const f2 a0001 = pa.a0001, a0212 = pa.a0212, a1122 = pa.a1122;
+    // AB = A B.  Columns 1, 2 as pairs, row r:  A[r][0] (j2,j5) + A[r][1] (j3,j6) + A[r][2] (j4,j7)
+    const f2 ab0 = pk_fma_b0lo(a0212, jp2, pk_fma_b0hi(a0001, jp1, pk_mul_b0lo(a0001, jp0)));  // A[0] = (a00, a01, a02)
+    const f2 ab1 = pk_fma_b0hi(a0212, jp2, pk_fma_b0lo(a1122, jp1, pk_mul_b0hi(a0001, jp0)));  // A[1] = (a01, a11, a12)
+    const f2 ab2 = pk_fma_b0hi(a1122, jp2, pk_fma_b0hi(a0212, jp1, pk_mul_b0lo(a0212, jp0)));  // A[2] = (a02, a12, a22)
+    // column 0:  A[r][1] j0 + A[r][2] j1
+    const float ab00 = fma1(a0212.x, jp3.y, mul1(a0001.y, jp3.x));
+    const float ab10 = fma1(a0212.y, jp3.y, mul1(a1122.x, jp3.x));
+    const float ab20 = fma1(a1122.y, jp3.y, mul1(a0212.y, jp3.x));
+    // x-block of H_E: a b c / b d e / c e f  with a=(0,h0,h1) b=(0,h2,h3) c=(0,h4,h5) d=(h6,h7,h8) e=(h9,h10,h11) f=(h12,h13,h14)
+    const f2 xab = pk_fma_b0lo(xe2, d.hp[1], pk_mul_b0hi(xe01, d.hp[0]));                               // (xa, xb)
+    const f2 xde = pk_fma_b0lo(xe2, d.hp[4], pk_fma_b0hi(xe01, d.hp[3], pk_mul_b0lo(xe01, d.hp[2])));  // (xd, xe)
+    const float xcc = fma1(xe2.x, d.hp[5].y, mul1(xe01.y, d.hp[5].x));
+    const f2 w = pk_mul(xe01, d.hp[6]);
+    const float xf = fma1(xe2.x, d.h14, add1(w.x, w.y));
     // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-    int idx = 7;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-#pragma unroll
-      for (int c = i; c < 3; c++) acc[idx++] += static_cast<double>(A[i][c]);
-#pragma unroll
-      for (int c = 0; c < 3; c++) acc[idx++] += static_cast<double>(AB[i][c]);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = a; b < 3; b++) {
-        float v = (a == 0) ? (B[1][0] * AB[1][b] + B[2][0] * AB[2][b])
-                           : ((B[0][a] * AB[0][b] + B[1][a] * AB[1][b]) + B[2][a] * AB[2][b]);
-        acc[idx++] += static_cast<double>(v + X[a][b]);
-      }
+    acc[7] += static_cast<double>(a0001.x);
+    acc[8] += static_cast<double>(a0001.y);
+    acc[9] += static_cast<double>(a0212.x);
+    acc[10] += static_cast<double>(ab00);
+    acc[11] += static_cast<double>(ab0.x);
+    acc[12] += static_cast<double>(ab0.y);
+    acc[13] += static_cast<double>(a1122.x);
+    acc[14] += static_cast<double>(a0212.y);
+    acc[15] += static_cast<double>(ab10);
+    acc[16] += static_cast<double>(ab1.x);
+    acc[17] += static_cast<double>(ab1.y);
+    acc[18] += static_cast<double>(a1122.y);
+    acc[19] += static_cast<double>(ab20);
+    acc[20] += static_cast<double>(ab2.x);
+    acc[21] += static_cast<double>(ab2.y);
+    // B^T (A B) + X ;  B[:,0] = (0, j0, j1)  B[:,1] = (j2, j3, j4)  B[:,2] = (j5, j6, j7)
+    const float v00 = fma1(jp3.y, ab20, mul1(jp3.x, ab10));
+    const f2 v0x = pk_fma_b0hi(jp3, ab2, pk_mul_b0lo(jp3, ab1));                              // (v01, v02)
+    const f2 v1x = pk_fma_b0lo(jp2, ab2, pk_fma_b0lo(jp1, ab1, pk_mul_b0lo(jp0, ab0)));      // (v11, v12)
+    const float v22 = fma1(jp2.y, ab2.y, fma1(jp1.y, ab1.y, mul1(jp0.y, ab0.y)));
+    acc[22] += static_cast<double>(add1(v00, xab.x));
+    acc[23] += static_cast<double>(add1(v0x.x, xab.y));
+    acc[24] += static_cast<double>(add1(v0x.y, xcc));
+    const f2 h45 = pk_add(v1x, xde);
+    acc[25] += static_cast<double>(h45.x);
+    acc[26] += static_cast<double>(h45.y);
+    acc[27] += static_cast<double>(add1(v22, xf));
   }
 }
 
@@ -488,9 +528,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 // PRELOADED: the caller already holds src[first] (the evaluation server keeps each lane's first point in registers
 // across rounds: the scan does not change between the evaluations of a registration, and the load would otherwise
 // head every round's dependent chain)
-template <int NNB, bool WANT_H, class P, bool STAMP = false, bool FACTORED = true, bool PRELOADED = false>
-__device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
-                                                 int first, int stride, double (&acc)[kNumAcc],
+template <int NNB, bool WANT_H, bool STAMP = false, bool PRELOADED = false>
+__device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const EvalParams& prm,
+                                                 const PackedTables& tab, int first, int stride, double (&acc)[kNumAcc],
                                                  unsigned long long* st = nullptr, float4 first_pt = float4{0.f, 0.f, 0.f, 0.f}) {
   for (int i = first; i < n; i += stride) {
     const float4 pt = (PRELOADED && i == first) ? first_pt : src[i];
@@ -500,115 +540,84 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
     // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
     // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
     // would poison the per-point finish even though every neighbour term is rejected.
-    if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
-    if (!near_grid(gv.g, vi, vj, vk)) continue;
-    int rec[NNB];
-    bool any = false;
+    // ONE structured region per point (no early `continue`s): the 29 f64 accumulators are then updated in place --
+    // with several exits the compiler kept two register sets for them and copied all of them twice per point
+    if (finite3(tx, ty, tz) && near_grid(gv.g, vi, vj, vk)) {
+      const unsigned centre = lut_index(gv.g, vi, vj, vk);
+      int rec[NNB];
+      bool any = false;
 #pragma unroll
-    for (int k = 0; k < NNB; k++) {
-      int dx, dy, dz;
-      nb_offset<NNB>(k, dx, dy, dz);
-      rec[k] = probe(gv, vi, vj, vk, dx, dy, dz);
-      any |= (rec[k] >= 0);
-    }
-    if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[2] = stamp(); }
-    if (!any) continue;
-    PointDeriv d;
-    point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
-    // Software pipeline over the neighbours: the record of neighbour k+1 is requested (index
-    // clamped, so the load is unconditional and hoistable) before neighbour k's math runs; one
-    // record gather latency is exposed per point instead of one per neighbour.
-    RecRegs cur = load_rec(gv.recs, rec[0] < 0 ? 0 : rec[0]);
-    if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = stamp(); }
-    PointAcc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NNB; k++) {
-      RecRegs nxt = cur;
-      if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
-      if (rec[k] >= 0) {
-        // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
-        const float x0 = static_cast<float>(static_cast<double>(tx) - cur.mx);
-        const float x1 = static_cast<float>(static_cast<double>(ty) - cur.my);
-        const float x2 = static_cast<float>(static_cast<double>(tz) - cur.mz);
-        if (FACTORED) accumulate_neighbor_factored<WANT_H>(acc[0], acc[28], pa, x0, x1, x2, cur, prm.d1, prm.d2);
-        else accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, cur, prm.d1, prm.d2);
+      for (int k = 0; k < NNB; k++) {
+        int dx, dy, dz;
+        nb_offset<NNB>(k, dx, dy, dz);
+        rec[k] = probe(gv, centre, dx, dy, dz);
+        any |= (rec[k] >= 0);
       }
-      cur = nxt;
+      if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[2] = stamp(); }
+      if (any) {
+        const double txd = static_cast<double>(tx), tyd = static_cast<double>(ty), tzd = static_cast<double>(tz);
+        // Software pipeline over the neighbours: the record of neighbour k+1 is requested (index
+        // clamped, so the load is unconditional and hoistable) before neighbour k's math runs; one
+        // record gather latency is exposed per point instead of one per neighbour.
+        PointAcc pa = point_acc_zero();
+        RecRegs cur = load_rec(gv.recs, rec[0] < 0 ? 0 : rec[0]);
+        if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = stamp(); }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+          RecRegs nxt = cur;
+          if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
+          if (rec[k] >= 0) {
+            // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
+            const float x0 = static_cast<float>(txd - cur.mx);
+            const float x1 = static_cast<float>(tyd - cur.my);
+            const float x2 = static_cast<float>(tzd - cur.mz);
+            accumulate_neighbor_factored<WANT_H>(pa, x0, x1, x2, cur, prm.d1, prm.d2);
+          }
+          cur = nxt;
+        }
+        // the point's own derivative pairs only now: 23 registers that the neighbour loop does not have to carry
+        PointDeriv d;
+        point_derivatives<WANT_H>(tab, pt.x, pt.y, pt.z, d);
+        finish_point<WANT_H>(acc, pa, d);
+      }
     }
-    if (FACTORED) finish_point<WANT_H>(acc, pa, d);
     if (STAMP) st[4] = stamp();
-  }
-}
-
-// DIRECT7, latency-oriented decomposition: one (point, neighbour) task per lane, 8 consecutive
-// lanes share a point (slot 7 idles).  Seven dependent gathers per point become seven parallel
-// lanes, so a 100k-point scan exposes 700k independent tasks instead of 100k serial chains.
-template <bool WANT_H, class P>
-__device__ __forceinline__ void derivatives_body_split7(const float4* __restrict__ src, int n, const GridView& gv,
-                                                        const P& prm, int first, int stride, double (&acc)[kNumAcc]) {
-  const int slot = threadIdx.x & 7;
-  if (slot == 7) return;
-  // order of getNeighborhoodAtPoint7 (_impl.hpp:423-430): centre, +x, -x, +y, -y, +z, -z
-  const int dx = (slot == 1) - (slot == 2), dy = (slot == 3) - (slot == 4), dz = (slot == 5) - (slot == 6);
-  const long long total = static_cast<long long>(n) * 8;
-  for (long long t = first; t < total; t += stride) {
-    const float4 pt = src[t >> 3];
-    float tx, ty, tz;
-    xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
-    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
-    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
-    // would poison the per-point finish even though every neighbour term is rejected.
-    if (!finite3(tx, ty, tz)) continue;
-    int vi, vj, vk;
-    search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
-    if (!near_grid(gv.g, vi, vj, vk)) continue;
-    const int rix = probe(gv, vi, vj, vk, dx, dy, dz);
-    if (rix < 0) continue;
-    const RecRegs r = load_rec(gv.recs, rix);
-    PointDeriv d;
-    point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
-    const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
-    const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
-    const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
-    accumulate_neighbor<WANT_H>(acc, d, x0, x1, x2, r, prm.d1, prm.d2);
   }
 }
 
 // KDTREE search: 3x3x3 cells around the point, centroid-distance filter, same factored math.
 // (The reference visits the hits sorted by distance; only the f64 summation order differs.)
-template <bool WANT_H, class P>
-__device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ src, int n, const GridView& gv, const P& prm,
-                                                    int first, int stride, double (&acc)[kNumAcc]) {
+template <bool WANT_H>
+__device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ src, int n, const GridView& gv, const EvalParams& prm,
+                                                    const PackedTables& tab, int first, int stride, double (&acc)[kNumAcc]) {
   const float r2 = __int_as_float(prm.pad);
   for (int i = first; i < n; i += stride) {
     const float4 pt = src[i];
     float tx, ty, tz;
     xform_point(prm.T, pt.x, pt.y, pt.z, tx, ty, tz);
-    // A non-finite point has no neighbourhood in the reference (its voxel index is garbage and fails
-    // the bounding-box test): it contributes nothing.  Without this, 0 x NaN of its point derivatives
-    // would poison the per-point finish even though every neighbour term is rejected.
+    // non-finite point: no neighbourhood in the reference (see derivatives_body)
     if (!finite3(tx, ty, tz)) continue;
     int vi, vj, vk;
     search_ijk(gv.g, tx, ty, tz, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
-    PointAcc pa = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const double nn0 = acc[28];
+    const unsigned centre = lut_index(gv.g, vi, vj, vk);
+    PointAcc pa = point_acc_zero();
     for (int a = -1; a <= 1; a++)
       for (int b = -1; b <= 1; b++)
         for (int c = -1; c <= 1; c++) {
-          const int rix = probe_kd(gv, vi, vj, vk, a, b, c, tx, ty, tz, r2);
+          const int rix = probe_kd(gv, centre, a, b, c, tx, ty, tz, r2);
           if (rix < 0) continue;
           const RecRegs r = load_rec(gv.recs, rix);
           const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
           const float x1 = static_cast<float>(static_cast<double>(ty) - r.my);
           const float x2 = static_cast<float>(static_cast<double>(tz) - r.mz);
-          accumulate_neighbor_factored<WANT_H>(acc[0], acc[28], pa, x0, x1, x2, r, prm.d1, prm.d2);
+          accumulate_neighbor_factored<WANT_H>(pa, x0, x1, x2, r, prm.d1, prm.d2);
         }
-    if (acc[28] != nn0) {
+    if (pa.nn != 0) {
       PointDeriv d;
-      point_derivatives(prm, pt.x, pt.y, pt.z, d, WANT_H);
+      point_derivatives<WANT_H>(tab, pt.x, pt.y, pt.z, d);
       finish_point<WANT_H>(acc, pa, d);
     }
   }
@@ -683,15 +692,16 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
     if (!near_grid(gv.g, vi, vj, vk)) continue;
     PointAcc64 pa = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool any = false;
+    const unsigned centre = lut_index(gv.g, vi, vj, vk);
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
-                                  : probe(gv, vi, vj, vk, dx, dy, dz);
+      const int rix = (NNB == 27) ? probe_kd(gv, centre, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
+                                  : probe(gv, centre, dx, dy, dz);
       if (rix < 0) continue;
       const RecRegs r = load_rec(gv.recs, rix);
       // the record keeps icov in its f32 rounding
-      const double c00 = r.c00, c01 = r.c01, c02 = r.c02, c11 = r.c11, c12 = r.c12, c22 = r.c22;
+      const double c00 = r.p0.x, c01 = r.p0.y, c02 = r.p2.x, c11 = r.p1.y, c12 = r.p2.y, c22 = r.p3.y;
       const double x0 = static_cast<double>(tx) - r.mx, x1 = static_cast<double>(ty) - r.my, x2 = static_cast<double>(tz) - r.mz;
       const double xc0 = (c00 * x0 + c01 * x1) + c02 * x2;
       const double xc1 = (c01 * x0 + c11 * x1) + c12 * x2;

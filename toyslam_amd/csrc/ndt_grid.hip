@@ -108,7 +108,7 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   geo.mul[2] = geo.div_b[0] * geo.div_b[1];
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
-  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
   HIP_TRY(rank.reserve(n));
@@ -122,13 +122,12 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   // the leaf count stays on the device (the kernels read it there): leaf arrays are sized for the
   // worst case and the host learns the totals once, at the end, instead of in the middle
   const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));
-  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
   HIP_TRY(leaf_count.reserve(n_leaves));
   HIP_TRY(leaf_rec.reserve(n_leaves));
   HIP_TRY(sorted_idx.reserve(n));
-  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
   HIP_TRY(ndt::launch_sort_gather(d_pts, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p));
@@ -174,7 +173,7 @@ ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   for (size_t k = 0; k <= n_scans; k++) off[k] = static_cast<int>(offsets[k] - offsets[0]);
   for (size_t k = 0; k < n_scans; k++) max_scan = std::max(max_scan, offsets[k + 1] - offsets[k]);
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
-  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx, d_off;
+  DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx, d_off;
   HIP_TRY(d_off.reserve(n_scans + 1));
   HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n_scans + 1) * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(cell_count.reserve(static_cast<size_t>(total_cells) + 1));
@@ -193,13 +192,12 @@ ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   unsigned tot[3];
   HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));  // read after the final synchronise
   const size_t n_leaves = std::min<size_t>(c->n, static_cast<size_t>(scan_cells));  // upper bound; the count stays on the device
-  HIP_TRY(lut.reserve(static_cast<size_t>(scan_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
   HIP_TRY(leaf_count.reserve(n_leaves));
   HIP_TRY(leaf_rec.reserve(n_leaves));
   HIP_TRY(sorted_idx.reserve(c->n));
-  HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   // start offset of every scan's first cell (+ the sentinel cell = grand total)
   std::vector<unsigned> starts(n_scans + 1);
@@ -306,14 +304,19 @@ ndt_status build_grid(ndt_context* h) {
   // Two host round trips (~30 us each) less per target; nothing below waits for the GPU.
   const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
   const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
-  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.n_cells)));
+  ndt::set_padded_lut(geo);
+  // every cell of the padded table starts out empty (kLutEmpty = -1 = all bits set); the finalize pass fills in the
+  // voxels that reached min_points_per_voxel
+  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
+  HIP_TRY(hipMemsetAsync(g->lut.p, 0xFF, static_cast<size_t>(geo.lut_cells) * sizeof(int), st));
   HIP_TRY(g->leaf_cell.reserve(max_leaves));
   HIP_TRY(g->leaf_start.reserve(max_leaves));
   HIP_TRY(g->leaf_count.reserve(max_leaves));
   HIP_TRY(g->leaf_rec.reserve(max_leaves));
   HIP_TRY(g->sorted_idx.reserve(n));
   HIP_TRY(g->recs.reserve(max_cand));
-  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->lut.p, g->leaf_cell.p,
+  HIP_TRY(g->centroids.reserve(max_cand));
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->leaf_cell.p,
                                  g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
   // ---- scatter + finalize
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
@@ -323,8 +326,8 @@ ndt_status build_grid(ndt_context* h) {
   if (!h->index_only) {
     HIP_TRY(big_pts.reserve(n));
     HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
-                                 static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p,
-                                 g->lut.p, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
+                                 static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p, g->centroids.p,
+                                 g->lut.p, geo, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
   }
   // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
   // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
@@ -453,7 +456,7 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   geo.mul[2] = geo.div_b[0] * geo.div_b[1];
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
-  DevBuf<int> key, lut, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
   HIP_TRY(rank.reserve(n));
@@ -465,13 +468,12 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, st));
   HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
   const size_t n_leaves = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));  // upper bound; the count stays on the device
-  HIP_TRY(lut.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(leaf_cell.reserve(n_leaves));
   HIP_TRY(leaf_start.reserve(n_leaves));
   HIP_TRY(leaf_count.reserve(n_leaves));
   HIP_TRY(leaf_rec.reserve(n_leaves));
   HIP_TRY(sorted_idx.reserve(n));
-  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, lut.p, leaf_cell.p, leaf_start.p,
+  HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, 1, block_sums.p, n_tiles, leaf_cell.p, leaf_start.p,
                                  leaf_count.p, leaf_rec.p, st));
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
   DevBuf<float4> big_pts;  // scratch of the crowded-voxel path (k_presort_large)
@@ -726,8 +728,8 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
   HIP_TRY(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned), h->stream));
   ndt::FinalizeDump dump{d_n.p, d_mean.p, d_cov.p, d_icov.p, d_evals.p};
   HIP_TRY(ndt::launch_finalize(g->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
-                               static_cast<int>(V), g->sorted_idx.p, g->min_pts, g->eig_ratio, g->recs.p, g->lut.p,
-                               d_cnt.p, dump, h->stream));
+                               static_cast<int>(V), g->sorted_idx.p, g->min_pts, g->eig_ratio, g->recs.p, g->centroids.p, g->lut.p,
+                               g->geom, d_cnt.p, dump, h->stream));
   std::vector<int> cell(V);
   HIP_TRY(hipMemcpyAsync(cell.data(), g->leaf_cell.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   if (nr_points) HIP_TRY(hipMemcpyAsync(nr_points, d_n.p, V * sizeof(int), hipMemcpyDeviceToHost, h->stream));

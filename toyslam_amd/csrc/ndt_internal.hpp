@@ -198,6 +198,7 @@ struct DeviceGrid {
   std::shared_ptr<DeviceCloud> target;  // kept for the dump pass
   DevBuf<int> lut;
   DevBuf<ndt::VoxelRec> recs;
+  DevBuf<float4> centroids;  // per record: voxel centroid (KDTREE search)
   DevBuf<int> leaf_cell, leaf_count, leaf_rec, sorted_idx;
   DevBuf<unsigned> leaf_start;
   size_t n_sorted = 0;  // target points that landed in a voxel (finite ones)
@@ -213,6 +214,7 @@ struct DeviceGrid {
     ndt::GridView v;
     v.lut = lut.p;
     v.recs = recs.p;
+    v.centroids = centroids.p;
     v.g = geom;
     return v;
   }

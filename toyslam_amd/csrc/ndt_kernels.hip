@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(unsigned* __restrict__ b
 
 __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* __restrict__ cell_count /* -> cursor */,
                                                        long long n_cells, unsigned min_pts,
-                                                       const unsigned* __restrict__ block_sums, int* __restrict__ lut,
+                                                       const unsigned* __restrict__ block_sums,
                                                        int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
                                                        int* __restrict__ leaf_count, int* __restrict__ leaf_rec) {
   const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
@@ -282,7 +282,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* __restrict__ ce
   for (int k = 0; k < kScanItems; k++) {
     const long long c = base + k;
     if (c < n_cells) {
-      lut[c] = -1;
       cell_count[c] = run.pts;  // scatter cursor
       if (cnt[k] > 0) {
         leaf_cell[run.occ] = static_cast<int>(c);
@@ -498,8 +497,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
                                                      const int* __restrict__ leaf_count,
                                                      const int* __restrict__ leaf_rec, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
-                                                     VoxelRec* __restrict__ recs, int* __restrict__ lut,
-                                                     unsigned* __restrict__ n_valid, FinalizeDump dump,
+                                                     VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
+                                                     GridGeom geom, unsigned* __restrict__ n_valid, FinalizeDump dump,
                                                      const float4* __restrict__ big_pts) {
   // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
   // covariance formula (_impl.hpp:329-330) cancels catastrophically when the coordinates are large
@@ -618,21 +617,30 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
       // centroid to the KD-tree BEFORE the eigenvalue / inverse checks (_impl.hpp:302-326 vs
       // :337-341,:360-364), so KDTREE search still returns a rejected voxel (trap 7), with the
       // icov_ it was left with (zero, or the inf-bearing inverse).  DIRECT searches skip it
-      // (nr_points = -1): the LUT entry carries kLutRejected.
+      // (nr_points = -1): the LUT entry is lut_rejected(r).
       const int r = leaf_rec[o];
       VoxelRec rec;
       rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
-      rec.icov[0] = static_cast<float>(icov[0][0]); rec.icov[1] = static_cast<float>(icov[0][1]);
-      rec.icov[2] = static_cast<float>(icov[0][2]); rec.icov[3] = static_cast<float>(icov[1][1]);
-      rec.icov[4] = static_cast<float>(icov[1][2]); rec.icov[5] = static_cast<float>(icov[2][2]);
-      rec.centroid[0] = fx; rec.centroid[1] = fy; rec.centroid[2] = fz;
+      const float c00 = static_cast<float>(icov[0][0]), c01 = static_cast<float>(icov[0][1]), c02 = static_cast<float>(icov[0][2]);
+      const float c11 = static_cast<float>(icov[1][1]), c12 = static_cast<float>(icov[1][2]), c22 = static_cast<float>(icov[2][2]);
+      rec.p0[0] = c00; rec.p0[1] = c01;
+      rec.p1[0] = c01; rec.p1[1] = c11;
+      rec.p2[0] = c02; rec.p2[1] = c12;
+      rec.p3[0] = c11; rec.p3[1] = c22;
       rec.n = cnt;
+      rec.pad = 0;
       recs[r] = rec;
+      centroids[r] = make_float4(fx, fy, fz, 0.0f);
+      // the cell's slot in the padded look-up table
+      const int c = leaf_cell[o];
+      const int cz = c / geom.mul[2], cy = (c - cz * geom.mul[2]) / geom.mul[1], cx = c - cz * geom.mul[2] - cy * geom.mul[1];
+      const long long slot = static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * geom.pmul[1] +
+                             static_cast<long long>(cz + kLutBorder) * geom.pmul[2];
       if (nr_points >= min_pts) {
-        lut[leaf_cell[o]] = r;
+        lut[slot] = r;
         is_valid = true;
       } else {
-        lut[leaf_cell[o]] = r | kLutRejected;
+        lut[slot] = lut_rejected(r);
       }
     }
   }
@@ -662,13 +670,16 @@ __global__ __launch_bounds__(kBlock) void k_derivatives_stamped(const float4* __
                                                                 EvalParams P, double* __restrict__ partials,
                                                                 unsigned long long* __restrict__ stamps) {
   __shared__ double lds[(kBlock / kWave) * 32];
+  __shared__ PackedTables sT;
+  pack_tables(P, sT, threadIdx.x, kBlock);
+  __syncthreads();
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   st[0] = stamp();
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
   const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-  derivatives_body<7, true, EvalParams, true>(src, n, gv, P, first, stride, acc, st);
+  derivatives_body<7, true, true>(src, n, gv, P, sT, first, stride, acc, st);
   const double tot = wave_fold<kNumAcc>(acc);
   st[5] = stamp();
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -686,39 +697,33 @@ __global__ __launch_bounds__(kBlock) void k_derivatives_stamped(const float4* __
   }
 }
 
-template <int NNB, bool WANT_H, bool BATCH, int VARIANT>
+template <int NNB, bool WANT_H, bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                         const ScanDesc* __restrict__ descs, const int* __restrict__ active,
                                                         int max_blocks, double* __restrict__ partials) {
   __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ EvalParams sP;
+  __shared__ PackedTables sT;
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
   const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-  if (BATCH) {
-    // grid.y walks the scans that asked for THIS kind of evaluation in this step
-    const int scan = active[blockIdx.y];
-    const ScanDesc* dsc = descs + scan;
-    const int* sp = reinterpret_cast<const int*>(&dsc->P);
+  // parameters through LDS: as kernel arguments they overflow the SGPR file.  BATCH: grid.y walks the scans that asked
+  // for THIS kind of evaluation in this step
+  const int scan = BATCH ? active[blockIdx.y] : 0;
+  const ScanDesc* dsc = BATCH ? descs + scan : nullptr;
+  {
+    const int* sp = BATCH ? reinterpret_cast<const int*>(&dsc->P) : reinterpret_cast<const int*>(&P);
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
-    __syncthreads();
-    if (NNB == 27) derivatives_body_kd<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
-    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
-    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src + dsc->offset, dsc->count, gv, sP, first, stride, acc);
-    block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
-  } else {
-    // parameters through LDS here too: as kernel arguments they overflow the SGPR file
-    const int* sp = reinterpret_cast<const int*>(&P);
-    int* dp = reinterpret_cast<int*>(&sP);
-    for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += kBlock) dp[t] = sp[t];
-    __syncthreads();
-    if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, first, stride, acc);
-    else if (VARIANT == 1) derivatives_body_split7<WANT_H>(src, n, gv, sP, first, stride, acc);
-    else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, VARIANT == 0>(src, n, gv, sP, first, stride, acc);
-    block_reduce_store<kNumAcc>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
+    pack_tables(*reinterpret_cast<const EvalParams*>(sp), sT, threadIdx.x, kBlock);
   }
+  __syncthreads();
+  const float4* pts = BATCH ? src + dsc->offset : src;
+  const int cnt = BATCH ? dsc->count : n;
+  if (NNB == 27) derivatives_body_kd<WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
+  block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
 }
 
 template <int NNB, bool BATCH>
@@ -765,6 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict_
   __shared__ double lds[(kBlock / kWave) * 32];
   __shared__ EvalParams sP;
   __shared__ Hess64Params sP64;
+  __shared__ PackedTables sT;
   const int scan = active[blockIdx.y];
   const ScanDesc* dsc = descs + scan;
   const int kind = dsc->kind;
@@ -773,6 +779,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict_
     int* dp = (kind == 2) ? reinterpret_cast<int*>(&sP64) : reinterpret_cast<int*>(&sP);
     const int words = static_cast<int>(((kind == 2) ? sizeof(Hess64Params) : sizeof(EvalParams)) / 4);
     for (int t = threadIdx.x; t < words; t += kBlock) dp[t] = sp[t];
+    if (kind != 2) pack_tables(dsc->P, sT, threadIdx.x, kBlock);
   }
   __syncthreads();
   double acc[kNumAcc];
@@ -784,11 +791,11 @@ __global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict_
   if (kind == 2) {
     hessian64_body<NNB, true>(pts, n, gv, sP64, first, stride, acc);
   } else if (NNB == 27) {
-    if (kind == 0) derivatives_body_kd<true>(pts, n, gv, sP, first, stride, acc);
-    else derivatives_body_kd<false>(pts, n, gv, sP, first, stride, acc);
+    if (kind == 0) derivatives_body_kd<true>(pts, n, gv, sP, sT, first, stride, acc);
+    else derivatives_body_kd<false>(pts, n, gv, sP, sT, first, stride, acc);
   } else {
-    if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true>(pts, n, gv, sP, first, stride, acc);
-    else derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true>(pts, n, gv, sP, first, stride, acc);
+    if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true>(pts, n, gv, sP, sT, first, stride, acc);
+    else derivatives_body<NNB == 27 ? 7 : NNB, false>(pts, n, gv, sP, sT, first, stride, acc);
   }
   block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
 }
@@ -965,12 +972,13 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
     int vi, vj, vk;
     search_ijk(gv.g, pt.x, pt.y, pt.z, vi, vj, vk);
     if (!near_grid(gv.g, vi, vj, vk)) continue;
+    const unsigned centre = lut_index(gv.g, vi, vj, vk);
     int rec[NNB];
     int cnt = 0;
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      rec[k] = (NNB == 27) ? probe_kd(gv, vi, vj, vk, dx, dy, dz, pt.x, pt.y, pt.z, r2) : probe(gv, vi, vj, vk, dx, dy, dz);
+      rec[k] = (NNB == 27) ? probe_kd(gv, centre, dx, dy, dz, pt.x, pt.y, pt.z, r2) : probe(gv, centre, dx, dy, dz);
       cnt += (rec[k] >= 0);
     }
     for (int k = 0; k < NNB; k++) {
@@ -978,9 +986,10 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
       const RecRegs r = load_rec(gv.recs, rec[k]);
       const double x0 = static_cast<double>(pt.x) - r.mx, x1 = static_cast<double>(pt.y) - r.my,
                    x2 = static_cast<double>(pt.z) - r.mz;
-      const double c0 = (static_cast<double>(r.c00) * x0 + static_cast<double>(r.c01) * x1) + static_cast<double>(r.c02) * x2;
-      const double c1 = (static_cast<double>(r.c01) * x0 + static_cast<double>(r.c11) * x1) + static_cast<double>(r.c12) * x2;
-      const double c2 = (static_cast<double>(r.c02) * x0 + static_cast<double>(r.c12) * x1) + static_cast<double>(r.c22) * x2;
+      const double c00 = r.p0.x, c01 = r.p0.y, c02 = r.p2.x, c11 = r.p1.y, c12 = r.p2.y, c22 = r.p3.y;
+      const double c0 = (c00 * x0 + c01 * x1) + c02 * x2;
+      const double c1 = (c01 * x0 + c11 * x1) + c12 * x2;
+      const double c2 = (c02 * x0 + c12 * x1) + c22 * x2;
       const double e = exp(-d2 * ((x0 * c0 + x1 * c1) + x2 * c2) / 2);
       acc[0] += (-d1 * e - d3) / cnt;
     }
@@ -1004,23 +1013,16 @@ inline int grid_for(size_t n, int max_blocks) {
 // ===========================================================================
 // launchers
 // ===========================================================================
-// Tunables (development aid): NDT_K2_SPLIT=0 selects the point-per-lane DIRECT7 kernel,
-// NDT_K2_MAX_BLOCKS caps the grid.
+// Tunable (development aid): NDT_K2_MAX_BLOCKS caps the grid.
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-// DIRECT7 kernel variant: 0 = factored, point per lane (default); 1 = one (point, neighbour)
-// task per lane; 2 = per-neighbour math in the reference's operation order (validation).
-int derivative_variant() {
-  static const int v = env_int("NDT_K2_VARIANT", 0);
-  return v;
-}
-bool derivative_split7() { return derivative_variant() == 1; }
+int derivative_variant() { return 0; }  // (the development variants of round 1 are gone: one body, spelled out by hand)
 int derivative_blocks(int n, int search) {
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
-  const size_t tasks = (search != 1 && search != 3 && derivative_split7()) ? static_cast<size_t>(n) * 8 : static_cast<size_t>(n);
-  return grid_for(tasks, cap);
+  (void)search;
+  return grid_for(static_cast<size_t>(n), cap);
 }
 
 hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream) {
@@ -1062,10 +1064,10 @@ hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_t
 }
 
 hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
-                             const unsigned* d_block_sums, int n_tiles, int* d_lut, int* d_leaf_cell,
+                             const unsigned* d_block_sums, int n_tiles, int* d_leaf_cell,
                              unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream) {
   hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(kBlock), 0, stream, d_cell_count_to_cursor, n_cells,
-                     static_cast<unsigned>(min_pts), d_block_sums, d_lut, d_leaf_cell, d_leaf_start, d_leaf_count,
+                     static_cast<unsigned>(min_pts), d_block_sums, d_leaf_cell, d_leaf_start, d_leaf_count,
                      d_leaf_rec);
   return hipGetLastError();
 }
@@ -1078,16 +1080,16 @@ hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const
 
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
-                           int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
-                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, float4* d_centroids, int* d_lut, const GridGeom& geom,
+                           unsigned* d_n_valid, FinalizeDump dump, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
   // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
   if (n_leaves == 0) return hipSuccess;
   if (d_big_pts)  // leaves with many points: sorted and gathered by one wave each, ahead of the per-leaf pass
     hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, d_leaf_start, d_leaf_count, n_leaves,
                        d_totals, d_sorted_idx, d_big_pts, presort_chunk(n_leaves));
   hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
-                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_lut,
-                     d_n_valid, dump, d_big_pts);
+                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_centroids,
+                     d_lut, geom, d_n_valid, dump, d_big_pts);
   return hipGetLastError();
 }
 
@@ -1133,36 +1135,31 @@ hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_sc
 
 int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile - 1) / kScanTile); }
 
-template <int NNB, bool WANT_H, int VARIANT>
+template <int NNB, bool WANT_H>
 static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
                            const int* active, int n_active, int max_blocks, int n_blocks, double* partials,
                            hipStream_t stream) {
   if (descs)
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true, VARIANT>), dim3(n_blocks, n_active), dim3(kBlock), 0, stream, src,
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, true>), dim3(n_blocks, n_active), dim3(kBlock), 0, stream, src,
                        n, gv, P, descs, active, max_blocks, partials);
   else
-    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false, VARIANT>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
+    hipLaunchKernelGGL((k_derivatives<NNB, WANT_H, false>), dim3(n_blocks, 1), dim3(kBlock), 0, stream, src, n,
                        gv, P, descs, active, max_blocks, partials);
 }
 
 hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
                               bool want_hessian, const ScanDesc* descs, const int* active, int n_active, int max_blocks,
                               int n_blocks, double* partials, hipStream_t stream) {
-  // search: 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
-  const int variant = derivative_variant();
-#define NDT_LAUNCH_DERIV(NNB, H, V) launch_deriv_t<NNB, H, V>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream)
+  // search: 0 = KDTREE, 1 = DIRECT26, 2 = DIRECT7 (and the reference's `default:`), 3 = DIRECT1
+#define NDT_LAUNCH_DERIV(NNB, H) launch_deriv_t<NNB, H>(src, n, gv, P, descs, active, n_active, max_blocks, n_blocks, partials, stream)
   if (search == 0) {
-    if (want_hessian) NDT_LAUNCH_DERIV(27, true, 0); else NDT_LAUNCH_DERIV(27, false, 0);
+    if (want_hessian) NDT_LAUNCH_DERIV(27, true); else NDT_LAUNCH_DERIV(27, false);
   } else if (search == 1) {
-    if (want_hessian) NDT_LAUNCH_DERIV(26, true, 0); else NDT_LAUNCH_DERIV(26, false, 0);
+    if (want_hessian) NDT_LAUNCH_DERIV(26, true); else NDT_LAUNCH_DERIV(26, false);
   } else if (search == 3) {
-    if (want_hessian) NDT_LAUNCH_DERIV(1, true, 0); else NDT_LAUNCH_DERIV(1, false, 0);
-  } else if (variant == 1) {
-    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 1); else NDT_LAUNCH_DERIV(7, false, 1);
-  } else if (variant == 2) {
-    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 2); else NDT_LAUNCH_DERIV(7, false, 2);
+    if (want_hessian) NDT_LAUNCH_DERIV(1, true); else NDT_LAUNCH_DERIV(1, false);
   } else {
-    if (want_hessian) NDT_LAUNCH_DERIV(7, true, 0); else NDT_LAUNCH_DERIV(7, false, 0);
+    if (want_hessian) NDT_LAUNCH_DERIV(7, true); else NDT_LAUNCH_DERIV(7, false);
   }
 #undef NDT_LAUNCH_DERIV
   return hipGetLastError();

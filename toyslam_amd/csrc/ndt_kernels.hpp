@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 namespace ndt {
@@ -10,14 +11,17 @@ namespace ndt {
 // One valid target voxel, exactly one 64-byte sector (half a 128-B L2 line):
 //   mean  : 3 x f64  -- the reference subtracts the f64 mean from the f32 point
 //                       in f64 and only then rounds to f32 (ndt_omp_impl.hpp:262,492)
-//   icov  : 6 x f32  -- upper triangle xx,xy,xz,yy,yz,zz of Sigma^-1, stored as the
-//                       f32 the reference casts to per use (:494)
-//   cx,cy,cz : f32 centroid (voxel_centroids_ entry), n : point count
+//   icov  : the six entries of Sigma^-1 (symmetric) as the f32 the reference casts to per use (:494), laid out
+//           as the four register PAIRS the packed f32 math of the derivative kernels multiplies by
+//           (v_pk_fma_f32 takes both halves of an operand from ONE aligned register pair):
+//             p0 = (c00, c01)   p1 = (c01, c11)   p2 = (c02, c12)   p3 = (c11, c22)
+//           -- c01 and c11 are stored twice so that no pair has to be assembled with moves
+//   n     : point count.  (The voxel centroid, read only by the KDTREE search, lives in GridView::centroids.)
 struct alignas(64) VoxelRec {
   double mean[3];
-  float icov[6];
-  float centroid[3];
+  float p0[2], p1[2], p2[2], p3[2];
   int n;
+  int pad;
 };
 static_assert(sizeof(VoxelRec) == 64, "VoxelRec must be one 64-B sector");
 
@@ -30,11 +34,38 @@ struct GridGeom {
   int div_b[3];
   int mul[3];
   long long n_cells;
+  // the voxel look-up table of the evaluation kernels is laid out over the bounding box PLUS a border of
+  // kLutBorder empty cells on every side: a point within one cell of the box (near_grid) probes its 7 / 26 / 27
+  // neighbour cells without a bounds test per probe (the reference's test, _impl.hpp:382-392, is what the border
+  // encodes).  pmul: strides of that padded table; lut_cells: its size.
+  int pmul[3];
+  long long lut_cells;
+  int pow2;  // every leaf size is a power of two: floor(x / leaf) == floor(x * inv_leaf) exactly
 };
+constexpr int kLutBorder = 2;
+inline void set_padded_lut(GridGeom& g) {
+  g.pmul[0] = 1;
+  g.pmul[1] = g.div_b[0] + 2 * kLutBorder;
+  g.pmul[2] = g.pmul[1] * (g.div_b[1] + 2 * kLutBorder);
+  g.lut_cells = static_cast<long long>(g.pmul[2]) * (g.div_b[2] + 2 * kLutBorder);
+  g.pow2 = 1;
+  for (int k = 0; k < 3; k++) {
+    int e = 0;
+    const float m = std::frexp(g.leaf[k], &e);
+    if (m != 0.5f) g.pow2 = 0;
+  }
+}
+
+// LUT entry: record index (>= 0) of a valid voxel; kLutEmpty; or lut_rejected(r) (<= -2) for a voxel that
+// reached min_points_per_voxel but was rejected (nr_points = -1, _impl.hpp:337-341,360-364): the DIRECT
+// searches skip it, the KDTREE search still sees its record (trap 7).
+constexpr int kLutEmpty = -1;
+__host__ __device__ inline int lut_rejected(int r) { return -(r + 2); }
 
 struct GridView {
-  const int* lut;        // n_cells entries: record index or -1
-  const VoxelRec* recs;  // valid voxels
+  const int* lut;            // padded table, g.lut_cells entries
+  const VoxelRec* recs;      // one record per voxel with >= min_points_per_voxel points
+  const float4* centroids;   // per record: voxel centroid (voxel_centroids_ entry), KDTREE search only
   GridGeom g;
 };
 
@@ -103,7 +134,7 @@ hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, i
                               int n_tiles, hipStream_t stream);
 hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream);
 hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
-                             const unsigned* d_block_sums, int n_tiles, int* d_lut, int* d_leaf_cell,
+                             const unsigned* d_block_sums, int n_tiles, int* d_leaf_cell,
                              unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream);
 hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const unsigned* d_cell_start, int* d_sorted_idx,
                           hipStream_t stream);
@@ -117,8 +148,8 @@ struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
 };
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
-                           int min_pts, double eig_ratio, VoxelRec* d_recs, int* d_lut, unsigned* d_n_valid,
-                           FinalizeDump dump, hipStream_t stream, const unsigned* d_totals = nullptr,
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, float4* d_centroids, int* d_lut, const GridGeom& geom,
+                           unsigned* d_n_valid, FinalizeDump dump, hipStream_t stream, const unsigned* d_totals = nullptr,
                            float4* d_big_pts = nullptr /* n points of scratch: enables the wave pre-sort of crowded leaves */);
 
 // K2: derivatives.  search: NDT_DIRECT26/7/1.  Single scan: descs == nullptr, params by value,
@@ -184,7 +215,6 @@ hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& 
                                       double* partials, unsigned long long* stamps, hipStream_t stream);
 hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream);
 int derivative_blocks(int n, int search);  // grid size used for n source points
-bool derivative_split7();
 int derivative_variant();
 int scan_tiles(long long n_cells);  // number of 2048-cell tiles of the cell scan
 

@@ -36,10 +36,12 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   // The 81 parameter words go to LDS first: read from the kernel arguments they occupy ~90 SGPRs,
   // which spill to VGPR lanes (v_readlane / v_writelane made up ~20 % of this kernel's VALU count).
   __shared__ EvalParams sP;
+  __shared__ PackedTables sT;
   {
     const int* sp = reinterpret_cast<const int*>(&P);
     int* dp = reinterpret_cast<int*>(&sP);
     for (int t = threadIdx.x; t < static_cast<int>(sizeof(EvalParams) / 4); t += TPB) dp[t] = sp[t];
+    pack_tables(P, sT, threadIdx.x, TPB);
   }
   __syncthreads();
   double acc[kNumAcc];
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   // neighbour counts better than one contiguous range per block (measured: -8 % at 2M points)
   // ppb points per block (points_per_block(n)): small scans use only the first ppb lanes of a block, see there
   const int first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
-  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, first, gridDim.x * ppb, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, EvalParams, false, true>(src, n, gv, sP, first, gridDim.x * ppb, acc);
+  if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   __shared__ double lds[kWaves * 32];
   __shared__ EvalParams sP;
   __shared__ Hess64Params sP64;
+  __shared__ PackedTables sT;
   __shared__ double s_f[8];  // 1, sx, cx, sy, cy, sz, cz
   __shared__ int s_kind;
   __shared__ int s_last;
@@ -215,7 +218,9 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   float4 my_pt = make_float4(0.f, 0.f, 0.f, 0.f);
   if (my_first < n) my_pt = src[my_first];
   unsigned terms_lo = 0, terms_hi = 0;  // this thread's row of kAngleTerms (threads 0..68 build the angle tables)
+  int pack_pos = 0;                     // ... and where its coefficient goes in PackedTables
   if (threadIdx.x < 69) {
+    pack_pos = kPackPos[threadIdx.x];
     const signed char* t = kAngleTerms[threadIdx.x];
     for (int k = 0; k < 4; k++) {
       terms_lo |= static_cast<unsigned>(static_cast<unsigned char>(t[k])) << (8 * k);
@@ -328,8 +333,7 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
         else sP64.hd[(tid - 24) / 3][(tid - 24) % 3] = c64;
       } else {  // the f32 matrices hold the same values rounded, except h_ang row d1, z: +sy (:383)
         const float c = static_cast<float>((tid == 24 + 6 * 3 + 2) ? s_f[3] : c64);
-        if (tid < 24) sP.j[tid / 3][tid % 3] = c;
-        else sP.h[(tid - 24) / 3][(tid - 24) % 3] = c;
+        reinterpret_cast<float*>(&sT)[pack_pos] = c;  // straight into the pair layout of the packed math
       }
     }
     __syncthreads();
@@ -350,11 +354,11 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       asm volatile("" : "+v"(first64));
       hessian64_body<NNB, true>(src, limit, gv, sP64, first64, stride, acc);
     } else if (NNB == 27) {
-      if (kind == 0) derivatives_body_kd<true>(src, limit, gv, sP, first, stride, acc);
-      else if (kind == 1) derivatives_body_kd<false>(src, limit, gv, sP, first, stride, acc);
+      if (kind == 0) derivatives_body_kd<true>(src, limit, gv, sP, sT, first, stride, acc);
+      else if (kind == 1) derivatives_body_kd<false>(src, limit, gv, sP, sT, first, stride, acc);
     } else {
-      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, EvalParams, false, true, true>(src, limit, gv, sP, first, stride, acc, nullptr, my_pt);
-      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, EvalParams, false, true, true>(src, limit, gv, sP, first, stride, acc, nullptr, my_pt);
+      if (kind == 0) derivatives_body<NNB == 27 ? 7 : NNB, true, false, true>(src, limit, gv, sP, sT, first, stride, acc, nullptr, my_pt);
+      else if (kind == 1) derivatives_body<NNB == 27 ? 7 : NNB, false, false, true>(src, limit, gv, sP, sT, first, stride, acc, nullptr, my_pt);
     }
     if (fine && tid == 0) fine[1] = __builtin_amdgcn_s_memrealtime();
     const double tot = wave_fold<kNumAcc>(acc);
