@@ -203,6 +203,14 @@ ndt_status ndt_align_batch_device(ndt_handle h, const void* d_pts, const size_t*
                                   size_t stride_bytes, const float* guesses, float* final_transformations,
                                   int* has_converged, int* final_num_iteration, double* transformation_probability);
 
+/* How many independent lock-step groups ndt_align_batch* runs the batch as (each on a stream and a host thread of
+ * its own, so one group's host-side Newton / More-Thuente steps and launches hide behind the other groups' kernels):
+ * 0 = automatic (2 from 16 scans, 4 from 256), 1 = one lock-step loop.  Every scan's result is independent of the
+ * members of its group; with the spatial ordering of the batch common to a group, results of different groupings
+ * agree to the rounding of the f64 sums.  Batches with an exchange step (communicator / all-reduce hook) always run as
+ * one loop. */
+ndt_status ndt_set_batch_groups(ndt_handle h, int n_groups);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------
  * The reference is a single process (ndt_omp_impl.hpp:206 is its only parallel construct); this is the exchange step
  * north_star adds.  Registrations of different scans are independent, so ndt_align_batch* on every rank over its own

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ndt_align_batch": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_align_batch_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int]),
+    "ndt_set_batch_groups": (C.c_int, [vp, C.c_int]),
     "ndt_align_batch_sharded": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_align_batch_sharded_device": (C.c_int, [vp, vp, szp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, fp, fp, ip, ip, dp]),
     "ndt_comm_get_unique_id": (C.c_int, [vp]),

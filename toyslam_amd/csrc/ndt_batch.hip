@@ -253,8 +253,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   }
   // rows of partials reserved per scan; the blocks actually used per scan follow the number of
   // scans that want the same kind of evaluation in a step (few active scans -> more blocks each)
-  const int max_blocks = ndt::derivative_blocks(static_cast<int>(max_n), h->search);
-  constexpr int kBlockBudget = 4096;
+  const int max_blocks = ndt::batch_blocks(static_cast<int>(max_n));
   HIP_TRY(h->partials.reserve(total * max_blocks * ndt::kEvalStride));
   HIP_TRY(h->descs.reserve((pinned_need + sizeof(ndt::ScanDesc) - 1) / sizeof(ndt::ScanDesc)));  // descriptors + the 3 active lists
   const ndt::GridView gv = h->grid->view();
@@ -264,7 +263,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     if (v) return std::max(1, atoi(v));
     return static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
   }();
-  StepPool pool(total >= 32 ? n_host_threads : 1);
+  StepPool pool((total >= 32 && !h->is_batch_worker) ? n_host_threads : 1);  // grouped batches: the groups are the host parallelism
   static const bool batch_timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   double t_fill = 0, t_gpu = 0, t_feed = 0;
   int n_steps = 0;
@@ -290,23 +289,19 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       active[kind * total + n_act[kind]++] = static_cast<int>(g);
     }
     if (n_live_all == 0) break;
-    int nblk_kind[3];
-    for (int c = 0; c < 3; c++) nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / std::max(1, n_act[c])));
     // scans asking for different kinds in the same step: one launch over all of them
     const int n_live = n_act[0] + n_act[1] + n_act[2];
-    const bool mixed = (n_act[0] != n_live && n_act[1] != n_live && n_act[2] != n_live) && ndt::derivative_variant() == 0;
+    const bool mixed = (n_act[0] != n_live && n_act[1] != n_live && n_act[2] != n_live);
     if (mixed) {
       int* all = active + 3 * total;
       int m = 0;
-      for (int c = 0; c < 3; c++) {
-        nblk_kind[c] = std::max(1, std::min(max_blocks, kBlockBudget / n_live));
+      for (int c = 0; c < 3; c++)
         for (int i = 0; i < n_act[c]; i++) all[m++] = active[c * total + i];
-      }
     }
     pool.run(total, [&](size_t g) {  // per-scan parameter tables (sin/cos, pose -> matrix)
       if (descs[g].kind == ndt::EVAL_NONE) return;
       const ndt::EvalRequest& rq = solvers[g].request();
-      descs[g].pad = nblk_kind[descs[g].kind];
+      descs[g].pad = ndt::batch_blocks(descs[g].count);  // the scan's own block count: its sums do not depend on the batch around it
       if (rq.kind == ndt::EVAL_HESSIAN_F64) fill_h64_params(rq, gs, kd_radius2(h->resolution), descs[g].P64);
       else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[g].P);
     });
@@ -322,11 +317,11 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       if (exchange) HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, total * ndt::kEvalStride * sizeof(double), h->stream));
       if (h->profiling) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
       if (mixed) {
-        HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * total, n_live, max_blocks, nblk_kind[0], h->partials.p, h->stream));
+        HIP_TRY(ndt::launch_batch_step(batch_pts, gv, h->search, h->descs.p, d_active + 3 * total, n_live, max_blocks, max_blocks, h->partials.p, h->stream));
       } else {
-        if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, d_active, n_act[0], max_blocks, nblk_kind[0], h->partials.p, h->stream));
-        if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + total, n_act[1], max_blocks, nblk_kind[1], h->partials.p, h->stream));
-        if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * total, n_act[2], max_blocks, nblk_kind[2], h->partials.p, h->stream));
+        if (n_act[0]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, true, h->descs.p, d_active, n_act[0], max_blocks, max_blocks, h->partials.p, h->stream));
+        if (n_act[1]) HIP_TRY(ndt::launch_derivatives(batch_pts, 0, gv, dummy, h->search, false, h->descs.p, d_active + total, n_act[1], max_blocks, max_blocks, h->partials.p, h->stream));
+        if (n_act[2]) HIP_TRY(ndt::launch_hessian64(batch_pts, 0, gv, dummy64, h->search, h->descs.p, d_active + 2 * total, n_act[2], max_blocks, max_blocks, h->partials.p, h->stream));
       }
       if (h->profiling) HIP_TRY(hipEventRecord(h->ev_b, h->stream));
       if (exchange) {
@@ -376,7 +371,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     }
     const auto tb3 = now();
     static const bool step_dump = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) >= 2; }();
-    if (step_dump) std::fprintf(stderr, "[step %d] act H=%d noH=%d h64=%d blocks/scan=%d/%d/%d gpu=%.1fus\n", n_steps, n_act[0], n_act[1], n_act[2], nblk_kind[0], nblk_kind[1], nblk_kind[2], secs(tb1, tb2) * 1e6);
+    if (step_dump) std::fprintf(stderr, "[step %d] act H=%d noH=%d h64=%d blocks/scan<=%d gpu=%.1fus\n", n_steps, n_act[0], n_act[1], n_act[2], max_blocks, secs(tb1, tb2) * 1e6);
     t_fill += secs(tb0, tb1);
     t_gpu += secs(tb1, tb2);
     t_feed += secs(tb2, tb3);
@@ -398,13 +393,89 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   return NDT_OK;
 }
 
+// A batch without an exchange step is run as several INDEPENDENT lock-step groups, each on a worker handle of its own
+// (own stream, own staging buffers, the target grid shared) driven by a host thread of its own: while one group's
+// kernels run, the other groups' hosts step their Newton / More-Thuente state machines, upload descriptors and queue
+// their next launches -- the per-step host time (~30-70 us: descriptor fill, H2D, launches, the polled result) that a
+// single lock-step loop leaves the GPU idle for disappears behind the other groups' kernels, and the tail of a group
+// (few live scans) shares the chip with full steps of the others.  A scan's registration does not depend on its
+// group's other members.  NDT_BATCH_GROUPS overrides the group count (1 = the single loop).
+static ndt_status align_batch_grouped(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
+                                      bool on_device, const float* guesses, float* final_T, int* conv, int* iters,
+                                      double* tprob) {
+  static const int forced = [] { const char* v = getenv("NDT_BATCH_GROUPS"); return v ? std::max(1, atoi(v)) : 0; }();
+  const bool exchange = h && (h->comm != nullptr || h->allreduce != nullptr);
+  size_t groups = (h && h->batch_groups_wanted > 0) ? static_cast<size_t>(h->batch_groups_wanted)
+                  : forced                           ? static_cast<size_t>(forced)
+                                                     : (n_scans >= 256 ? 4 : n_scans >= 16 ? 2 : 1);
+  groups = std::min(groups, std::max<size_t>(1, n_scans / 4));
+  // (event pairs around the kernels of a lock-step -- ndt_profile_enable(1) -- only mean something without overlap)
+  if (!h || !offsets || exchange || groups <= 1 || !h->grid || !h->target || h->profiling)
+    return align_batch_impl(h, pts, offsets, n_scans, stride, on_device, guesses, final_T, conv, iters, tprob);
+  ndt_status s0 = ensure_device(h);
+  if (s0) return s0;
+  HIP_TRY(hipStreamSynchronize(h->stream));  // the shared grid may still be under construction on h's stream
+  while (h->batch_workers.size() < groups) {
+    ndt_context* w = new ndt_context();
+    w->device = h->device;
+    w->is_batch_worker = true;
+    h->batch_workers.push_back(w);
+  }
+  std::vector<ndt_status> st(groups, NDT_OK);
+  std::vector<std::string> msg(groups);
+  std::vector<std::thread> threads;
+  for (size_t g = 0; g < groups; g++) {
+    ndt_context* w = h->batch_workers[g];
+    w->resolution = h->resolution;
+    w->step_size = h->step_size;
+    w->outlier_ratio = h->outlier_ratio;
+    w->trans_eps = h->trans_eps;
+    w->max_iter = h->max_iter;
+    w->search = h->search;
+    w->min_pts = h->min_pts;
+    w->eig_ratio = h->eig_ratio;
+    w->target = h->target;
+    w->target_dense = h->target_dense;
+    w->grid = h->grid;
+    const size_t lo = n_scans * g / groups, hi = n_scans * (g + 1) / groups;
+    threads.emplace_back([=, &st, &msg] {
+      ndt_status s = align_batch_impl(w, pts, offsets + lo, hi - lo, stride, on_device, guesses ? guesses + 16 * lo : nullptr,
+                             final_T ? final_T + 16 * lo : nullptr, conv ? conv + lo : nullptr, iters ? iters + lo : nullptr,
+                             tprob ? tprob + lo : nullptr);
+      st[g] = s;
+      if (s) msg[g] = ndt_last_error();
+    });
+  }
+  for (auto& t : threads) t.join();
+  long long ne = 0, nh = 0;
+  double nn_w = 0, pts_w = 0;
+  int steps = 0;
+  for (size_t g = 0; g < groups; g++) {
+    ndt_context* w = h->batch_workers[g];
+    if (st[g]) return fail(st[g], msg[g]);
+    const size_t lo = n_scans * g / groups, hi = n_scans * (g + 1) / groups;
+    const double evals_pts = static_cast<double>(w->n_evals) * (hi > lo ? static_cast<double>(offsets[hi] - offsets[lo]) / static_cast<double>(hi - lo) : 0.0);
+    ne += w->n_evals;
+    nh += w->n_hess;
+    nn_w += w->mean_neighbors * evals_pts;
+    pts_w += evals_pts;
+    steps = std::max(steps, w->batch_lock_steps);
+  }
+  h->n_evals = static_cast<int>(std::min<long long>(ne, INT32_MAX));
+  h->n_hess = static_cast<int>(std::min<long long>(nh, INT32_MAX));
+  h->mean_neighbors = pts_w > 0 ? nn_w / pts_w : 0.0;
+  h->batch_lock_steps = steps;
+  h->batch_groups = static_cast<int>(groups);
+  return NDT_OK;
+}
+
 ndt_status ndt_align_batch(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
                            const float* guesses, float* final_T, int* conv, int* iters, double* tprob) {
-  return align_batch_impl(h, pts, offsets, n_scans, stride, false, guesses, final_T, conv, iters, tprob);
+  return align_batch_grouped(h, pts, offsets, n_scans, stride, false, guesses, final_T, conv, iters, tprob);
 }
 ndt_status ndt_align_batch_device(ndt_handle h, const void* pts, const size_t* offsets, size_t n_scans, size_t stride,
                                   const float* guesses, float* final_T, int* conv, int* iters, double* tprob) {
-  return align_batch_impl(h, pts, offsets, n_scans, stride, true, guesses, final_T, conv, iters, tprob);
+  return align_batch_grouped(h, pts, offsets, n_scans, stride, true, guesses, final_T, conv, iters, tprob);
 }
 ndt_status ndt_align_batch_sharded(ndt_handle h, const void* pts, const size_t* offsets, size_t n_local, size_t first_scan,
                                    size_t total_scans, size_t stride, const float* guesses, float* final_T, int* conv, int* iters,
@@ -417,6 +488,12 @@ ndt_status ndt_align_batch_sharded_device(ndt_handle h, const void* d_pts, const
                                           int* iters, double* tprob) {
   if (total_scans == 0) return fail(NDT_ERR_INVALID, "total_scans must be > 0");
   return align_batch_impl(h, d_pts, offsets, n_local, stride, true, guesses, final_T, conv, iters, tprob, first_scan, total_scans);
+}
+
+ndt_status ndt_set_batch_groups(ndt_handle h, int n_groups) {
+  if (!h || n_groups < 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  h->batch_groups_wanted = n_groups;
+  return NDT_OK;
 }
 
 ndt_status ndt_set_allreduce(ndt_handle h, ndt_allreduce_fn fn, void* user, int on_device) {

@@ -305,8 +305,14 @@ struct ndt_context {
   int comm_rank = 0, comm_world = 1;
   long long comm_collectives = 0;
   int batch_lock_steps = 0;  // lock-steps of the last ndt_align_batch*
+  int batch_groups = 1;      // independent lock-step groups the last batch ran as
+  bool is_batch_worker = false;
+  int batch_groups_wanted = 0;  // ndt_set_batch_groups: 0 = automatic
+  std::vector<ndt_context*> batch_workers;  // worker handles of those groups (own stream and staging each; grid shared)
 
   ~ndt_context() {
+    for (ndt_context* w : batch_workers) delete w;
+    batch_workers.clear();
     ndtc::comm_release(this);
     if (stream) {  // nothing of this handle may still be running when its buffers go back to the pool
       (void)hipSetDevice(device);

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  const int first = blockIdx.x * kBlock + threadIdx.x;
   // parameters through LDS: as kernel arguments they overflow the SGPR file.  BATCH: grid.y walks the scans that asked
   // for THIS kind of evaluation in this step
   const int scan = BATCH ? active[blockIdx.y] : 0;
@@ -721,6 +721,10 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
   __syncthreads();
   const float4* pts = BATCH ? src + dsc->offset : src;
   const int cnt = BATCH ? dsc->count : n;
+  // BATCH: a scan is walked by ITS OWN number of blocks (descs[scan].pad, a function of its size only), whatever the
+  // grid is: its sums do not depend on which other scans share the launch
+  const int stride = BATCH ? dsc->pad * kBlock : static_cast<int>(gridDim.x) * kBlock;
+  if (BATCH && static_cast<int>(blockIdx.x) >= dsc->pad) return;
   if (NNB == 27) derivatives_body_kd<WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
   else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
   block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
@@ -754,7 +758,9 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     prm = &sP;
   }
   double* out = partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride;
-  hessian64_body<NNB>(src, n, gv, *prm, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, acc);
+  const int nb = BATCH ? descs[scan].pad : static_cast<int>(gridDim.x);  // a scan's own block count (see k_derivatives)
+  if (static_cast<int>(blockIdx.x) >= nb) return;
+  hessian64_body<NNB>(src, n, gv, *prm, blockIdx.x * kBlock + threadIdx.x, nb * kBlock, acc);
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
 
@@ -785,7 +791,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict_
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-  const int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  if (static_cast<int>(blockIdx.x) >= dsc->pad) return;  // (uniform; after the barriers above)
+  const int first = blockIdx.x * kBlock + threadIdx.x, stride = dsc->pad * kBlock;
   const float4* pts = src + dsc->offset;
   const int n = dsc->count;
   if (kind == 2) {
@@ -1019,6 +1026,9 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 int derivative_variant() { return 0; }  // (the development variants of round 1 are gone: one body, spelled out by hand)
+// blocks a scan of n points is walked by inside a lock-step batch: four points per thread (the wave fold and the block
+// epilogue are paid once per thread), a function of the scan's size only
+int batch_blocks(int n) { return max(1, min(1024, (n + 4 * kBlock - 1) / (4 * kBlock))); }
 int derivative_blocks(int n, int search) {
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
   (void)search;

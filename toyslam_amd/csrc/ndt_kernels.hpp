@@ -215,6 +215,7 @@ hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& 
                                       double* partials, unsigned long long* stamps, hipStream_t stream);
 hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream);
 int derivative_blocks(int n, int search);  // grid size used for n source points
+int batch_blocks(int n);                   // blocks per scan inside a lock-step batch (a function of the scan's size only)
 int derivative_variant();
 int scan_tiles(long long n_cells);  // number of 2048-cell tiles of the cell scan
 

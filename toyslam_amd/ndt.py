@@ -301,6 +301,10 @@ class NormalDistributionsTransform:
         """setInputSource from a raw host pointer (e.g. the page-locked buffer of a PcdSequence scan)."""
         check(self._L.ndt_set_input_source(self._h, C.c_void_p(host_ptr), n, stride_bytes))
 
+    def setBatchGroups(self, n):
+        """Independent lock-step groups alignBatch runs as (0 = automatic, 1 = one loop)."""
+        check(self._L.ndt_set_batch_groups(self._h, int(n)))
+
     def setAllreduce(self, fn, on_device=False):
         """fn(buffer_address, n_doubles, on_device) -> 0 on success; None removes the hook."""
         if fn is None:
