@@ -285,6 +285,57 @@ ndt_status build_grid(ndt_context* h) {
   if (geo.n_cells <= 0 || geo.n_cells > static_cast<long long>(std::numeric_limits<int32_t>::max()))
     return fail(NDT_ERR_GRID_OVERFLOW, "voxel grid too large");
 
+  const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
+  const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
+  ndt::set_padded_lut(geo);
+  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
+  HIP_TRY(g->counts.reserve(8));  // [points binned, occupied voxels, candidate voxels (>= min_pts), valid voxels, points in crowded cells]
+  HIP_TRY(g->leaf_cell.reserve(max_leaves));
+  HIP_TRY(g->leaf_start.reserve(max_leaves));
+  HIP_TRY(g->leaf_count.reserve(max_leaves));
+  HIP_TRY(g->leaf_rec.reserve(max_leaves));
+  HIP_TRY(g->sorted_idx.reserve(n));
+  // Which form of K1?  The bucket form wins on clouds of moderate density (synthetic sets, maps: 2.5 x at 1M points); clouds
+  // whose points crowd into few voxels (a 0.1 m-filtered scan in 1 m voxels: hundreds per voxel) are built faster by the
+  // general chain, which gives every crowded voxel a workgroup of its own.  A build reports how crowded its cloud was
+  // (counts[4], copied to pinned memory without waiting); the NEXT build of the handle -- the nodes register scan after
+  // scan of the same sensor -- reads that number: by then the upload's synchronisation has long passed it.
+  static const int k1_mode = [] { const char* v = getenv("NDT_K1"); return !v ? 0 : std::strcmp(v, "old") == 0 ? 1 : std::strcmp(v, "new") == 0 ? 2 : 0; }();
+  if (h->k1_feedback && h->k1_feedback_valid) {
+    const unsigned binned = h->k1_feedback[0], crowded = h->k1_feedback[4];
+    if (binned > 0) h->k1_crowded_hint = (static_cast<double>(crowded) > 0.3 * static_cast<double>(binned)) ? 1 : 0;
+  }
+  const bool buckets_on = k1_mode == 2 || (k1_mode == 0 && h->k1_crowded_hint != 1);
+  ndt::GridBuildPlan plan{};
+  if (buckets_on && !h->index_only && ndt::grid_build_plan(geo.n_cells, n, plan)) {
+    // ---- bucket form (ndt_kernels.hip "K1, bucket form"): no per-point global atomic, per-voxel work staged through LDS
+    const size_t K = static_cast<size_t>(plan.n_buckets);
+    const size_t rec_slots = static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1;  // slot = segment start / min_pts
+    HIP_TRY(g->recs.reserve(rec_slots));
+    HIP_TRY(g->centroids.reserve(rec_slots));
+    DevBuf<unsigned> ctrl, blockbase, order;
+    HIP_TRY(ctrl.reserve(4 + K));  // tickets[2], pad[2], bucket_count[K]: zeroed by the build's first kernel
+    HIP_TRY(g->bucket_base.reserve(K + 1));
+    HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
+    HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
+    HIP_TRY(g->bpts.reserve(n));
+    ndt::GridBuildScratch S{};
+    S.tickets = ctrl.p;
+    S.bucket_count = ctrl.p + 4;
+    S.bucket_base = g->bucket_base.p;
+    S.blockbase = blockbase.p;
+    S.bpts = g->bpts.p;
+    S.order = order.p;
+    HIP_TRY(ndt::launch_grid_build_buckets(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
+                                           g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
+    g->plan = plan;
+    g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
+  } else {
+  // every cell of the padded table starts out empty (kLutEmpty = -1 = all bits set); the finalize pass fills in the
+  // voxels that reached min_points_per_voxel
+  HIP_TRY(hipMemsetAsync(g->lut.p, 0xFF, static_cast<size_t>(geo.lut_cells) * sizeof(int), st));
+  HIP_TRY(g->recs.reserve(max_cand));
+  HIP_TRY(g->centroids.reserve(max_cand));
   // ---- count
   DevBuf<unsigned> cell_count, block_sums, rank;
   DevBuf<int> key;
@@ -296,31 +347,16 @@ ndt_status build_grid(ndt_context* h) {
   // ---- scan
   const int n_tiles = ndt::scan_tiles(geo.n_cells);
   HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
-  HIP_TRY(g->counts.reserve(4));  // [points binned, occupied voxels, candidate voxels (>= min_pts), valid voxels]
   HIP_TRY(ndt::launch_scan_reduce(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, st));
   HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, g->counts.p, st));
   // The counts stay on the device: the later kernels read the voxel count there, the arrays are sized
   // for the worst case, and the host fetches the four numbers only if somebody asks (grid_counts()).
   // Two host round trips (~30 us each) less per target; nothing below waits for the GPU.
-  const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
-  const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
-  ndt::set_padded_lut(geo);
-  // every cell of the padded table starts out empty (kLutEmpty = -1 = all bits set); the finalize pass fills in the
-  // voxels that reached min_points_per_voxel
-  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
-  HIP_TRY(hipMemsetAsync(g->lut.p, 0xFF, static_cast<size_t>(geo.lut_cells) * sizeof(int), st));
-  HIP_TRY(g->leaf_cell.reserve(max_leaves));
-  HIP_TRY(g->leaf_start.reserve(max_leaves));
-  HIP_TRY(g->leaf_count.reserve(max_leaves));
-  HIP_TRY(g->leaf_rec.reserve(max_leaves));
-  HIP_TRY(g->sorted_idx.reserve(n));
-  HIP_TRY(g->recs.reserve(max_cand));
-  HIP_TRY(g->centroids.reserve(max_cand));
   HIP_TRY(ndt::launch_scan_apply(cell_count.p, geo.n_cells, h->min_pts, block_sums.p, n_tiles, g->leaf_cell.p,
                                  g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, st));
   // ---- scatter + finalize
   HIP_TRY(ndt::launch_scatter(key.p, rank.p, n, cell_count.p, g->sorted_idx.p, st));
-  HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, sizeof(unsigned), st));
+  HIP_TRY(hipMemsetAsync(g->counts.p + 3, 0, 2 * sizeof(unsigned), st));
   ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   DevBuf<float4> big_pts;  // scratch of the crowded-leaf path (k_presort_large)
   if (!h->index_only) {
@@ -328,6 +364,12 @@ ndt_status build_grid(ndt_context* h) {
     HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p,
                                  static_cast<int>(max_leaves), g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p, g->centroids.p,
                                  g->lut.p, geo, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
+  }
+  }
+  if (!h->index_only) {  // this build's crowding report for the next one (no wait: see above)
+    if (!h->k1_feedback) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->k1_feedback), 8 * sizeof(unsigned), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(h->k1_feedback, g->counts.p, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    h->k1_feedback_valid = true;
   }
   // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
   // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
@@ -340,6 +382,19 @@ ndt_status build_grid(ndt_context* h) {
 // occupied / candidate / valid voxel counts of a built grid (fetched from the device on first use)
 ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
   if (g->counts_known || g->empty) return NDT_OK;
+  std::lock_guard<std::mutex> lock(g->fit_mu);
+  if (g->counts_known) return NDT_OK;
+  if (g->leaves_pending) {  // bucket-form build: number the leaves now that somebody wants them
+    const size_t K = static_cast<size_t>(g->plan.n_buckets);
+    DevBuf<unsigned> scratch;
+    HIP_TRY(scratch.reserve(4 * K + 4));
+    HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->bpts.p, g->bucket_base.p, scratch.p, g->leaf_cell.p, g->leaf_start.p,
+                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    g->leaves_pending = false;
+    g->bpts.release();
+    g->bucket_base.release();
+  }
   unsigned c[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(c, g->counts.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -121,7 +121,30 @@ constexpr int kNumAcc = 29;
 // All launch on `stream` and return the first HIP error.
 hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream);
 
-struct GridBuildScratch;  // opaque, owned by the grid
+// K1 in its bucket form (ndt_kernels.hip): the voxel index space cut into n_buckets runs of cells_per_bucket = 2^shift
+// consecutive cells; pts_per_block points per block of the two point passes.
+struct GridBuildPlan {
+  int shift, n_buckets, cells_per_bucket, pts_per_block, n_blocks;
+};
+// false: the grid is outside the bucket form's range (more than 8192 x 4096 cells): the general path builds it
+bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& plan);
+struct GridBuildScratch {
+  unsigned* tickets;       // [4]: the control words (zeroed by the build), followed by
+  unsigned* bucket_count;  // [n_buckets] (= tickets + 4, zeroed by the build)
+  unsigned* bucket_base;   // [n_buckets + 1]   (kept with the grid: the leaf pass needs it)
+  unsigned* blockbase;     // [n_blocks x n_buckets]
+  float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
+  unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
+};
+// counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
+// [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
+hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
+                                     double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, float4* centroids,
+                                     int* lut, unsigned* counts, hipStream_t stream);
+hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const float4* bpts, const unsigned* bucket_base,
+                              unsigned* scratch /* 4 n_buckets + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count,
+                              int* leaf_rec, unsigned* counts, hipStream_t stream);
+
 // repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
                               int n_blocks, hipStream_t stream);
