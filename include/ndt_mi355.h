@@ -84,6 +84,12 @@ ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t 
 /* Same, for clouds already resident in HBM (device pointers on the handle's device). */
 ndt_status ndt_set_input_target_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense);
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+/* The voxel index behind the target grid and the prefilter (the reference's std::map<size_t, Leaf> keyed by the linear
+ * voxel index, voxel_grid_covariance_omp.h:201): 0 = chosen by occupancy (default), 1 = dense table over the bounding
+ * box, 2 = sparse (sort-based build, hash look-up; what a fine leaf over a wide box needs: the 0.1 m prefilter of
+ * apps/align.cpp:60-69, kilometre-sized maps).  Results are bit-identical either way. */
+ndt_status ndt_set_voxel_index(ndt_handle h, int mode);
+
 /* One uploaded (and spatially ordered) source cloud serving several handles on the same device, the way ndt_clone
  * shares it: `dst` registers the cloud `src` holds.  The levels of a multi-resolution pyramid (BASELINE configs[4]:
  * 2.0 -> 1.0 -> 0.5 m grids over one target, one handle per grid) take every scan from one upload this way, and a

@@ -977,3 +977,71 @@ def test_evaluation_server_gives_up_when_the_host_goes_quiet(mods, pair):
     assert served and scores[0] == scores[1] == scores[2]
     g.align()  # and the handle is fine afterwards
     assert g.hasConverged()
+
+
+# ------------------------------------------------------------------ sparse voxel index (ndt_sparse.hip)
+def test_sparse_voxel_index_equals_dense(mods, pair):
+    """The sort-built, hash-looked-up voxel index against the dense table on the same clouds: identical voxels, bit-identical
+    means / covariances / inverse covariances, bit-identical evaluation sums and registrations -- whatever the search mode."""
+    ndt, po, clouds = mods
+    t, s = pair
+    grids, evals, aligns = {}, {}, {}
+    p = np.array([0.3, -0.2, 0.1, 0.01, -0.02, 0.03])
+    for mode in (1, 2):
+        g = ndt.NormalDistributionsTransform()
+        g.setVoxelIndex(mode)
+        g.setInputTarget(t)
+        g.setInputSource(s)
+        grids[mode] = g.grid()
+        for method in (ndt.DIRECT7, ndt.DIRECT1, ndt.DIRECT26, ndt.KDTREE):
+            g.setNeighborhoodSearchMethod(method)
+            evals[mode, method] = g.eval(p, True)
+            g.align()
+            aligns[mode, method] = (g.getFinalTransformation().copy(), g.getFinalNumIteration())
+        assert np.allclose(g.hessian_f64(p), g.hessian_f64(p))
+    for k in ("idx", "n", "mean", "cov", "icov", "evals"):
+        assert np.array_equal(grids[1][k], grids[2][k]), k
+    for method in (ndt.DIRECT7, ndt.DIRECT1, ndt.DIRECT26, ndt.KDTREE):
+        a, b = evals[1, method], evals[2, method]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], method
+        assert np.array_equal(aligns[1, method][0], aligns[2, method][0]) and aligns[1, method][1] == aligns[2, method][1]
+
+
+def test_sparse_index_is_chosen_for_a_mostly_empty_box_and_matches_the_oracle(mods):
+    """A map 3 km across at 1 m voxels (4.5e8 cells for 3e5 points): the automatic choice is the sparse index; grid and
+    evaluation still equal the oracle's (its std::map does not care about the box either)."""
+    ndt, po, clouds = mods
+    rng = np.random.default_rng(77)
+    centres = rng.uniform([-1500, -1500, 0], [1500, 1500, 40], (300, 3))
+    tgt = (centres[rng.integers(0, 300, 300000)] + rng.normal(0, 1.2, (300000, 3))).astype(np.float32)
+    src = clouds.source_from_target(tgt, 40000)
+    g, o = make_pair(mods, tgt, src)
+    gg, og = g.grid(), o.grid()
+    assert int(np.prod(gg["div_b"].astype(np.int64))) > 2 ** 25
+    assert np.array_equal(gg["idx"], og["idx"]) and np.array_equal(gg["n"], og["n"])
+    assert np.array_equal(gg["mean"], og["mean"])
+    p = np.array([0.3, -0.2, 0.1, 0.005, -0.003, 0.0175])
+    a, b = g.eval(p, True), o.eval(p, True)
+    assert a[3] == pytest.approx(b[3], abs=1e-12)
+    assert a[0] == pytest.approx(b[0], rel=2e-6) and close_sums(a[1], b[1]) and close_sums(a[2], b[2])
+    g.align()
+    r = o.align()
+    assert rot_err(g.getFinalTransformation(), r["T"]) < ROT_TOL and trans_err(g.getFinalTransformation(), r["T"]) < TRANS_TOL
+    assert g.getFinalNumIteration() == r["iterations"]
+
+
+def test_sparse_prefilter_of_a_wide_scan(mods):
+    """pcl::VoxelGrid at 0.1 m over a 300 m wide scan (what apps/align.cpp:60-69 does to every cloud): 5e8 cells for 4e5
+    points -- sparse index by the automatic choice -- equal to the dense path's and to the oracle's centroids."""
+    ndt, po, clouds = mods
+    rng = np.random.default_rng(5)
+    scan = clouds.target_surfaces(400000, extent=300.0, n_boxes=80)
+    g = ndt.NormalDistributionsTransform()
+    ref = po.voxel_grid_filter(scan, 0.1)[0]
+    auto = g.voxelGridFilter(scan, 0.1)
+    assert np.array_equal(auto, ref)
+    g.setVoxelIndex(1)
+    dense = g.voxelGridFilter(scan, 0.1)
+    assert np.array_equal(dense, ref)
+    g.setVoxelIndex(2)
+    assert np.array_equal(g.voxelGridFilter(scan[:50000], 0.5), po.voxel_grid_filter(scan[:50000], 0.5)[0])

@@ -305,18 +305,37 @@ __device__ __forceinline__ unsigned lut_index(const GridGeom& g, int i, int j, i
 }
 __device__ __forceinline__ int lut_offset(const GridGeom& g, int dx, int dy, int dz) { return dx + dy * g.pmul[1] + dz * g.pmul[2]; }
 
+// look-up table entry of voxel (ci, cj, ck) of a SPARSE grid: bounds test as _impl.hpp:382-392, then the hash walk
+__device__ __forceinline__ int lut_entry_hash(const GridView& gv, int ci, int cj, int ck) {
+  if (ci < gv.g.min_b[0] || ci > gv.g.max_b[0] || cj < gv.g.min_b[1] || cj > gv.g.max_b[1] || ck < gv.g.min_b[2] || ck > gv.g.max_b[2])
+    return kLutEmpty;
+  const int key = (ci - gv.g.min_b[0]) * gv.g.mul[0] + (cj - gv.g.min_b[1]) * gv.g.mul[1] + (ck - gv.g.min_b[2]) * gv.g.mul[2];
+  const int2* tab = reinterpret_cast<const int2*>(gv.lut);
+  const unsigned mask = (1u << gv.g.hash_bits) - 1u;
+  for (unsigned h = hash_slot(key, gv.g.hash_bits);; h = (h + 1u) & mask) {
+    const int2 e = tab[h];
+    if (e.x == key) return e.y;
+    if (e.x == -1) return kLutEmpty;
+  }
+}
+// look-up table entry of the voxel at offset (dx, dy, dz) from voxel (vi, vj, vk) (centre = its padded dense index)
+__device__ __forceinline__ int lut_entry(const GridView& gv, int vi, int vj, int vk, unsigned centre, int dx, int dy, int dz) {
+  if (gv.g.hash_bits) return lut_entry_hash(gv, vi + dx, vj + dy, vk + dz);  // uniform
+  return gv.lut[centre + static_cast<unsigned>(lut_offset(gv.g, dx, dy, dz))];
+}
+
 // record index (>= 0) of voxel (i+dx, j+dy, k+dz) if the DIRECT searches may use it, else negative
 // (_impl.hpp:382-399: outside the box, empty, fewer than min_points_per_voxel points, or rejected)
-__device__ __forceinline__ int probe(const GridView& gv, unsigned centre, int dx, int dy, int dz) {
-  return gv.lut[centre + static_cast<unsigned>(lut_offset(gv.g, dx, dy, dz))];
+__device__ __forceinline__ int probe(const GridView& gv, int vi, int vj, int vk, unsigned centre, int dx, int dy, int dz) {
+  return lut_entry(gv, vi, vj, vk, centre, dx, dy, dz);
 }
 
 // KDTREE: record index of voxel (i+dx, ...) if it is in the centroid cloud (valid or rejected) and
 // its f32 centroid is closer than the radius -- radiusSearch, voxel_grid_covariance_omp.h:476-505,
 // [FLANN] L2_Simple accumulated in f32, RadiusResultSet keeps dist < r^2.  Else -1.
-__device__ __forceinline__ int probe_kd(const GridView& gv, unsigned centre, int dx, int dy, int dz, float x, float y,
-                                        float z, float r2) {
-  const int e = gv.lut[centre + static_cast<unsigned>(lut_offset(gv.g, dx, dy, dz))];
+__device__ __forceinline__ int probe_kd(const GridView& gv, int vi, int vj, int vk, unsigned centre, int dx, int dy, int dz, float x,
+                                        float y, float z, float r2) {
+  const int e = lut_entry(gv, vi, vj, vk, centre, dx, dy, dz);
   if (e == kLutEmpty) return -1;
   const int rix = (e >= 0) ? e : -(e + 2);
   const float4 c = gv.centroids[rix];
@@ -552,7 +571,7 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
       for (int k = 0; k < NNB; k++) {
         int dx, dy, dz;
         nb_offset<NNB>(k, dx, dy, dz);
-        rec[k] = probe(gv, centre, dx, dy, dz);
+        rec[k] = probe(gv, vi, vj, vk, centre, dx, dy, dz);
         any |= (rec[k] >= 0);
       }
       if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[2] = stamp(); }
@@ -607,7 +626,7 @@ __device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ s
     for (int a = -1; a <= 1; a++)
       for (int b = -1; b <= 1; b++)
         for (int c = -1; c <= 1; c++) {
-          const int rix = probe_kd(gv, centre, a, b, c, tx, ty, tz, r2);
+          const int rix = probe_kd(gv, vi, vj, vk, centre, a, b, c, tx, ty, tz, r2);
           if (rix < 0) continue;
           const RecRegs r = load_rec(gv.recs, rix);
           const float x0 = static_cast<float>(static_cast<double>(tx) - r.mx);
@@ -696,8 +715,8 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      const int rix = (NNB == 27) ? probe_kd(gv, centre, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
-                                  : probe(gv, centre, dx, dy, dz);
+      const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, centre, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
+                                  : probe(gv, vi, vj, vk, centre, dx, dy, dz);
       if (rix < 0) continue;
       const RecRegs r = load_rec(gv.recs, rix);
       // the record keeps icov in its f32 rounding

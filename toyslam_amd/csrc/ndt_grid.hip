@@ -288,13 +288,47 @@ ndt_status build_grid(ndt_context* h) {
   const size_t max_leaves = std::min<size_t>(static_cast<size_t>(n), static_cast<size_t>(geo.n_cells));
   const size_t max_cand = std::min<size_t>(max_leaves, static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1);
   ndt::set_padded_lut(geo);
-  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
+  // Dense or sparse voxel index?  Dense (a table over the whole bounding box, one dependent load per probe) as long as the
+  // cell count stays within reach of the point count; sparse (sort-based build, hash look-up: ndt_sparse.hip) when the box
+  // is mostly empty -- the regime the reference's std::map handles for free.  ndt_set_voxel_index overrides.
+  const bool sparse = !h->index_only && (h->voxel_index == 2 || (h->voxel_index == 0 && (geo.n_cells > (1ll << 25) || geo.n_cells > 64ll * n + (1ll << 22))));
   HIP_TRY(g->counts.reserve(8));  // [points binned, occupied voxels, candidate voxels (>= min_pts), valid voxels, points in crowded cells]
   HIP_TRY(g->leaf_cell.reserve(max_leaves));
   HIP_TRY(g->leaf_start.reserve(max_leaves));
   HIP_TRY(g->leaf_count.reserve(max_leaves));
   HIP_TRY(g->leaf_rec.reserve(max_leaves));
   HIP_TRY(g->sorted_idx.reserve(n));
+  if (sparse) {
+    const size_t rec_slots = static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1;  // slot = segment start / min_pts
+    HIP_TRY(g->recs.reserve(rec_slots));
+    HIP_TRY(g->centroids.reserve(rec_slots));
+    int bits = 10;
+    while ((static_cast<size_t>(1) << bits) < 2 * rec_slots) bits++;
+    geo.hash_bits = bits;
+    HIP_TRY(g->lut.reserve(static_cast<size_t>(2) << bits));  // int2 slots
+    HIP_TRY(hipMemsetAsync(g->lut.p, 0xFF, (static_cast<size_t>(2) << bits) * sizeof(int), st));
+    const size_t tb = ndt::sparse_index_temp_bytes(n);
+    DevBuf<unsigned char> temp;
+    DevBuf<unsigned> w;  // keys_a, keys_b, flags, ord
+    DevBuf<int> vals;
+    HIP_TRY(temp.reserve(tb));
+    HIP_TRY(w.reserve(4 * static_cast<size_t>(n)));
+    HIP_TRY(vals.reserve(n));
+    HIP_TRY(ndt::launch_sparse_index(h->target->pts.p, n, h->target_dense, geo, h->min_pts, temp.p, tb, w.p, w.p + n, vals.p, w.p + 2 * static_cast<size_t>(n),
+                                     w.p + 3 * static_cast<size_t>(n), g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, g->sorted_idx.p,
+                                     g->counts.p, st));
+    ndt::FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf<float4> big_pts;
+    HIP_TRY(big_pts.reserve(n));
+    HIP_TRY(ndt::launch_finalize(h->target->pts.p, g->leaf_cell.p, g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, static_cast<int>(max_leaves),
+                                 g->sorted_idx.p, h->min_pts, h->eig_ratio, g->recs.p, g->centroids.p, g->lut.p, geo, g->counts.p + 3, nodump, st,
+                                 g->counts.p, big_pts.p));
+    g->counts_known = false;
+    g->empty = false;
+    h->grid = g;
+    return NDT_OK;
+  }
+  HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
   // Which form of K1?  The bucket form wins on clouds of moderate density (synthetic sets, maps: 2.5 x at 1M points); clouds
   // whose points crowd into few voxels (a 0.1 m-filtered scan in 1 m voxels: hundreds per voxel) are built faster by the
   // general chain, which gives every crowded voxel a workgroup of its own.  A build reports how crowded its cloud was
@@ -512,6 +546,33 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
   DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  if (h->voxel_index == 2 || (h->voxel_index == 0 && geo.n_cells > 16ll * static_cast<long long>(n) + (1ll << 22))) {
+    // a fine leaf over a wide box (apps/align.cpp: 0.1 m over a whole scan): per-point work only (ndt_sparse.hip)
+    const size_t max_l = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));
+    const size_t tb = ndt::sparse_index_temp_bytes(ni);
+    DevBuf<unsigned char> temp;
+    DevBuf<unsigned> w;
+    DevBuf<int> vals;
+    DevBuf<float4> big2;
+    HIP_TRY(temp.reserve(tb));
+    HIP_TRY(w.reserve(4 * n));
+    HIP_TRY(vals.reserve(n));
+    HIP_TRY(totals.reserve(8));
+    HIP_TRY(leaf_cell.reserve(max_l));
+    HIP_TRY(leaf_start.reserve(max_l));
+    HIP_TRY(leaf_count.reserve(max_l));
+    HIP_TRY(leaf_rec.reserve(max_l));
+    HIP_TRY(sorted_idx.reserve(n));
+    HIP_TRY(big2.reserve(n));
+    HIP_TRY(ndt::launch_sparse_index(d_in, ni, is_dense, geo, 1, temp.p, tb, w.p, w.p + n, vals.p, w.p + 2 * n, w.p + 3 * n, leaf_cell.p, leaf_start.p,
+                                     leaf_count.p, leaf_rec.p, sorted_idx.p, totals.p, st));
+    HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(max_l), sorted_idx.p, d_out, st, totals.p, big2.p));
+    unsigned tot2[3];
+    HIP_TRY(hipMemcpyAsync(tot2, totals.p, sizeof(tot2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_out = tot2[1];
+    return NDT_OK;
+  }
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
   HIP_TRY(rank.reserve(n));
@@ -575,6 +636,12 @@ ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t 
 }
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, size_t stride) {
   return set_source_impl(h, pts, n, stride, true);
+}
+
+ndt_status ndt_set_voxel_index(ndt_handle h, int mode) {
+  if (!h || mode < 0 || mode > 2) return fail(NDT_ERR_INVALID, "bad arguments");
+  h->voxel_index = mode;
+  return NDT_OK;
 }
 
 ndt_status ndt_share_input_source(ndt_handle dst, ndt_handle src) {

@@ -108,6 +108,7 @@ ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
   h->search = src->search;
   h->num_threads = src->num_threads;
   h->persistent = src->persistent;
+  h->voxel_index = src->voxel_index;
   h->min_pts = src->min_pts;
   h->eig_ratio = src->eig_ratio;
   h->target = src->target;

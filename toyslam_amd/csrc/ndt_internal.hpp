@@ -283,6 +283,7 @@ struct ndt_context {
   unsigned* k1_feedback = nullptr;  // pinned: {binned, -, -, valid, points in crowded cells} of the previous target build
   bool k1_feedback_valid = false;
   int k1_crowded_hint = -1;         // -1 unknown, 0 moderate density (bucket form of K1), 1 crowded voxels (general chain)
+  int voxel_index = 0;              // ndt_set_voxel_index: 0 automatic, 1 dense table, 2 sparse (sorted build + hash look-up)
   bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
   // Two command mailboxes, used by alternate server instances: a server told to finish (transform +

@@ -598,16 +598,26 @@ __device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o,
       rec.pad = 0;
       recs[r] = rec;
       centroids[r] = make_float4(fx, fy, fz, 0.0f);
-      // the cell's slot in the padded look-up table
-      const int c = cell;
-      const int cz = c / geom.mul[2], cy = (c - cz * geom.mul[2]) / geom.mul[1], cx = c - cz * geom.mul[2] - cy * geom.mul[1];
-      const long long slot = static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * geom.pmul[1] +
-                             static_cast<long long>(cz + kLutBorder) * geom.pmul[2];
-      if (nr_points >= min_pts) {
-        lut[slot] = r;
-        is_valid = true;
+      const int entry = (nr_points >= min_pts) ? r : lut_rejected(r);
+      is_valid = nr_points >= min_pts;
+      if (geom.hash_bits) {
+        // sparse grid: claim a slot of the hash table (keys are unique: one insert per voxel)
+        int2* tab = reinterpret_cast<int2*>(lut);
+        const unsigned mask = (1u << geom.hash_bits) - 1u;
+        for (unsigned hslot = hash_slot(cell, geom.hash_bits);; hslot = (hslot + 1u) & mask) {
+          const int seen = atomicCAS(&tab[hslot].x, -1, cell);
+          if (seen == -1 || seen == cell) {
+            tab[hslot].y = entry;
+            break;
+          }
+        }
       } else {
-        lut[slot] = lut_rejected(r);
+        // the cell's slot in the padded look-up table
+        const int c = cell;
+        const int cz = c / geom.mul[2], cy = (c - cz * geom.mul[2]) / geom.mul[1], cx = c - cz * geom.mul[2] - cy * geom.mul[1];
+        const long long slot = static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * geom.pmul[1] +
+                               static_cast<long long>(cz + kLutBorder) * geom.pmul[2];
+        lut[slot] = entry;
       }
     }
   }
@@ -1501,7 +1511,7 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
-      rec[k] = (NNB == 27) ? probe_kd(gv, centre, dx, dy, dz, pt.x, pt.y, pt.z, r2) : probe(gv, centre, dx, dy, dz);
+      rec[k] = (NNB == 27) ? probe_kd(gv, vi, vj, vk, centre, dx, dy, dz, pt.x, pt.y, pt.z, r2) : probe(gv, vi, vj, vk, centre, dx, dy, dz);
       cnt += (rec[k] >= 0);
     }
     for (int k = 0; k < NNB; k++) {

@@ -41,6 +41,9 @@ struct GridGeom {
   int pmul[3];
   long long lut_cells;
   int pow2;  // every leaf size is a power of two: floor(x / leaf) == floor(x * inv_leaf) exactly
+  // sparse grids: the look-up table is an open-addressing hash keyed by the reference's linear voxel index
+  // (hash_bits > 0: 2^hash_bits slots of (key, entry), key -1 = free); lut_cells / pmul are then unused
+  int hash_bits;
 };
 constexpr int kLutBorder = 2;
 inline void set_padded_lut(GridGeom& g) {
@@ -48,6 +51,7 @@ inline void set_padded_lut(GridGeom& g) {
   g.pmul[1] = g.div_b[0] + 2 * kLutBorder;
   g.pmul[2] = g.pmul[1] * (g.div_b[1] + 2 * kLutBorder);
   g.lut_cells = static_cast<long long>(g.pmul[2]) * (g.div_b[2] + 2 * kLutBorder);
+  g.hash_bits = 0;
   g.pow2 = 1;
   for (int k = 0; k < 3; k++) {
     int e = 0;
@@ -62,8 +66,10 @@ inline void set_padded_lut(GridGeom& g) {
 constexpr int kLutEmpty = -1;
 __host__ __device__ inline int lut_rejected(int r) { return -(r + 2); }
 
+__host__ __device__ inline unsigned hash_slot(int key, int bits) { return (static_cast<unsigned>(key) * 0x9E3779B1u) >> (32 - bits); }
+
 struct GridView {
-  const int* lut;            // padded table, g.lut_cells entries
+  const int* lut;            // padded table, g.lut_cells entries; sparse grids (g.hash_bits > 0): the hash table, int2 slots
   const VoxelRec* recs;      // one record per voxel with >= min_points_per_voxel points
   const float4* centroids;   // per record: voxel centroid (voxel_centroids_ entry), KDTREE search only
   GridGeom g;
@@ -161,6 +167,15 @@ hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells
                              unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream);
 hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const unsigned* d_cell_start, int* d_sorted_idx,
                           hipStream_t stream);
+
+// Sparse voxel index (ndt_sparse.hip): leaf arrays in ascending voxel order from a stable sort of (voxel, point) pairs.
+// counts: device [5] = {points binned, occupied voxels, candidates, -, -} (zeroed here; the finalize pass adds [3], [4]).
+// keys_a / keys_b / vals_a / flags / ord: n words of scratch each; temp: sparse_index_temp_bytes(n).
+size_t sparse_index_temp_bytes(int n);
+hipError_t launch_sparse_index(const float4* pts, int n, int dense, const GridGeom& g, int min_pts, void* temp, size_t temp_bytes,
+                               unsigned* keys_a, unsigned* keys_b, int* vals_a, unsigned* flags, unsigned* ord, int* leaf_cell,
+                               unsigned* leaf_start, int* leaf_count, int* leaf_rec, int* sorted_idx, unsigned* counts,
+                               hipStream_t stream);
 
 struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
   int* nr_points;

@@ -301,6 +301,10 @@ class NormalDistributionsTransform:
         """setInputSource from a raw host pointer (e.g. the page-locked buffer of a PcdSequence scan)."""
         check(self._L.ndt_set_input_source(self._h, C.c_void_p(host_ptr), n, stride_bytes))
 
+    def setVoxelIndex(self, mode):
+        """0 = dense / sparse voxel index chosen by occupancy, 1 = dense table, 2 = sparse (sorted build + hash look-up)."""
+        check(self._L.ndt_set_voxel_index(self._h, int(mode)))
+
     def setBatchGroups(self, n):
         """Independent lock-step groups alignBatch runs as (0 = automatic, 1 = one loop)."""
         check(self._L.ndt_set_batch_groups(self._h, int(n)))
