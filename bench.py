@@ -496,11 +496,13 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
             pass
         valu, valu_name = committed_profile("pmc_valu.json")
         try:
-            per_wave = valu["server"]["SQ_INSTS_VALU_per_wave_per_evaluation"]
-            waves = valu["server"]["waves"]
+            per_wave = valu["server_valu_insts_per_wave_per_evaluation"]
+            waves = [v["SQ_WAVES"] for k, v in valu["kernels"].items() if "k_eval_server<7>" in k][0]
             insts_per_launch = per_wave * waves * evals_per_launch
             committed["valu_issue_frac_committed_profile"] = insts_per_launch / avg_s / VALU_PEAK_WAVE_INSTS_PER_S
-            committed["valu_issue_frac_source"] = valu_name + " (SQ_INSTS_VALU per wave per evaluation x waves x evaluations of this run / this run's kernel time / (1024 SIMDs x 2.4 GHz / 4))"
+            committed["valu_insts_per_wave_per_evaluation_committed_profile"] = per_wave
+            committed["valu_issue_frac_source"] = valu_name + (" (SQ_INSTS_VALU per wave per evaluation x waves x evaluations of this run / this run's "
+                                                               "kernel time / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction))")
         except Exception:
             pass
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -612,9 +614,13 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
         out["mean_neighbors"] = stb["mean_neighbors"]
         committed = {}
         prof, src_name = committed_profile("batch64_summary.json")
-        if prof and n_local == 64 and args.set == "U":
-            committed = {"traffic_committed_profile": prof.get("derivative_kernels_hbm_bytes_per_lock_step"),
-                         "traffic_committed_profile_source": src_name}
+        if prof and prof.get("derivative_kernels_hbm_bytes_per_scan_evaluation") and args.set == "U":
+            per_eval = prof["derivative_kernels_hbm_bytes_per_scan_evaluation"]
+            committed = {"traffic_committed_profile": per_eval * n_scan_evals / max(n_steps_timed, 1),
+                         "traffic_committed_profile_per_scan_evaluation": per_eval,
+                         "traffic_committed_profile_source": src_name + " (tools/profile_batch.sh + tools/summarize_batch_profile.py: separate --pmc "
+                                                                        "FETCH_SIZE / WRITE_SIZE passes of the 64-scan command, KB, 2 x FETCH_SIZE on gfx950; per scan "
+                                                                        "evaluation x the scan evaluations of this run's launches)"}
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "algorithmic_bytes_per_launch": bytes_total / max(n_steps_timed, 1),

@@ -4,6 +4,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_batch
+rm -rf $O
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --workload batch --batch 64 --steps 3 --warmup 1 > $O/stats.log 2>&1

@@ -16,6 +16,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+constexpr int kBatchPointsPerBlock = 4 * kBlock;  // lock-step batches: a block's contiguous run of a scan's points
 
 // ---------------------------------------------------------------------------
 // helpers

@@ -1246,13 +1246,21 @@ __global__ __launch_bounds__(kBlock) void k_derivatives(const float4* __restrict
   }
   __syncthreads();
   const float4* pts = BATCH ? src + dsc->offset : src;
-  const int cnt = BATCH ? dsc->count : n;
+  int cnt = BATCH ? dsc->count : n;
   // BATCH: a scan is walked by ITS OWN number of blocks (descs[scan].pad, a function of its size only), whatever the
-  // grid is: its sums do not depend on which other scans share the launch
-  const int stride = BATCH ? dsc->pad * kBlock : static_cast<int>(gridDim.x) * kBlock;
-  if (BATCH && static_cast<int>(blockIdx.x) >= dsc->pad) return;
-  if (NNB == 27) derivatives_body_kd<WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H>(pts, cnt, gv, sP, sT, first, stride, acc);
+  // grid is: its sums do not depend on which other scans share the launch.  Block b takes one CONTIGUOUS run of
+  // kBatchPointsPerBlock points of the (spatially ordered) scan, the runs dealt to the XCDs in eighths (xcd_chunk): every
+  // XCD's L2 then works on one compact region of the voxel records instead of all eight caching the whole map.
+  int stride = static_cast<int>(gridDim.x) * kBlock, first_pt = first;
+  if (BATCH) {
+    if (static_cast<int>(blockIdx.x) >= dsc->pad) return;
+    const int lo = xcd_chunk(blockIdx.x, dsc->pad) * kBatchPointsPerBlock;
+    first_pt = lo + static_cast<int>(threadIdx.x);
+    cnt = min(cnt, lo + kBatchPointsPerBlock);
+    stride = kBlock;
+  }
+  if (NNB == 27) derivatives_body_kd<WANT_H>(pts, cnt, gv, sP, sT, first_pt, stride, acc);
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H>(pts, cnt, gv, sP, sT, first_pt, stride, acc);
   block_reduce_store<kNumAcc>(acc, partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride, lds);
 }
 
@@ -1284,9 +1292,14 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
     prm = &sP;
   }
   double* out = partials + (static_cast<size_t>(scan) * max_blocks + blockIdx.x) * kEvalStride;
-  const int nb = BATCH ? descs[scan].pad : static_cast<int>(gridDim.x);  // a scan's own block count (see k_derivatives)
-  if (static_cast<int>(blockIdx.x) >= nb) return;
-  hessian64_body<NNB>(src, n, gv, *prm, blockIdx.x * kBlock + threadIdx.x, nb * kBlock, acc);
+  if (BATCH) {  // a scan's own block count, one contiguous run of points per block (see k_derivatives)
+    const int nb = descs[scan].pad;
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    const int lo = xcd_chunk(blockIdx.x, nb) * kBatchPointsPerBlock;
+    hessian64_body<NNB>(src, min(n, lo + kBatchPointsPerBlock), gv, *prm, lo + static_cast<int>(threadIdx.x), kBlock, acc);
+  } else {
+    hessian64_body<NNB>(src, n, gv, *prm, blockIdx.x * kBlock + threadIdx.x, static_cast<int>(gridDim.x) * kBlock, acc);
+  }
   block_reduce_store<kNumAcc>(acc, out, lds);
 }
 
@@ -1318,9 +1331,10 @@ __global__ __launch_bounds__(kBlock) void k_batch_step(const float4* __restrict_
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
   if (static_cast<int>(blockIdx.x) >= dsc->pad) return;  // (uniform; after the barriers above)
-  const int first = blockIdx.x * kBlock + threadIdx.x, stride = dsc->pad * kBlock;
+  const int lo = xcd_chunk(blockIdx.x, dsc->pad) * kBatchPointsPerBlock;  // one contiguous run of points per block (see k_derivatives)
+  const int first = lo + static_cast<int>(threadIdx.x), stride = kBlock;
   const float4* pts = src + dsc->offset;
-  const int n = dsc->count;
+  const int n = min(dsc->count, lo + kBatchPointsPerBlock);
   if (kind == 2) {
     hessian64_body<NNB, true>(pts, n, gv, sP64, first, stride, acc);
   } else if (NNB == 27) {
@@ -1554,7 +1568,7 @@ static int env_int(const char* name, int dflt) {
 int derivative_variant() { return 0; }  // (the development variants of round 1 are gone: one body, spelled out by hand)
 // blocks a scan of n points is walked by inside a lock-step batch: four points per thread (the wave fold and the block
 // epilogue are paid once per thread), a function of the scan's size only
-int batch_blocks(int n) { return max(1, min(1024, (n + 4 * kBlock - 1) / (4 * kBlock))); }
+int batch_blocks(int n) { return max(1, (n + kBatchPointsPerBlock - 1) / kBatchPointsPerBlock); }
 int derivative_blocks(int n, int search) {
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 1024);
   (void)search;
