@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-lockstep-leg", action="store_true", help="N > 1 mapbuild: skip the RCCL lock-step leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the selftest)")
     ap.add_argument("--dry-run", action="store_true", help="self-launch only: print the per-rank environment plan and exit")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 and rendezvous over gloo: exercises the sharded workload, the launcher and the "
+                         "JSON line on a one-GPU box (RCCL refuses two ranks on one device, so the lock-step leg reports an error)")
     return ap.parse_args(argv)
 
 
@@ -250,9 +253,11 @@ def main():
     import torch
     dist = None
     use_gpu = workload != "selftest"
+    if args.rehearse_one_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        backend = args.backend or ("nccl" if use_gpu else "gloo")
+        backend = args.backend or ("gloo" if (args.rehearse_one_gpu or not use_gpu) else "nccl")
         if use_gpu:
             torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -388,7 +393,7 @@ def main():
         recovered = int(sum_over_ranks(ok))
     per_rank_regs = None
     if dist is not None:
-        mine = torch.zeros(world, dtype=torch.float64, device="cuda")
+        mine = torch.zeros(world, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         mine[rank] = (steps * (len(T_gts) if T_gts is not None else 1)) / dt_local
         dist.all_reduce(mine)
         per_rank_regs = [float(x) for x in mine.tolist()]
@@ -646,10 +651,11 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
+            on_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
             uid = torch.zeros(ndt.COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
                 uid = torch.from_numpy(np.frombuffer(ndt.comm_get_unique_id(), dtype=np.uint8).copy())
-            uid = uid.cuda()
+            uid = uid.to(on_dev)
             dist.broadcast(uid, 0)
             reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world)
             kw = dict(device_ptr=dev.data_ptr() if dev is not None else 0, offsets=offsets, stride_bytes=16,
@@ -662,12 +668,12 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
             torch.cuda.synchronize()
             dist.barrier()
             tl = time.perf_counter() - ta
-            t = torch.tensor([tl], dtype=torch.float64, device="cuda")
+            t = torch.tensor([tl], dtype=torch.float64, device=on_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ok = 0
             for k, Tg in enumerate(T_gts):
                 ok += int(near_T_gt(res["T"][lo + k], Tg))
-            okt = torch.tensor([float(ok)], dtype=torch.float64, device="cuda")
+            okt = torch.tensor([float(ok)], dtype=torch.float64, device=on_dev)
             dist.all_reduce(okt)
             cs = reg.commStats()
             result = {"value": args.scans / float(t.item()), "unit": "registrations/s", "ms_per_step": float(t.item()) * 1e3,

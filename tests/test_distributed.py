@@ -154,3 +154,64 @@ def test_two_rank_point_sharded_on_gpu(built_lib, pair, golden, tmp_path):
     assert res["converged"] and res["iterations"] == ref["iterations"]
     # trans_probability = score / N uses the local N on each rank; the transform is the global one
     assert np.abs(np.array(res["T"]) - np.array(ref["T"])).max() < 1e-5
+
+
+SHARDED_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["NDT_ROOT"])
+import torch, torch.distributed as dist
+from toyslam_amd import ndt, clouds, dist as nd
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["NDT_PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+tgt = clouds.target_surfaces(200000, extent=60.0, n_boxes=30)
+B = 7
+scans = [clouds.mapbuild_scan(tgt, k, 20000 + 1000 * k, 0.3, 1.0)[0] for k in range(B)]   # ragged batch
+lo, hi = nd.shard_range(B, rank, world)
+g = ndt.NormalDistributionsTransform(device=0)      # both ranks share the one GPU of the test box
+g.setTransformationEpsilon(0.01); g.setMaximumIterations(40)
+g.setInputTarget(tgt)
+g.setAllreduce(nd.make_allreduce(), on_device=False)   # ONE in-place SUM of the [B][32] rows per lock-step (gloo, host copy)
+res = g.alignBatchSharded(scans[lo:hi], first_scan=lo, total_scans=B)
+cs = g.commStats()
+# every rank holds every scan's result
+T = torch.from_numpy(res["T"].astype(np.float64).copy())
+Tmax = T.clone(); dist.all_reduce(Tmax, op=dist.ReduceOp.MAX)
+Tmin = T.clone(); dist.all_reduce(Tmin, op=dist.ReduceOp.MIN)
+assert torch.equal(Tmax, Tmin)
+if rank == 0:
+    g1 = ndt.NormalDistributionsTransform(device=0)
+    g1.setTransformationEpsilon(0.01); g1.setMaximumIterations(40)
+    g1.setInputTarget(tgt)
+    g1.setBatchGroups(1)
+    ref = g1.alignBatch(scans)                       # the same batch by ONE process, one lock-step loop
+    print(json.dumps({"same_T": bool(np.array_equal(ref["T"], res["T"])), "same_iterations": bool(np.array_equal(ref["iterations"], res["iterations"])),
+                      "max_T_diff": float(np.abs(ref["T"] - res["T"]).max()), "lock_steps": cs["lock_steps"], "shard": [lo, hi],
+                      "same_tprob": bool(np.allclose(ref["trans_probability"], res["trans_probability"], rtol=1e-12))}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_lock_step_batch_on_gpu(built_lib, tmp_path):
+    """north_star's map-build exchange with two real ranks: each holds its share of the scans, both step ALL the
+    Newton / More-Thuente state machines, one SUM all-reduce of the zero-padded [B][32] rows per lock-step -- every rank
+    ends with every scan's registration, identical to the one-process batch."""
+    import json
+    port = _free_port()
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", NDT_PORT=str(port), NDT_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["same_iterations"] and res["same_tprob"], res
+    # a rank's share is ordered on a lattice over ITS scans' bounding box: the sums agree to rounding with the one-process batch
+    assert res["same_T"] or res["max_T_diff"] < 1e-5, res
+    assert res["shard"] == [0, 4] and res["lock_steps"] >= 3
