@@ -22,7 +22,7 @@ rows = list(csv.DictReader(open(os.path.join(O, "kernel_stats.csv"))))
 for r in rows[:16]:
     out["kernel_stats"][r["Name"][:100]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
 tot = collections.defaultdict(float)
-for name in ("fetch", "write"):
+for name in ("fetch", "write"):  # (one run per pass: profile_batch.sh starts from an empty directory)
     for f in glob.glob(os.path.join(O, name, "*", "*counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
