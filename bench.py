@@ -43,6 +43,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# numpy's BLAS pool: one thread.  The synthetic inputs are made with a few (N x 3) @ (3 x 3) products; OpenBLAS starts one
+# worker per visible core for them (64 on the GPU hosts) and the workers keep spinning for a while afterwards.  On a
+# box whose cgroup grants 16 CPUs of a 256-thread host that spinning exhausts the CFS quota tens of milliseconds into
+# the timed region, and the kernel then parks EVERY thread of the process -- the one polling for evaluation results
+# included -- for 40-80 ms (measured: cpu.stat nr_throttled, and NDT_TIMING=2's longest-poll-gap).  Set before numpy loads.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 METRIC = "scan registrations/sec (100k-pt src vs 1M-pt target, 30 Newton iters)"
 MAX_ITER, EPS = 28, 1e-9  # max_iterations_ = 28, transformation_epsilon_ = 1e-9 => 30 outer passes (trap 9)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md)
@@ -66,6 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--extent", type=float, default=400.0, help="scene size of --workload large / pyramid (SURVEY 8(d): 400 m)")
     ap.add_argument("--seq-scans", type=int, default=16, help="scans of the streamed sequence of --workload pyramid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bind", action="store_true", help="leave the CPU affinity of the rank alone (default: the cores of the GPU's NUMA node)")
     ap.add_argument("--no-mapbuild-leg", action="store_true", help="N = 1 single: skip the 512-scan map-build leg")
     ap.add_argument("--no-lockstep-leg", action="store_true", help="N > 1 mapbuild: skip the RCCL lock-step leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the selftest)")
@@ -184,6 +193,21 @@ def committed_profile(name):
         return json.load(open(c[-1])), os.path.relpath(c[-1], ROOT)
     except Exception:
         return None, None
+
+
+def thread_cpu_times():
+    """{tid: (comm, user+system seconds)} of this process's threads (/proc/self/task)."""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open("/proc/self/task/%s/stat" % t).read()
+            comm = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(t)] = (comm, (int(rest[11]) + int(rest[12])) / tck)
+        except Exception:
+            pass
+    return out
 
 
 def median_time(fn, n=5):
@@ -308,7 +332,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    binding = bind_near_gpu(local_rank) if torch.cuda.is_available() else None
+    binding = bind_near_gpu(local_rank) if (torch.cuda.is_available() and not args.no_bind) else None
     from toyslam_amd import clouds, ndt
 
     # ---- inputs (synthetic, seeded; resident in HBM before the timed region) ----
@@ -375,11 +399,16 @@ def main():
     for _ in range(warmup):
         step()
     barrier()
+    thr0 = thread_cpu_times() if os.environ.get("NDT_BENCH_THREADS") else None
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier()
     dt_local = time.perf_counter() - t0
+    if thr0 is not None:  # diagnostics: which host threads burned CPU during the timed region (cgroup quota hunting)
+        thr1 = thread_cpu_times()
+        used = sorted(((thr1[t][1] - thr0.get(t, (None, 0))[1], thr1[t][0], t) for t in thr1), reverse=True)
+        sys.stderr.write("[bench threads] %d threads, timed region %.3f s; busiest (cpu-s, comm, tid): %s\n" % (len(thr1), dt_local, used[:12]))
     dt = max_over_ranks(dt_local)
 
     # every rank: did its registrations end at the known T_gt?  (summed over ranks; outside the timed region)
@@ -485,6 +514,10 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
     bytes_per_eval = algorithmic_bytes_per_eval(N_SOURCE, hbar)
     evals_per_launch = st2["n_evals"] + st2["n_hessian_recomputes"]
     bytes_per_launch = evals_per_launch * bytes_per_eval
+    server_used = n_launch > 0 and avg_s > 0
+    if not server_used:  # NDT_PERSISTENT=0: the launch path ran; its per-evaluation kernel is the dominant one
+        avg_s = ms_eval * 1e-3 / max(n_eval_launch, 1)
+        evals_per_launch, bytes_per_launch, n_launch = 1, bytes_per_eval, n_eval_launch
     achieved = bytes_per_launch / avg_s / 1e9
     # HBM traffic and VALU issue of the same kernel: PMC counters need rocprofv3 around the process, so they cannot be
     # collected inside this run; the figures of the newest committed profile of this command are attached under
@@ -512,8 +545,9 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
             pass
     out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                       "kernel": "k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
-                                 "their reductions, the f64 Hessian recompute and the output transform)",
+                       "kernel": ("k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
+                                  "their reductions, the f64 Hessian recompute and the output transform)") if server_used else
+                                 "k_derivatives_fused<DIRECT7> (one launch per evaluation: NDT_PERSISTENT=0)",
                        "avg_kernel_us": avg_s * 1e6, "launches_timed": n_launch,
                        "evaluations_per_launch": evals_per_launch,
                        "algorithmic_bytes_per_evaluation": bytes_per_eval,

@@ -2,7 +2,12 @@ import json
 import os
 import sys
 
-import numpy as np
+# numpy's BLAS pool: one thread (set before numpy loads).  Its workers spin after every product; inside a CPU-quota
+# cgroup on a many-core host that spinning gets the whole process parked by the kernel for tens of milliseconds --
+# long enough for the evaluation server's 20 ms patience to run out under a test (see bench.py).
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
 import pytest
 
 # the oracle's OpenMP regions are small; on a many-core host the default team (one thread per core) costs more

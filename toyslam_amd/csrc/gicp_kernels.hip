@@ -502,7 +502,9 @@ __global__ __launch_bounds__(kBlock) void k_gicp_server(const float4* __restrict
       bool got = false;
       for (;;) {
         if (lane < kGicpCmdWords) w = __hip_atomic_load(&mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (lane == kGicpCmdWords) w = __hip_atomic_load(&mb->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (__ballot(lane >= kGicpCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
+        if (__ballot(lane == kGicpCmdWords && w == expect) != 0) break;  // block 0 gave up on this very command: leave with it
         if (__builtin_amdgcn_s_memrealtime() - t0 > patience) break;
         __builtin_amdgcn_s_sleep(2);
       }

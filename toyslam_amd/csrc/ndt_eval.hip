@@ -294,11 +294,24 @@ ndt_status server_evaluate(ndt_context* h, const ndt::EvalRequest& rq, const ndt
       if (!(arrived & (1u << p)) && pub_ready(h->host_pub + static_cast<size_t>(p) * ndt::kPublishSlots, seq)) arrived |= 1u << p;
     return arrived == all;
   };
+  static const bool gap_probe = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) >= 2; }();
+  auto t_prev = t0;
   while (!parts_ready()) {
     __builtin_ia32_pause();
+    if (gap_probe) {  // diagnostics: the longest time this thread was away from its poll loop
+      const auto t_now = std::chrono::steady_clock::now();
+      const double gap = std::chrono::duration<double>(t_now - t_prev).count();
+      if (gap > h->t_gap) h->t_gap = gap;
+      t_prev = t_now;
+    }
     if ((++spins & 0x3FFF) == 0) {
       if (ndt::server_dead_word(h->server_host_mb) != 0 || hipStreamQuery(h->stream) != hipErrorNotReady) {
         // the server left (idle time-out or error): drain and let the caller relaunch
+        static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
+        if (timing)
+          std::fprintf(stderr, "[ndt timing] server left: seq %llu dead word %llu arrived %#x of %#x after %.1f us, kind %d, blocks %d\n", seq,
+                       ndt::server_dead_word(h->server_host_mb), arrived, all,
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6, static_cast<int>(rq.kind), h->server_blocks);
         server_mark(h, false);
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (parts_ready()) break;
@@ -403,9 +416,9 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   }
   static const bool timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
   if (timing) {
-    std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus first-eval=%.1fus (per align)\n",
-                 solver.n_evals + solver.n_hess, h->t_launch * 1e6, h->t_wait * 1e6, h->t_solver * 1e6, h->t_fill * 1e6);
-    h->t_launch = h->t_wait = h->t_solver = h->t_fill = 0;
+    std::fprintf(stderr, "[ndt timing] evals=%d launch=%.1fus wait=%.1fus solver=%.1fus first-eval=%.1fus longest-poll-gap=%.1fus (per align)\n",
+                 solver.n_evals + solver.n_hess, h->t_launch * 1e6, h->t_wait * 1e6, h->t_solver * 1e6, h->t_fill * 1e6, h->t_gap * 1e6);
+    h->t_launch = h->t_wait = h->t_solver = h->t_fill = h->t_gap = 0;
   }
   std::memcpy(h->final_T, solver.final_T, sizeof(h->final_T));
   h->converged = solver.converged ? 1 : 0;

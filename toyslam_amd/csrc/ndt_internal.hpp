@@ -265,7 +265,7 @@ struct ndt_context {
   double* host_pub = nullptr;     // pinned, tagged publication row of the single-scan paths (ndt_kernels.hip publish_row_tagged)
   size_t host_result_rows = 0;
   unsigned long long eval_seq = 0;
-  double t_launch = 0, t_wait = 0, t_solver = 0, t_fill = 0;  // NDT_TIMING=1 accounting (seconds)
+  double t_launch = 0, t_wait = 0, t_solver = 0, t_fill = 0, t_gap = 0;  // NDT_TIMING=1 accounting (seconds; t_gap: NDT_TIMING=2)
   // results
   float final_T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   int converged = 0, nr_iterations = 0;

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
         const unsigned long long patience = (blockIdx.x == 0) ? idle_ticks : 4 * idle_ticks;
         for (;;) {
           if (lane < kCmdWords) w = __hip_atomic_load(&host_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          else if (lane == kCmdWords) w = __hip_atomic_load(&host_mb->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) { got = true; break; }
+          if (__ballot(lane == kCmdWords && w == expect) != 0) break;  // block 0 gave up on this very command: leave with it
           if (__builtin_amdgcn_s_memrealtime() - t0 > patience) break;
           __builtin_amdgcn_s_sleep(2);
         }
