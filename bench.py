@@ -157,7 +157,13 @@ def host_info():
             cores.add((pkg, core))
         except OSError:
             cores.add(("?", str(c)))
-    return {"cpu_model": model, "logical_cpus": len(cpus), "physical_cores": len(cores)}
+    quota = None  # cgroup v2 CPU bandwidth: "max" or "<quota_us> <period_us>" -- what the box really grants
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "logical_cpus": len(cpus), "physical_cores": len(cores), "cgroup_cpu_quota": quota}
 
 
 def bind_near_gpu(local_rank):
@@ -600,7 +606,10 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
         out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": phys, "kind": "port",
                                "sample": "%d full registrations of the same workload (median), after 1 warm-up; align only, target grid resident" % n_t,
                                "ms_per_registration": med * 1e3, "target_build_ms": tb * 1e3, "evaluations": r["n_evals"],
-                               "cpu_model": hi_["cpu_model"], "threads": phys, "host_logical_cpus": hi_["logical_cpus"]}
+                               "cpu_model": hi_["cpu_model"], "threads": phys, "host_logical_cpus": hi_["logical_cpus"],
+                               "cgroup_cpu_quota": hi_["cgroup_cpu_quota"],
+                               "note": "threads beyond the cgroup's CPU quota are throttled by the kernel, not run: see cpu_baseline_16_threads "
+                                       "and cpu_baseline_optimised.by_threads for the same port at the box's granted share"}
         out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T_timed[:3, :3] - r["T"][:3, :3]).max()),
                                    "trans_max_abs_m": float(np.abs(T_timed[:3, 3] - r["T"][:3, 3]).max()),
                                    "iterations_gpu": it_timed, "iterations_oracle": r["iterations"],

@@ -339,7 +339,9 @@ ndt_status build_grid(ndt_context* h) {
     const unsigned binned = h->k1_feedback[0], crowded = h->k1_feedback[4];
     if (binned > 0) h->k1_crowded_hint = (static_cast<double>(crowded) > 0.3 * static_cast<double>(binned)) ? 1 : 0;
   }
-  const bool buckets_on = k1_mode == 2 || (k1_mode == 0 && h->k1_crowded_hint != 1);
+  // (small clouds -- the mapping nodes' 16 k points -- are launch-latency-bound: the 4-launch bucket form wins there however
+  // crowded the voxels are, its crowded cells being summed by lane teams: 101 -> 74 us on the reference pair)
+  const bool buckets_on = k1_mode == 2 || (k1_mode == 0 && (h->k1_crowded_hint != 1 || n <= 65536));
   ndt::GridBuildPlan plan{};
   if (buckets_on && !h->index_only && ndt::grid_build_plan(geo.n_cells, n, plan)) {
     // ---- bucket form (ndt_kernels.hip "K1, bucket form"): no per-point global atomic, per-voxel work staged through LDS

@@ -954,6 +954,12 @@ __device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cen
 constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
 constexpr unsigned kCrowdedCell = 48;             // a cell with more points counts as crowded (see build_grid's choice of path)
 constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
+// Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
+// three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
+// _impl.hpp:233-244) -- one thread walking a 400-point voxel of a real scan issues 15 f64 instructions per point by
+// itself (~20 us per voxel), a lane per chain issues two.
+constexpr int kTeamCell = 32, kTeamLanes = 16;
+constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
 __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int shift, int K, int C, int min_pts,
                                                       double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
@@ -964,10 +970,16 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
+  __shared__ int s_nteam;                     // team cells of the current pass ...
+  __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells ...
+  __shared__ double s_team64[kMaxTeamCells][9];  // ... and their sums (sx sy sz cxx cxy cxz cyy cyz czz)
+  __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
+  __shared__ float s_one;
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) return;  // empty bucket (uniform)
   const unsigned nb = be - bb;
+  if (threadIdx.x == 0) s_one = 1.0f;
   unsigned* cnt = k1_lds;          // [C] points per cell
   unsigned* cstart = k1_lds + C;   // [C] start of the cell's segment inside the bucket (exclusive prefix of cnt)
   unsigned* cur = k1_lds + 2 * C;  // [C] scatter cursors of the current pass
@@ -1120,6 +1132,56 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       __syncthreads();
       continue;
     }
+    // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
+    if (threadIdx.x == 0) s_nteam = 0;
+    __syncthreads();
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
+      const int n_c = static_cast<int>(cnt[c]);
+      if (n_c > kTeamCell && n_c >= min_pts) {
+        const int slot = atomicAdd(&s_nteam, 1);
+        s_team_cell[slot] = c;
+        cur[c] = static_cast<unsigned>(slot);  // (the scatter cursors are free again)
+      }
+    }
+    __syncthreads();
+    if (s_nteam > 0) {
+#pragma clang fp contract(off)
+      const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
+      // lane -> (a, b): 0-2 mean sums a * 1; 3-8 the products xx xy xz yy yz zz; 9-11 the f32 centroid sums
+      const int ia = (tl < 3) ? tl : (tl < 6) ? 0 : (tl < 8) ? 1 : (tl == 8) ? 2 : (tl < 12) ? tl - 9 : 0;
+      const int ib = (tl == 3) ? 0 : (tl == 4 || tl == 6) ? 1 : (tl == 5 || tl == 7 || tl == 8) ? 2 : -1;
+      const float* pa = (ia == 0) ? ox : (ia == 1) ? oy : oz;
+      const float* pb = (ib == 0) ? ox : (ib == 1) ? oy : (ib == 2) ? oz : &s_one;
+      const unsigned sb = (ib < 0) ? 0u : 1u;  // mean / centroid lanes multiply by the constant 1.0f (exact)
+      const int n_team = s_nteam;
+      for (int s = team; s < n_team; s += kBlock / kTeamLanes) {
+        const int c = s_team_cell[s];
+        const unsigned beg = cstart[c] - base, n_c = cnt[c];
+        double acc = (tl == 3 || tl == 6 || tl == 8) ? 1.0 : 0.0;  // cov_ starts as Identity (voxel_grid_covariance_omp.h:107)
+        float acc32 = 0.f;
+        unsigned i = 0;
+        for (; i + 4 <= n_c; i += 4) {
+          float a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { a[u] = pa[beg + i + u]; b[u] = pb[(beg + i + u) * sb]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double prod = static_cast<double>(a[u]) * static_cast<double>(b[u]);
+            acc += prod;
+            acc32 += a[u];
+          }
+        }
+        for (; i < n_c; i++) {
+          const float a = pa[beg + i], b = pb[(beg + i) * sb];
+          const double prod = static_cast<double>(a) * static_cast<double>(b);
+          acc += prod;
+          acc32 += a;
+        }
+        if (tl < 9) s_team64[s][tl] = acc;
+        else if (tl < 12) s_team32[s][tl - 9] = acc32;
+      }
+    }
+    __syncthreads();
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
       const int n_c = static_cast<int>(cnt[c]);
       if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
@@ -1128,15 +1190,23 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       // no scan over the buckets is needed to number the records (k1_leaves numbers the LEAVES when somebody asks)
       const int r = static_cast<int>((bb + cstart[c]) / static_cast<unsigned>(min_pts));
       VoxelSums S;
-      int i = 0;
-      for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
-        float x[4], y[4], z[4];
+      if (n_c > kTeamCell) {
+        const unsigned slot = cur[c];
+        S.sx = s_team64[slot][0]; S.sy = s_team64[slot][1]; S.sz = s_team64[slot][2];
+        S.cxx = s_team64[slot][3]; S.cxy = s_team64[slot][4]; S.cxz = s_team64[slot][5];
+        S.cyy = s_team64[slot][6]; S.cyz = s_team64[slot][7]; S.czz = s_team64[slot][8];
+        S.fx = s_team32[slot][0]; S.fy = s_team32[slot][1]; S.fz = s_team32[slot][2];
+      } else {
+        int i = 0;
+        for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
+          float x[4], y[4], z[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { x[u] = ox[beg + i + u]; y[u] = oy[beg + i + u]; z[u] = oz[beg + i + u]; }
+          for (int u = 0; u < 4; u++) { x[u] = ox[beg + i + u]; y[u] = oy[beg + i + u]; z[u] = oz[beg + i + u]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) S.add(x[u], y[u], z[u]);
+          for (int u = 0; u < 4; u++) S.add(x[u], y[u], z[u]);
+        }
+        for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       }
-      for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       n_ok += finish_voxel(S, n_c, 0, r, cell0 + c, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
@@ -1653,9 +1723,13 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   constexpr int kMaxBuckets = 8192, kMaxCells = 4096;
   if (n_points <= 0 || n_cells <= 0 || n_cells > static_cast<long long>(kMaxBuckets) * kMaxCells) return false;
   // ~1000 points per bucket: a bucket's per-point arrays then live in LDS and there are several blocks per CU
-  const long long k_target = std::max<long long>(64, std::min<long long>(kMaxBuckets, n_points / 1024));
+  // ... and at least a bucket per CU: a small cloud (the mapping nodes' 16 k points) is latency-bound on its fullest bucket
+  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 8; }();
+  const long long k_small = std::min<long long>(4096, n_points / small_div);  // small clouds: crowded cells spread over many blocks
+  const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / 1024));
   int C = pow2_ceil((n_cells + k_target - 1) / k_target);
-  C = std::max(32, std::min(kMaxCells, C));
+  static const int min_c = [] { const char* v = getenv("NDT_K1_MIN_C"); return v ? std::max(1, atoi(v)) : 32; }();
+  C = std::max(n_points <= 262144 ? min_c : 32, std::min(kMaxCells, C));
   while ((n_cells + C - 1) / C > kMaxBuckets) C <<= 1;
   if (C > kMaxCells) return false;
   P.cells_per_bucket = C;
@@ -1684,7 +1758,10 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
   const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
   int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));  // a power of two: the bitonic sort of a crowded pass
+  if (K <= 512 || n <= 262144) lds_cap = kK1LdsCap;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
   while (lds_cap > 256 && lds_cap > (60 * 1024 / 4 - 3 * C) / 5) lds_cap >>= 1;
+  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
+  if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
                      S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut, counts + 3,
                      S.order, static_cast<unsigned>(n));
