@@ -14,6 +14,8 @@
 
 #include "ndt_pcd.hpp"
 
+#include <emmintrin.h>
+
 namespace ndt {
 namespace {
 
@@ -246,14 +248,60 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
     std::vector<unsigned char> body;
     const size_t raw_bytes = h.points * h.record;
     if (h.data == 1) {
-      body.resize(raw_bytes);
-      if (raw_bytes && std::fread(body.data(), 1, raw_bytes, f) != raw_bytes) { rc = 2; err = std::string(path) + ": truncated binary body"; }
-      if (!rc)
-        for (size_t i = 0; i < h.points; i++) {
-          const unsigned char* r = body.data() + i * h.record;
-          put(i, scalar_to_float(r + h.fields[ix].offset, h.fields[ix]), scalar_to_float(r + h.fields[iy].offset, h.fields[iy]),
-              scalar_to_float(r + h.fields[iz].offset, h.fields[iz]));
+      // chunks of records through one small buffer (a 2M-point scan is a 24 MB body: a body-sized temporary costs as much
+      // in page faults as the read itself); records whose x / y / z are 4-byte floats -- what every PCL writer produces
+      // for PointXYZ* -- are copied without the per-scalar type dispatch
+      const size_t chunk = 32768;
+      body.resize(std::min(chunk, std::max<size_t>(h.points, 1)) * h.record);
+      const Field &fx = h.fields[ix], &fy = h.fields[iy], &fz = h.fields[iz];
+      const bool f32 = fx.type == 'F' && fx.size == 4 && fy.type == 'F' && fy.size == 4 && fz.type == 'F' && fz.size == 4;
+      const bool wide = stride >= 16;
+      uint32_t nonfinite = 0;
+      for (size_t i0 = 0; i0 < h.points && !rc; i0 += chunk) {
+        const size_t m = std::min(chunk, h.points - i0);
+        if (std::fread(body.data(), h.record, m, f) != m) { rc = 2; err = std::string(path) + ": truncated binary body"; break; }
+        const unsigned char* r = body.data();
+        unsigned char* d = o + i0 * stride;
+        if (f32 && wide && h.record == 12 && fx.offset == 0 && fy.offset == 4 && fz.offset == 8) {
+          // the plain "x y z" record of pcl::PCDWriter for PointXYZ: one unaligned 16-byte load per point (the last record of
+          // the chunk is done by the general loop below: a 16-byte load there would read past the buffer)
+          const __m128 one = _mm_castsi128_ps(_mm_set_epi32(0x3f800000, 0, 0, 0));
+          const __m128 keep = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
+          const __m128i expo = _mm_set_epi32(0, 0x7f800000, 0x7f800000, 0x7f800000);
+          __m128i bad = _mm_setzero_si128();
+          size_t i = 0;
+          for (; i + 1 < m; i++, r += 12, d += stride) {
+            const __m128 v = _mm_or_ps(_mm_and_ps(_mm_loadu_ps(reinterpret_cast<const float*>(r)), keep), one);
+            _mm_storeu_ps(reinterpret_cast<float*>(d), v);
+            bad = _mm_or_si128(bad, _mm_cmpeq_epi32(_mm_and_si128(_mm_castps_si128(v), expo), expo));
+          }
+          if (_mm_movemask_epi8(bad) & 0x0fff) nonfinite = 1;
+          for (; i < m; i++, r += 12, d += stride) {
+            uint32_t v[4];
+            std::memcpy(v, r, 12);
+            v[3] = 0x3f800000u;
+            std::memcpy(d, v, 16);
+            nonfinite |= static_cast<uint32_t>((v[0] & 0x7f800000u) == 0x7f800000u) | static_cast<uint32_t>((v[1] & 0x7f800000u) == 0x7f800000u) |
+                         static_cast<uint32_t>((v[2] & 0x7f800000u) == 0x7f800000u);
+          }
+        } else if (f32) {
+          for (size_t i = 0; i < m; i++, r += h.record, d += stride) {
+            uint32_t v[4];
+            std::memcpy(&v[0], r + fx.offset, 4);
+            std::memcpy(&v[1], r + fy.offset, 4);
+            std::memcpy(&v[2], r + fz.offset, 4);
+            v[3] = 0x3f800000u;  // 1.0f
+            std::memcpy(d, v, wide ? 16 : 12);
+            // non-finite <=> exponent all ones
+            nonfinite |= static_cast<uint32_t>((v[0] & 0x7f800000u) == 0x7f800000u) | static_cast<uint32_t>((v[1] & 0x7f800000u) == 0x7f800000u) |
+                         static_cast<uint32_t>((v[2] & 0x7f800000u) == 0x7f800000u);
+          }
+        } else {
+          for (size_t i = 0; i < m; i++, r += h.record)
+            put(i0 + i, scalar_to_float(r + fx.offset, fx), scalar_to_float(r + fy.offset, fy), scalar_to_float(r + fz.offset, fz));
         }
+      }
+      if (nonfinite) dense = false;
     } else {
       uint32_t sizes[2];
       if (std::fread(sizes, 4, 2, f) != 2) { rc = 2; err = std::string(path) + ": truncated compressed header"; }

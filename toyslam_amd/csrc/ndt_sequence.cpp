@@ -29,7 +29,8 @@ PcdSequence::PcdSequence(std::string directory, Alloc alloc, Release release)
     : dir_(std::move(directory)), alloc_(std::move(alloc)), release_(std::move(release)) {}
 
 PcdSequence::~PcdSequence() {
-  if (inflight_.valid()) inflight_.wait();
+  for (std::future<void>& f : inflight_)
+    if (f.valid()) f.wait();
   for (Slot& s : slots_)
     if (s.buf) release_(s.buf);
 }
@@ -60,10 +61,10 @@ int PcdSequence::poll(size_t loaded_clouds, std::string& err) {
 
 void PcdSequence::start_read(size_t index) {
   if (index >= queue_.size()) return;
-  Slot* slot = &slots_[index & 1];
+  Slot* slot = &slots_[index % kSlots];
   const std::string path = queue_[index].path;
-  inflight_index_ = index;
-  inflight_ = std::async(std::launch::async, [this, slot, path] {
+  inflight_index_[index % kSlots] = index;
+  inflight_[index % kSlots] = std::async(std::launch::async, [this, slot, path] {
     slot->status = 0;
     slot->err.clear();
     slot->n = 0;
@@ -96,15 +97,21 @@ void PcdSequence::start_read(size_t index) {
 int PcdSequence::next(Scan& out, std::string& err) {
   out = Scan{};
   if (cursor_ >= queue_.size()) return 1;
-  if (!(inflight_.valid() && inflight_index_ == cursor_)) {
-    if (inflight_.valid()) inflight_.wait();
-    start_read(cursor_);
-  }
-  inflight_.wait();
+  // The scan handed out by the previous call is released by this one, so every slot but the one handed out now may hold
+  // a read in flight: entries cursor_ .. cursor_ + kSlots - 1 (the first of them is waited for below).
+  if (read_ahead_ < cursor_) read_ahead_ = cursor_;
+  auto top_up = [this](size_t limit) {
+    for (; read_ahead_ < queue_.size() && read_ahead_ < limit; read_ahead_++) {
+      std::future<void>& f = inflight_[read_ahead_ % kSlots];
+      if (f.valid()) f.wait();  // (an older read into this slot: long finished, its scan handed out)
+      start_read(read_ahead_);
+    }
+  };
+  top_up(cursor_ + kSlots);
   const size_t mine = cursor_++;
-  const Slot& slot = slots_[mine & 1];
-  // the other buffer is free now (its scan was handed out one call ago): read ahead into it
-  if (cursor_ < queue_.size()) start_read(cursor_);
+  std::future<void>& fm = inflight_[mine % kSlots];
+  if (fm.valid()) fm.wait();
+  const Slot& slot = slots_[mine % kSlots];
   out.file_number = queue_[mine].number;
   out.path = queue_[mine].path.c_str();
   if (slot.status) {

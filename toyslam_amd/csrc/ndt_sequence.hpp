@@ -16,7 +16,7 @@ int extract_file_number(const std::string& stem);
 
 class PcdSequence {
  public:
-  // alloc / release of the two scan buffers (pinned host memory when a GPU is there)
+  // alloc / release of the kSlots scan buffers (pinned host memory when a GPU is there)
   using Alloc = std::function<void*(size_t)>;
   using Release = std::function<void(void*)>;
   PcdSequence(std::string directory, Alloc alloc, Release release);
@@ -37,8 +37,10 @@ class PcdSequence {
     const char* path = nullptr;
   };
   // The next queued file (0), nothing queued (1), or a file that cannot be read (2: err set, the file is skipped,
-  // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following file is being read.
+  // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following kSlots - 1 files are being
+  // read and parsed, one background thread each (a 2M-point scan takes longer to read and parse than to register).
   int next(Scan& out, std::string& err);
+  static constexpr size_t kSlots = 6;
 
  private:
   struct Entry {
@@ -59,9 +61,10 @@ class PcdSequence {
   Release release_;
   std::vector<Entry> queue_;
   size_t cursor_ = 0;
-  Slot slots_[2];
-  std::future<void> inflight_;
-  size_t inflight_index_ = static_cast<size_t>(-1);
+  Slot slots_[kSlots];
+  std::future<void> inflight_[kSlots];            // the read into slot k ...
+  size_t inflight_index_[kSlots] = {};  // ... is of queue entry inflight_index_[k] (valid while the future is)
+  size_t read_ahead_ = 0;                         // queue entries below this index have been started
 };
 
 }  // namespace ndt
