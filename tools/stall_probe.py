@@ -1,5 +1,8 @@
+"""60 back-to-back registrations of a 2M-point scan (configs[2] shape): median / max wall time and the registrations
+that took more than 10 ms -- the probe that found the CFS-quota stalls of the polling host thread.
+  python tools/stall_probe.py [extent_m]     NDT_TIMING=2 adds the longest poll gap per registration on stderr."""
 import sys, os, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyslam_amd import clouds, ndt
 if os.environ.get('PROBE_TORCH'):
     import torch; torch.zeros(1).cuda(); torch.cuda.synchronize()

@@ -1,6 +1,9 @@
+"""setInputTarget (cloud in HBM) over cloud shapes from uniform to heavily crowded, per K1 form:
+  for k in old new auto; do NDT_K1=$k python tools/time_k1_forms.py; done
+us_median_later: one build + device synchronisation; us_pipelined: six builds back to back / 6."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyslam_amd import clouds, ndt
 import torch
 cases = [("pair-like 16k/40m", 16000, 40.0, 1.0), ("60k/40m", 60000, 40.0, 1.0), ("300k/60m", 300000, 60.0, 1.0), ("1M/60m", 1000000, 60.0, 1.0),

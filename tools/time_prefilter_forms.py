@@ -1,6 +1,7 @@
+"""ndt_voxel_grid_filter_device with the dense, the sparse and the automatically chosen voxel index (N1 prefilter)."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyslam_amd import clouds, ndt
 import torch
 for n, leaf in ((100000, 0.1), (300000, 0.1), (2000000, 0.5)):
