@@ -200,14 +200,12 @@ def test_config3_fixed_work_batch(mods, map_build):
     assert ((rot < 2e-3) & (tr < 2e-2)).sum() >= 240  # U(+-0.5 m, +-2 deg) on structureless set U: about half are inside the basin
     res2 = g.alignBatch(scans)
     assert np.array_equal(res["T"], res2["T"])
-    # as ONE lock-step loop instead of the automatic four groups: the same registrations to the rounding of the sums
-    # (a group orders its scans on a lattice common to the group)
+    # as ONE lock-step loop instead of the automatic four groups: the same bits (a scan is ordered on a lattice of its
+    # own and walked by a block count of its own, so its sums do not depend on the scans around it)
     g.setBatchGroups(1)
     res1 = g.alignBatch(scans)
-    same_count = int((res1["iterations"] == res["iterations"]).sum())
-    assert same_count >= 480, same_count  # at the noise floor of the forced passes a line search may end one pass apart
-    assert max(rot_err(a, b) for a, b in zip(res1["T"], res["T"])) < ROT_TOL
-    assert max(trans_err(a, b) for a, b in zip(res1["T"], res["T"])) < TRANS_TOL
+    assert np.array_equal(res1["T"], res["T"]) and np.array_equal(res1["iterations"], res["iterations"])
+    assert np.array_equal(res1["trans_probability"], res["trans_probability"])
     res = res1
     # the sharded lock-step form with a one-rank RCCL communicator: bit for bit the one-loop batch
     g.commInitRank(ndt.comm_get_unique_id(), 0, 1)

@@ -875,6 +875,13 @@ def test_ragged_batch_equals_individual(mods, pair, method):
     g.setMaximumIterations(30)
     g.setInputTarget(t)
     res = g.alignBatch(scans)
+    # cut into independent groups (one of them holds the scan 500 m away, which changes that group's bounding box):
+    # bit for bit the one loop -- a member's point order and block count depend on the member alone
+    g.setBatchGroups(3)
+    res_g = g.alignBatch(scans)
+    g.setBatchGroups(0)
+    assert np.array_equal(res["T"], res_g["T"], equal_nan=True) and np.array_equal(res["iterations"], res_g["iterations"])
+    assert np.array_equal(res["trans_probability"], res_g["trans_probability"], equal_nan=True)
     for k, scan in enumerate(scans):
         g.setInputSource(scan)
         g.align()

@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyslam_amd import clouds, ndt  # noqa: E402
 
 
+MARK = "FUZZ_BATCH_MARK" in os.environ  # with FUZZ_BATCH_ONLY: run every case, mark that one's stderr section
+ONLY = int(os.environ["FUZZ_BATCH_ONLY"]) if "FUZZ_BATCH_ONLY" in os.environ else None  # run this case only (same random stream)
+
+
 def main():
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
     n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -34,7 +38,44 @@ def main():
                 sc = (sc + 1000.0).astype(np.float32)
             scans.append(sc.astype(np.float32))
             guesses.append(np.eye(4, dtype=np.float32) if rng.random() < 0.5 else clouds.random_T(rng, 0.2, 1.0).astype(np.float32))
+        if ONLY is not None and case != ONLY and not MARK:
+            continue
+        g.setBatchGroups(1)
+        if ONLY == case:
+            sys.stderr.write("==== one loop\n")
+            sys.stderr.flush()
         res = g.alignBatch(scans, guesses)
+        if ONLY == case:
+            sys.stderr.write("==== groups\n")
+            sys.stderr.flush()
+        # the same batch cut into independent groups (own worker handle, stream and host thread each): a member's share of
+        # the launch does not depend on the other members, so the results must be the same bits
+        groups = int(rng.integers(2, 5))
+        g.setBatchGroups(groups)
+        res_g = g.alignBatch(scans, guesses)
+        g.setBatchGroups(0)
+        if ONLY == case:
+            sys.stderr.write("==== end\n")
+            sys.stderr.flush()
+        if not (np.array_equal(res["T"], res_g["T"], equal_nan=True) and np.array_equal(res["iterations"], res_g["iterations"]) and
+                np.array_equal(res["converged"], res_g["converged"]) and np.array_equal(res["trans_probability"], res_g["trans_probability"], equal_nan=True)):
+            bad += 1
+            print("MISMATCH case", case, ": %d groups differ from one loop" % groups)
+            g.setBatchGroups(1)
+            again = g.alignBatch(scans, guesses)
+            g.setBatchGroups(groups)
+            again_g = g.alignBatch(scans, guesses)
+            g.setBatchGroups(0)
+            eq = lambda a, b: np.array_equal(a["trans_probability"], b["trans_probability"], equal_nan=True)  # noqa: E731
+            print("   repeat: one loop == one loop again:", eq(res, again), "; groups == groups again:", eq(res_g, again_g), "; one loop again == groups again:", eq(again, again_g))
+            for k in range(len(scans)):
+                if res["converged"][k] != res_g["converged"][k] or not np.array_equal(res["trans_probability"][k], res_g["trans_probability"][k], equal_nan=True):
+                    print("   member", k, "n", len(scans[k]), "converged", res["converged"][k], res_g["converged"][k], "trans_probability",
+                          res["trans_probability"][k], res_g["trans_probability"][k])
+                if not (np.array_equal(res["T"][k], res_g["T"][k], equal_nan=True) and res["iterations"][k] == res_g["iterations"][k]):
+                    print("   member", k, "of", len(scans), "n", len(scans[k]), "iterations", res["iterations"][k], res_g["iterations"][k], "max |dT|",
+                          float(np.nanmax(np.abs(res["T"][k] - res_g["T"][k]))), "search", g.getNeighborhoodSearchMethod() if hasattr(g, "getNeighborhoodSearchMethod") else "?",
+                          "sizes", [len(x) for x in scans])
         for k, sc in enumerate(scans):
             g.setInputSource(sc)
             g.align(guesses[k])

@@ -26,6 +26,9 @@ def cloud(rng, n, extent):
     return (c + rng.uniform(-3000, 3000, 3) * (rng.random() < 0.3)).astype(np.float32)
 
 
+FORM = int(os.environ["FUZZ_GRID_INDEX"]) if "FUZZ_GRID_INDEX" in os.environ else None  # pin the voxel index form (0 / 1 / 2)
+
+
 def main():
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
     n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -47,6 +50,9 @@ def main():
         # ---- K1
         g = ndt.NormalDistributionsTransform()
         g.setResolution(res)
+        # the voxel index: automatic, dense table, or sort + hash -- every form against the oracle (and so against each other)
+        index_form = int(rng.choice([0, 1, 2])) if FORM is None else FORM
+        g.setVoxelIndex(index_form)
         g.setMinPointPerVoxel(min_pts)
         g.setCovEigValueInflationRatio(eig)
         o = po.OracleNDT(resolution=res, min_points_per_voxel=min_pts, eig_ratio=eig)
@@ -78,7 +84,7 @@ def main():
                             why = "%s differs (rel %.3g)" % (k, np.abs(x[fin] - y[fin]).max() / scale)
         if why:
             bad += 1
-            print("MISMATCH K1 case", case, "n", n, "extent", extent, "res", res, "min_pts", min_pts, "eig", eig, "dense", dense, ":", why)
+            print("MISMATCH K1 case", case, "index form", index_form, "n", n, "extent", extent, "res", res, "min_pts", min_pts, "eig", eig, "dense", dense, ":", why)
         # ---- N1 / N2
         leaf = float(rng.choice([0.05, 0.3, 1.0])) * max(extent / 30.0, 0.05)
         ref, ov = po.voxel_grid_filter(c, leaf, is_dense=dense)

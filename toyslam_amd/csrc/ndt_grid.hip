@@ -138,80 +138,136 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   return NDT_OK;
 }
 
-// All scans of a batch in ONE count/scan/scatter pass: a common lattice over the batch's bounding
-// box, composite key scan * n_cells + cell.  The ordered points of scan k end up contiguous at
-// scan_starts[k] (non-finite points are dropped, so the segments are compacted).
+// The scans of a batch in count / scan / scatter passes (composite key: the scan's first counter + its cell); the ordered
+// points of scan k end up contiguous at scan_starts[k] (non-finite points are dropped, so the segments are compacted).
+// A scan's order must not depend on the batch around it -- a member of a lock-step batch gets the same sums, bit for bit,
+// whichever group or rank it is registered in (tools/fuzz_batch.py) -- so every scan is ordered on a lattice of its own:
+// pitch `resolution` (doubled only while that ONE scan's box has more than kMaxCounters cells), box from its own points.
+// Scans go through in passes of at most kMaxCounters counters.
 ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans) {
   hipStream_t st = h->stream;
-  const int ni = static_cast<int>(c->n);
   c->scan_counts.assign(n_scans, 0);
   c->scan_starts.assign(n_scans + 1, 0);
-  const BBox bb = bbox_of(*c, 0);  // from the upload
-  const float* min_p = bb.mn;
-  const float* max_p = bb.mx;
-  if (!(min_p[0] <= max_p[0])) return NDT_OK;
-  ndt::GridGeom geo{};
-  for (float pitch = h->resolution;; pitch *= 2.0f) {
-    double cells = 1;
-    for (int k = 0; k < 3; k++) {
-      geo.leaf[k] = pitch;
-      geo.inv_leaf[k] = 1.0f / pitch;
-      geo.min_b[k] = static_cast<int>(std::floor(min_p[k] * geo.inv_leaf[k]));
-      geo.max_b[k] = static_cast<int>(std::floor(max_p[k] * geo.inv_leaf[k]));
-      geo.div_b[k] = geo.max_b[k] - geo.min_b[k] + 1;
-      cells *= geo.div_b[k];
-    }
-    if (cells * static_cast<double>(n_scans) <= 32.0e6) break;
-  }
-  geo.mul[0] = 1;
-  geo.mul[1] = geo.div_b[0];
-  geo.mul[2] = geo.div_b[0] * geo.div_b[1];
-  geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
-  const long long total_cells = geo.n_cells * static_cast<long long>(n_scans);
+  c->n_sorted = 0;
+  if (n_scans == 0 || c->n == 0) return NDT_OK;
+  constexpr double kMaxCounters = 32.0e6;
+  // ---- per-scan bounding boxes (one kernel, one small copy back)
   std::vector<int> off(n_scans + 1);
   size_t max_scan = 0;
   for (size_t k = 0; k <= n_scans; k++) off[k] = static_cast<int>(offsets[k] - offsets[0]);
   for (size_t k = 0; k < n_scans; k++) max_scan = std::max(max_scan, offsets[k + 1] - offsets[k]);
-  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
-  DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx, d_off;
+  DevBuf<int> d_off, d_box;
   HIP_TRY(d_off.reserve(n_scans + 1));
+  HIP_TRY(d_box.reserve(6 * n_scans));
+  std::vector<int> box(6 * n_scans);
+  for (size_t k = 0; k < n_scans; k++)
+    for (int j = 0; j < 6; j++) box[6 * k + j] = j < 3 ? std::numeric_limits<int>::max() : std::numeric_limits<int>::min();
   HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n_scans + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(cell_count.reserve(static_cast<size_t>(total_cells) + 1));
-  HIP_TRY(key.reserve(c->n));
-  HIP_TRY(rank.reserve(c->n));
-  HIP_TRY(hipMemsetAsync(cell_count.p, 0, (static_cast<size_t>(total_cells) + 1) * sizeof(unsigned), st));
-  HIP_TRY(ndt::launch_count_batch(c->pts.p, d_off.p, static_cast<int>(n_scans), static_cast<int>(max_scan), geo, key.p, rank.p,
-                                  cell_count.p, st));
-  // one extra (always empty) cell at the end so that its start offset is the grand total
-  const long long scan_cells = total_cells + 1;
-  const int n_tiles = ndt::scan_tiles(scan_cells);
-  HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
-  HIP_TRY(totals.reserve(4));
-  HIP_TRY(ndt::launch_scan_reduce(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, st));
-  HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
-  unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));  // read after the final synchronise
-  const size_t n_leaves = std::min<size_t>(c->n, static_cast<size_t>(scan_cells));  // upper bound; the count stays on the device
-  HIP_TRY(leaf_cell.reserve(n_leaves));
-  HIP_TRY(leaf_start.reserve(n_leaves));
-  HIP_TRY(leaf_count.reserve(n_leaves));
-  HIP_TRY(leaf_rec.reserve(n_leaves));
-  HIP_TRY(sorted_idx.reserve(c->n));
-  HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, leaf_cell.p, leaf_start.p,
-                                 leaf_count.p, leaf_rec.p, st));
-  // start offset of every scan's first cell (+ the sentinel cell = grand total)
-  std::vector<unsigned> starts(n_scans + 1);
-  HIP_TRY(hipMemcpy2DAsync(starts.data(), sizeof(unsigned), cell_count.p, static_cast<size_t>(geo.n_cells) * sizeof(unsigned),
-                           sizeof(unsigned), n_scans + 1, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
-  HIP_TRY(ndt::launch_sort_gather(c->pts.p, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p, st, totals.p));
+  HIP_TRY(hipMemcpyAsync(d_box.p, box.data(), box.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(ndt::launch_scan_bboxes(c->pts.p, d_off.p, static_cast<int>(n_scans), static_cast<int>(max_scan), d_box.p, st));
+  HIP_TRY(hipMemcpyAsync(box.data(), d_box.p, box.size() * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  // ---- every scan's own lattice
+  std::vector<ndt::ScanLattice> lat(n_scans);
   for (size_t k = 0; k < n_scans; k++) {
-    c->scan_starts[k] = starts[k];
-    c->scan_counts[k] = starts[k + 1] - starts[k];
+    ndt::ScanLattice& L = lat[k];
+    L = ndt::ScanLattice{};
+    if (box[6 * k] > box[6 * k + 3]) continue;  // no finite point: n_cells 0
+    float mn[3], mx[3];
+    for (int j = 0; j < 3; j++) { mn[j] = ndt::scan_bbox_decode(box[6 * k + j]); mx[j] = ndt::scan_bbox_decode(box[6 * k + 3 + j]); }
+    for (float pitch = h->resolution;; pitch *= 2.0f) {
+      const float inv = 1.0f / pitch;
+      double cells = 1;
+      int div[3];
+      for (int j = 0; j < 3; j++) {
+        L.min_b[j] = static_cast<int>(std::floor(mn[j] * inv));
+        div[j] = static_cast<int>(std::floor(mx[j] * inv)) - L.min_b[j] + 1;
+        cells *= div[j];
+      }
+      if (cells <= kMaxCounters) {
+        L.inv_leaf = inv;
+        L.mul1 = div[0];
+        L.mul2 = div[0] * div[1];
+        L.n_cells = static_cast<int>(cells);
+        break;
+      }
+    }
   }
-  c->scan_starts[n_scans] = starts[n_scans];
-  c->n_sorted = tot[0];
+  DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank, d_starts;
+  DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  DevBuf<ndt::ScanLattice> d_lat;
+  DevBuf<long long> d_bases;
+  size_t out_base = 0;
+  for (size_t s0 = 0; s0 < n_scans;) {
+    // this pass: scans [s0, s0 + ns) while their counters fit
+    size_t ns = 0;
+    long long total_cells = 0;
+    while (s0 + ns < n_scans && (ns == 0 || static_cast<double>(total_cells + lat[s0 + ns].n_cells) <= kMaxCounters)) {
+      lat[s0 + ns].base = total_cells;
+      total_cells += lat[s0 + ns].n_cells;
+      ns++;
+    }
+    const size_t first_pt = offsets[s0] - offsets[0], n_pts = offsets[s0 + ns] - offsets[s0];
+    if (n_pts == 0 || total_cells == 0) {
+      for (size_t k = 0; k < ns; k++) c->scan_starts[s0 + k] = out_base;
+      s0 += ns;
+      continue;
+    }
+    const int ni = static_cast<int>(n_pts);
+    const float4* in = c->pts.p + first_pt;
+    std::vector<int> poff(ns + 1);
+    std::vector<long long> bases(ns + 1);
+    size_t pass_max = 0;
+    for (size_t k = 0; k <= ns; k++) poff[k] = static_cast<int>(offsets[s0 + k] - offsets[s0]);
+    for (size_t k = 0; k < ns; k++) {
+      pass_max = std::max(pass_max, offsets[s0 + k + 1] - offsets[s0 + k]);
+      bases[k] = lat[s0 + k].base;
+    }
+    bases[ns] = total_cells;  // the sentinel cell: the pass's total
+    HIP_TRY(d_off.reserve(ns + 1));
+    HIP_TRY(d_lat.reserve(ns));
+    HIP_TRY(d_bases.reserve(ns + 1));
+    HIP_TRY(d_starts.reserve(ns + 1));
+    HIP_TRY(hipMemcpyAsync(d_off.p, poff.data(), (ns + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_lat.p, lat.data() + s0, ns * sizeof(ndt::ScanLattice), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_bases.p, bases.data(), (ns + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+    HIP_TRY(cell_count.reserve(static_cast<size_t>(total_cells) + 1));
+    HIP_TRY(key.reserve(n_pts));
+    HIP_TRY(rank.reserve(n_pts));
+    HIP_TRY(hipMemsetAsync(cell_count.p, 0, (static_cast<size_t>(total_cells) + 1) * sizeof(unsigned), st));
+    HIP_TRY(ndt::launch_count_batch(in, d_off.p, static_cast<int>(ns), static_cast<int>(pass_max), d_lat.p, key.p, rank.p, cell_count.p, st));
+    // one extra (always empty) cell at the end so that its start offset is the pass's total
+    const long long scan_cells = total_cells + 1;
+    const int n_tiles = ndt::scan_tiles(scan_cells);
+    HIP_TRY(block_sums.reserve(static_cast<size_t>(n_tiles) * 3));
+    HIP_TRY(totals.reserve(4));
+    HIP_TRY(ndt::launch_scan_reduce(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, st));
+    HIP_TRY(ndt::launch_scan_blocks(block_sums.p, n_tiles, totals.p, st));
+    unsigned tot[3];
+    HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));  // read after the pass's synchronise
+    const size_t n_leaves = std::min<size_t>(n_pts, static_cast<size_t>(scan_cells));  // upper bound; the count stays on the device
+    HIP_TRY(leaf_cell.reserve(n_leaves));
+    HIP_TRY(leaf_start.reserve(n_leaves));
+    HIP_TRY(leaf_count.reserve(n_leaves));
+    HIP_TRY(leaf_rec.reserve(n_leaves));
+    HIP_TRY(sorted_idx.reserve(n_pts));
+    HIP_TRY(ndt::launch_scan_apply(cell_count.p, scan_cells, 1, block_sums.p, n_tiles, leaf_cell.p, leaf_start.p, leaf_count.p, leaf_rec.p, st));
+    // start offset of every scan's first cell (+ the sentinel cell)
+    std::vector<unsigned> starts(ns + 1);
+    HIP_TRY(ndt::launch_pick(cell_count.p, d_bases.p, d_starts.p, static_cast<int>(ns + 1), st));
+    HIP_TRY(hipMemcpyAsync(starts.data(), d_starts.p, (ns + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ndt::launch_scatter(key.p, rank.p, ni, cell_count.p, sorted_idx.p, st));
+    HIP_TRY(ndt::launch_sort_gather(in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, c->sorted.p + out_base, st, totals.p));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t k = 0; k < ns; k++) {
+      c->scan_starts[s0 + k] = out_base + starts[k];
+      c->scan_counts[s0 + k] = starts[k + 1] - starts[k];
+    }
+    out_base += starts[ns];
+    c->n_sorted += tot[0];
+    s0 += ns;
+  }
+  c->scan_starts[n_scans] = out_base;
   return NDT_OK;
 }
 

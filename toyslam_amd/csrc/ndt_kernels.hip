@@ -154,24 +154,65 @@ __global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts
   }
 }
 
-// Batch variant for the source ordering of many scans at once: blockIdx.y = scan, composite key
-// scan * n_cells + cell, so one count/scan/scatter pass orders every scan inside its own segment.
-__global__ __launch_bounds__(kBlock) void k_count_batch(const float4* __restrict__ pts, const int* __restrict__ scan_off,
-                                                        GridGeom g, int* __restrict__ key, unsigned* __restrict__ rank,
-                                                        unsigned* __restrict__ cell_count) {
+// Batch variant for the source ordering of many scans at once: blockIdx.y = scan, composite key = the scan's base + its
+// cell on the scan's OWN lattice (ScanLattice), so one count / scan / scatter pass orders every scan inside its own
+// segment and a scan's order is a function of its own points only.
+__device__ __forceinline__ int enc_f32(float f) {  // order-preserving: a < b  <=>  enc(a) < enc(b)  (finite values)
+  const int b = __float_as_int(f);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__global__ __launch_bounds__(kBlock) void k_scan_bboxes(const float4* __restrict__ pts, const int* __restrict__ scan_off, int* __restrict__ out) {
   const int lo = scan_off[blockIdx.y], hi = scan_off[blockIdx.y + 1];
-  const long long base = static_cast<long long>(blockIdx.y) * g.n_cells;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    if (!finite3(p.x, p.y, p.z)) continue;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, kWave));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, kWave));
+    }
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && mn[0] <= mx[0]) {
+    int* o = out + 6 * blockIdx.y;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      atomicMin(o + k, enc_f32(mn[k]));
+      atomicMax(o + 3 + k, enc_f32(mx[k]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_batch(const float4* __restrict__ pts, const int* __restrict__ scan_off,
+                                                        const ScanLattice* __restrict__ lat, int* __restrict__ key,
+                                                        unsigned* __restrict__ rank, unsigned* __restrict__ cell_count) {
+#pragma clang fp contract(off)
+  const int lo = scan_off[blockIdx.y], hi = scan_off[blockIdx.y + 1];
+  const ScanLattice L = lat[blockIdx.y];
   for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
     const float4 p = pts[i];
     int c = -1;
-    if (finite3(p.x, p.y, p.z)) {
-      c = build_cell(g, p.x, p.y, p.z);
-      if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;
-      else c = static_cast<int>(base + c);
+    if (L.n_cells > 0 && finite3(p.x, p.y, p.z)) {
+      const int i0 = static_cast<int>(floorf(p.x * L.inv_leaf)) - L.min_b[0];
+      const int i1 = static_cast<int>(floorf(p.y * L.inv_leaf)) - L.min_b[1];
+      const int i2 = static_cast<int>(floorf(p.z * L.inv_leaf)) - L.min_b[2];
+      const int cell = i0 + i1 * L.mul1 + i2 * L.mul2;
+      if (i0 >= 0 && i1 >= 0 && i2 >= 0 && cell >= 0 && cell < L.n_cells) c = static_cast<int>(L.base + cell);
     }
     key[i] = c;
     if (c >= 0) rank[i] = atomicAdd(&cell_count[c], 1u);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pick(const unsigned* __restrict__ cell_count, const long long* __restrict__ bases,
+                                                 unsigned* __restrict__ out, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = cell_count[bases[i]];
 }
 
 // ---------------------------------------------------------------------------
@@ -1818,10 +1859,24 @@ hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start,
   return hipGetLastError();
 }
 
-hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const GridGeom& g,
+hipError_t launch_scan_bboxes(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, int* d_out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_bboxes, dim3(grid_for(max_scan_points, 64), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, d_out);
+  return hipGetLastError();
+}
+float scan_bbox_decode(int v) {
+  const int b = v ^ ((v >> 31) & 0x7fffffff);
+  float f;
+  std::memcpy(&f, &b, sizeof(f));
+  return f;
+}
+hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const ScanLattice* d_lat,
                               int* d_key, unsigned* d_rank, unsigned* d_cell_count, hipStream_t stream) {
-  hipLaunchKernelGGL(k_count_batch, dim3(grid_for(max_scan_points, 256), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, g,
+  hipLaunchKernelGGL(k_count_batch, dim3(grid_for(max_scan_points, 256), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, d_lat,
                      d_key, d_rank, d_cell_count);
+  return hipGetLastError();
+}
+hipError_t launch_pick(const unsigned* cell_count, const long long* d_bases, unsigned* d_out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_pick, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cell_count, d_bases, d_out, n);
   return hipGetLastError();
 }
 

@@ -157,8 +157,23 @@ hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, 
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
 hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
                         unsigned* d_cell_count, hipStream_t stream);
-hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const GridGeom& g,
+// Source ordering of a lock-step batch: every scan on a lattice of ITS OWN (pitch and box from its own points only), so
+// that a scan's order -- and with it the order of its f64 sums -- does not depend on the batch around it.
+struct ScanLattice {
+  float inv_leaf;   // 1 / pitch
+  int min_b[3];     // floor(min * inv_leaf) of the scan's own bounding box
+  int mul1, mul2;   // strides of y and z (x: 1)
+  int n_cells;      // cells of the scan's box; 0: no finite point
+  long long base;   // first composite cell of the scan in this pass's counter array
+};
+// bounding boxes per scan, order-preserving int encoding of the floats: out[scan][0..2] = min xyz, [3..5] = max xyz
+// (the caller fills out with INT_MAX / INT_MIN first); scan_bbox_decode turns an encoded value back into the float
+hipError_t launch_scan_bboxes(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, int* d_out, hipStream_t stream);
+float scan_bbox_decode(int v);
+hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const ScanLattice* d_lat,
                               int* d_key, unsigned* d_rank, unsigned* d_cell_count, hipStream_t stream);
+// out[k] = cell_count[bases[k]] (k < n): where every scan's ordered segment starts, after the exclusive scan
+hipError_t launch_pick(const unsigned* cell_count, const long long* d_bases, unsigned* d_out, int n, hipStream_t stream);
 hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
                               int n_tiles, hipStream_t stream);
 hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream);
