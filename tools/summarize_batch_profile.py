@@ -23,7 +23,8 @@ for r in rows[:16]:
     out["kernel_stats"][r["Name"][:100]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
 tot = collections.defaultdict(float)
 for name in ("fetch", "write"):  # (one run per pass: profile_batch.sh starts from an empty directory)
-    for f in glob.glob(os.path.join(O, name, "*", "*counter_collection.csv")):
+    # (gpurun merges every call's files into the local gpurun_out/: only the newest run of each pass counts)
+    for f in sorted(glob.glob(os.path.join(O, name, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"][:100]][r["Counter_Name"]].append(float(r["Counter_Value"]))
