@@ -82,6 +82,18 @@ def test_binary_round_trip_and_python_reader(ndt, tmp_path):
     # empty cloud
     ndt.pcd_write_xyz(q, np.zeros((0, 3), np.float32))
     assert ndt.pcd_read_xyz(q)[0].shape == (0, 3)
+    # the chunked reader (32 768 records per chunk; the last record of a chunk takes the scalar path): non-finite values
+    # anywhere clear the dense flag, every coordinate survives
+    big = (rng.standard_normal((70001, 3)) * [30, 30, 3]).astype(np.float32)
+    ndt.pcd_write_xyz(q, big)
+    got, dense = ndt.pcd_read_xyz(q)
+    assert dense and np.array_equal(got, big)
+    for where, col, bad in ((0, 0, np.nan), (32767, 2, np.inf), (32768, 1, -np.inf), (40000, 2, np.nan), (70000, 0, np.nan)):
+        c = big.copy()
+        c[where, col] = bad
+        ndt.pcd_write_xyz(q, c)
+        got, dense = ndt.pcd_read_xyz(q)
+        assert not dense and np.array_equal(got, c, equal_nan=True), where
 
 
 def test_extra_fields_orders_and_types(ndt, tmp_path):
