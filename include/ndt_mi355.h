@@ -311,6 +311,10 @@ ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* st
 /* Diagnostic: round-trip latency of the persistent evaluation server, averaged over n_iter commands:
  * us[0] = no-op round (protocol only), us[1] = derivatives without Hessian, us[2] = with Hessian. */
 ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, double* us);
+/* Diagnostic: `rounds` evaluations at pose p driven from the DEVICE (the last arriving block adds the part sums and posts the
+ * next command itself; no Newton / line-search step): us[0] per round without the per-point body, us[1] with the
+ * with-Hessian body -- the floor a device-side solver would start from.  DIRECT7 only. */
+ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double* us);
 
 /* Host-side scalar pieces of the driver (no GPU needed), exported so that the
  * CPU test-suite can check them against the oracle. */

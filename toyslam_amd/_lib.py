@@ -101,6 +101,7 @@ SIGNATURES = {
     "ndt_grid_dump": (C.c_int, [vp, C.POINTER(C.c_int64), ip, dp, dp, dp, dp]),
     "ndt_diag_stamps": (C.c_int, [vp, dp, C.POINTER(C.c_ulonglong), szp]),
     "ndt_diag_server_roundtrip": (C.c_int, [vp, dp, C.c_int, dp]),
+    "ndt_diag_selfdrive": (C.c_int, [vp, dp, C.c_int, dp]),
     "ndt_selftest_reduce": (C.c_int, [vp, C.c_int, dp]),
     "ndt_selftest_server_idle": (C.c_int, [vp, dp, C.c_int, ip, dp]),
     "ndt_profile_enable": (C.c_int, [vp, C.c_int]),

@@ -539,6 +539,67 @@ ndt_status ndt_diag_stamps(ndt_handle h, const double* p, unsigned long long* st
   return NDT_OK;
 }
 
+// Diagnostic: `rounds` evaluations at pose p with the host out of the loop (k_selfdrive: the last arriver adds the part
+// sums and posts the next command itself).  us[0]: per round without the per-point body (protocol only), us[1]: with the
+// with-Hessian body.  What a device-side Newton / More-Thuente step would start from, before the solver's own time.
+ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double* us) {
+  if (!h || !p || !us || rounds <= 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = check_ready(h);
+  if (s) return s;
+  if (h->source->k2_n() == 0 || h->grid->empty) return fail(NDT_ERR_INVALID, "empty inputs");
+  if (h->search != 2) return fail(NDT_ERR_INVALID, "DIRECT7 only");
+  s = server_stop(h);
+  if (s) return s;
+  std::lock_guard<std::mutex> turn(server_device_mutex(h->device));
+  const int n = h->source->k2_n();
+  const int ppb = ndt::points_per_block(n);
+  const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + ppb - 1) / ppb));
+  const size_t mb_bytes = ndt::server_mailbox_bytes();
+  DevBuf<unsigned char> mb;
+  DevBuf<double> parts;
+  HIP_TRY(mb.reserve(mb_bytes));
+  HIP_TRY(parts.reserve(static_cast<size_t>(ndt::kServerParts) * ndt::kEvalStride));
+  HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
+  HIP_TRY(h->server_counter.reserve(32 * (1 + ndt::kServerParts)));
+  HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
+  const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
+  const float r2 = kd_radius2(h->resolution);
+  int pad_bits;
+  std::memcpy(&pad_bits, &r2, sizeof(int));
+  float T[16], T12[12];
+  ndt::pose_to_matrix(p, T);
+  colmajor_to_T12(T, T12);
+  double cs[6];
+  ndt::snapped_cos_sin(p, cs);
+  alignas(64) unsigned char staged[1024];
+  if (mb_bytes > sizeof(staged)) return fail(NDT_ERR_INVALID, "mailbox larger than the staging block");
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  for (int with_body = 0; with_body < 2; with_body++) {
+    const unsigned long long first_seq = h->eval_seq + 1;
+    h->eval_seq += static_cast<unsigned long long>(rounds);
+    std::memset(staged, 0, sizeof(staged));
+    ndt::server_post(staged, first_seq, 0, T12, cs);
+    HIP_TRY(hipMemcpyAsync(mb.p, staged, mb_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * (1 + ndt::kServerParts) * sizeof(unsigned), h->stream));
+    HIP_TRY(hipEventRecord(e0, h->stream));
+    HIP_TRY(ndt::launch_selfdrive(h->source->k2_pts(), n, h->grid->view(), h->search, mb.p, nblk, h->partials.p, h->server_counter.p, parts.p,
+                                  h->host_pub, first_seq, rounds, with_body, gs.d1, gs.d2, pad_bits, h->stream));
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    us[with_body] = static_cast<double>(ms) * 1e3 / rounds;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // the last round's row must be what the evaluation paths compute at this pose (the caller compares with ndt_eval)
+  if (!pub_ready(h->host_pub, h->eval_seq)) return fail(NDT_ERR_HIP, "self-driven rounds did not publish their last row");
+  pub_gather(h->host_pub, h->host_result);
+  return NDT_OK;
+}
+
 ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, double* us) {
   if (!h || !p || !us || n_iter <= 0) return fail(NDT_ERR_INVALID, "bad arguments");
   ndt_status s = check_ready(h);

@@ -229,6 +229,10 @@ size_t server_mailbox_bytes();
 void server_reset_mailbox(void* host_mailbox);
 void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6);
 unsigned long long server_dead_word(const void* host_mailbox);
+// diagnostic: the server's round driven from the device (k_selfdrive, ndt_latency.hip); server_post fills a host copy of the mailbox
+hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, double* partials,
+                            unsigned* counter, double* parts, double* out_row, unsigned long long first_seq, int rounds, int with_body,
+                            double gauss_d1, double gauss_d2, int param_pad, hipStream_t stream);
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,

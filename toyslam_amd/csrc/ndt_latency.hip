@@ -412,6 +412,143 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Diagnostic (never used by the product path): the evaluation server's round with the HOST taken out of the loop.
+// Same tables, body, fold, row store, shard tickets and part sums as k_eval_server; then the 16 shard-last blocks
+// meet on a second-level ticket, the last of them adds the 16 parts (what the host does today) and posts the NEXT
+// command itself -- same pose, next sequence number -- into a device mailbox that every block polls.  No Newton /
+// More-Thuente step is computed: kernel time / rounds is the protocol + body cost a device-side solver would START from
+// (what moving the solver onto the device could save at best).
+// ---------------------------------------------------------------------------------------------------------
+template <int NNB>
+__global__ __launch_bounds__(kServerTPB) void k_selfdrive(const float4* __restrict__ src, int n, GridView gv, ServerMailbox* dev_mb,
+                                                          double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                          double* __restrict__ parts, double* __restrict__ out_row,
+                                                          unsigned long long first_seq, int rounds, int with_body, double gauss_d1,
+                                                          double gauss_d2, int param_pad, int ppb) {
+  constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
+  __shared__ double lds[kWaves * 32];
+  __shared__ EvalParams sP;
+  __shared__ PackedTables sT;
+  __shared__ double s_f[8];
+  __shared__ int s_last;
+  __shared__ int s_final;
+  __shared__ unsigned long long s_cmd[kCmdWords];
+  unsigned long long expect = first_seq;
+  const int my_first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
+  float4 my_pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (my_first < n) my_pt = src[my_first];
+  unsigned terms_lo = 0, terms_hi = 0;
+  int pack_pos = 0;
+  if (threadIdx.x < 69) {
+    pack_pos = kPackPos[threadIdx.x];
+    const signed char* t = kAngleTerms[threadIdx.x];
+    for (int k = 0; k < 4; k++) {
+      terms_lo |= static_cast<unsigned>(static_cast<unsigned char>(t[k])) << (8 * k);
+      terms_hi |= static_cast<unsigned>(static_cast<unsigned char>(t[4 + k])) << (8 * k);
+    }
+  }
+  if (threadIdx.x == 0) {
+    sP.d1 = gauss_d1;
+    sP.d2 = static_cast<float>(gauss_d2);
+    sP.pad = param_pad;
+  }
+  const unsigned n_parts = min(static_cast<unsigned>(kParts), gridDim.x);
+  for (int round = 0; round < rounds; round++) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    asm volatile("" : "+s"(dev_mb), "+s"(partials), "+s"(counter), "+s"(parts), "+s"(out_row), "+s"(src));
+    if (wave == 0) {  // every block: wait for the device command block
+      unsigned long long w = 0;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        if (lane < kCmdWords) w = __hip_atomic_load(&dev_mb->cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(lane >= kCmdWords || static_cast<unsigned>(w) == static_cast<unsigned>(expect)) == ~0ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) break;  // 20 ms: never hang the grid
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned payload = static_cast<unsigned>(w >> 32);
+      const unsigned next = __shfl_down(payload, 1, kWave);
+      if (lane < kCmdWords) s_cmd[lane] = w;
+      if (lane < 12) sP.T[lane] = __int_as_float(static_cast<int>(payload));
+      if (lane >= 13 && lane < 25 && ((lane - 13) & 1) == 0) {
+        const double v = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(next) << 32) | payload));
+        const int a = (lane - 13) >> 1;
+        s_f[(a < 3) ? 2 + 2 * a : 1 + 2 * (a - 3)] = v;
+      }
+      if (lane == 0) { s_f[0] = 1.0; s_f[7] = 0.0; }
+    }
+    __syncthreads();
+    if (tid < 69) {
+      const double c64 = angle_coefficient_f64_held(terms_lo, terms_hi, s_f);
+      const float c = static_cast<float>((tid == 24 + 6 * 3 + 2) ? s_f[3] : c64);
+      reinterpret_cast<float*>(&sT)[pack_pos] = c;
+    }
+    __syncthreads();
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int first = (tid < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + tid : n, stride = gridDim.x * ppb;
+    if (with_body) derivatives_body<NNB, true, false, true>(src, n, gv, sP, sT, first, stride, acc, nullptr, my_pt);
+    const double tot = wave_fold<kNumAcc>(acc);
+    if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < kEvalStride) {
+        double v = 0.0;
+        if (lane < kNumAcc) {
+          v = lds[lane];
+#pragma unroll
+          for (int w = 1; w < kWaves; w++) v += lds[w * 32 + lane];
+        }
+        __hip_atomic_store(partials + static_cast<size_t>(blockIdx.x) * kEvalStride + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
+        const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
+        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t1 == (static_cast<unsigned>(round) + 1u) * in_shard - 1u) ? 1 : 0;
+        s_final = 0;
+      }
+    }
+    __syncthreads();
+    if (s_last) {  // part sum of this shard -> device memory, then the second-level ticket
+      const int shard = static_cast<int>(blockIdx.x % static_cast<unsigned>(kParts));
+      if (tid < kEvalStride) {
+        const double v = sum_rows_fixed<kParts>(partials, gridDim.x, shard * kEvalStride + tid);
+        __hip_atomic_store(parts + static_cast<size_t>(shard) * kEvalStride + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_final = (t2 == (static_cast<unsigned>(round) + 1u) * n_parts - 1u) ? 1 : 0;
+      }
+      __syncthreads();
+      if (s_final) {  // what the host does today: the 16 parts in order ... and (here) the next command
+        if (tid < kEvalStride) {
+          double t = 0.0;
+          for (unsigned p = 0; p < static_cast<unsigned>(kParts); p++)
+            t += (p < n_parts) ? __hip_atomic_load(parts + static_cast<size_t>(p) * kEvalStride + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          lds[tid] = t;
+        }
+        __syncthreads();
+        if (round + 1 < rounds) {
+          if (tid < kCmdWords)
+            __hip_atomic_store(&dev_mb->cmd[tid], (s_cmd[tid] & 0xffffffff00000000ull) | ((expect + 1) & 0xffffffffull), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          publish_row_tagged(out_row, lds, tid, expect);
+        }
+      }
+    }
+    __syncthreads();
+    expect++;
+  }
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v ? std::atoi(v) : dflt;
@@ -482,6 +619,14 @@ void server_post(void* host_mailbox, unsigned long long seq, int kind, const flo
   for (int i = 0; i < kCmdWords / 2; i++)
     _mm_stream_si128(reinterpret_cast<__m128i*>(&mb->cmd[2 * i]), _mm_load_si128(reinterpret_cast<const __m128i*>(&c[2 * i])));
   _mm_sfence();
+}
+hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, double* partials,
+                            unsigned* counter, double* parts, double* out_row, unsigned long long first_seq, int rounds, int with_body,
+                            double gauss_d1, double gauss_d2, int param_pad, hipStream_t stream) {
+  if (search != 2) return hipErrorInvalidValue;  // DIRECT7 only: a diagnostic
+  hipLaunchKernelGGL(k_selfdrive<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, static_cast<ServerMailbox*>(dev_mailbox), partials,
+                     counter, parts, out_row, first_seq, rounds, with_body, gauss_d1, gauss_d2, param_pad, points_per_block(n));
+  return hipGetLastError();
 }
 unsigned long long server_dead_word(const void* host_mailbox) {
   return __atomic_load_n(&static_cast<const ServerMailbox*>(host_mailbox)->dead, __ATOMIC_ACQUIRE);

@@ -338,6 +338,13 @@ class NormalDistributionsTransform:
         check(self._L.ndt_diag_server_roundtrip(self._h, _d(p), n_iter, _d(us)))
         return dict(nop_us=us[0], no_hessian_us=us[1], with_hessian_us=us[2])
 
+    def diag_selfdrive(self, p, rounds=200):
+        """Rounds driven from the device (no host in the loop, no solver step): us per round without / with the body."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        us = np.zeros(2)
+        check(self._L.ndt_diag_selfdrive(self._h, _d(p), rounds, _d(us)))
+        return dict(protocol_only_us=us[0], with_hessian_body_us=us[1])
+
     def selftest_reduce(self, n_blocks=3):
         out = np.zeros((n_blocks, _lib.EVAL_STRIDE))
         check(self._L.ndt_selftest_reduce(self._h, n_blocks, _d(out)))
