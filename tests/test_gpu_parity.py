@@ -1052,3 +1052,24 @@ def test_sparse_prefilter_of_a_wide_scan(mods):
     assert np.array_equal(dense, ref)
     g.setVoxelIndex(2)
     assert np.array_equal(g.voxelGridFilter(scan[:50000], 0.5), po.voxel_grid_filter(scan[:50000], 0.5)[0])
+
+
+def test_server_round_diagnostics(mods, pair):
+    """The two protocol diagnostics run on the product's buffers and leave the handle usable: the host-driven round trip
+    (ndt_diag_server_roundtrip) and the device-driven round (ndt_diag_selfdrive: the last arriving block posts the next
+    command itself -- the measurement behind DESIGN.md's "device-side solver" paragraph)."""
+    ndt, po, clouds = mods
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    g.setInputSource(s)
+    p = np.array([0.05, -0.03, 0.02, 0.004, -0.002, 0.006])
+    before = g.eval(p, True)
+    host = g.diag_server_roundtrip(p, 50)
+    dev = g.diag_selfdrive(p, 50)
+    assert 0.5 < host["nop_us"] < host["with_hessian_us"] < 500.0
+    assert 0.5 < dev["protocol_only_us"] < dev["with_hessian_body_us"] < 500.0
+    after = g.eval(p, True)
+    assert before[0] == after[0] and np.array_equal(before[1], after[1]) and np.array_equal(before[2], after[2])
+    g.align()
+    assert g.hasConverged()
