@@ -40,6 +40,11 @@ ndt_status gicp_set_max_correspondence_distance(gicp_handle h, double d);
  * Points must be finite (pcl::KdTreeFLANN requires it of its queries); NDT_ERR_INVALID otherwise. */
 ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_t stride_bytes);
 ndt_status gicp_set_input_source(gicp_handle h, const void* pts, size_t n, size_t stride_bytes);
+/* setSourceCovariances / setTargetCovariances (gicp_omp.h:165-168,186-189): one 3x3 f64 matrix per point of the cloud set
+ * before ([n][9] row-major; symmetric, the upper triangle is used) instead of the k-NN covariances computeCovariances
+ * (gicp_omp_impl.hpp:48-116) would produce; setting the cloud again resets them, n == 0 / NULL clears them. */
+ndt_status gicp_set_source_covariances(gicp_handle h, const double* cov, size_t n);
+ndt_status gicp_set_target_covariances(gicp_handle h, const double* cov, size_t n);
 
 /* pcl::Registration::align(output, guess) -> computeTransformation (gicp_omp_impl.hpp:372-517).
  * guess / final_T: column-major 4x4 f32 (Eigen::Matrix4f::data()), guess may be NULL (identity).

@@ -44,10 +44,15 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
 #define GICP_MI355_PCL_SHARED_PTR 1
 #endif
 #endif
+  using MatricesVector = std::vector<Eigen::Matrix3d, Eigen::aligned_allocator<Eigen::Matrix3d> >;  // gicp_omp.h:96
 #ifdef GICP_MI355_PCL_SHARED_PTR
+  using MatricesVectorPtr = pcl::shared_ptr<MatricesVector>;
+  using MatricesVectorConstPtr = pcl::shared_ptr<const MatricesVector>;
   using Ptr = pcl::shared_ptr<GeneralizedIterativeClosestPoint<PointSource, PointTarget> >;
   using ConstPtr = pcl::shared_ptr<const GeneralizedIterativeClosestPoint<PointSource, PointTarget> >;
 #else
+  using MatricesVectorPtr = boost::shared_ptr<MatricesVector>;
+  using MatricesVectorConstPtr = boost::shared_ptr<const MatricesVector>;
   using Ptr = boost::shared_ptr<GeneralizedIterativeClosestPoint<PointSource, PointTarget> >;
   using ConstPtr = boost::shared_ptr<const GeneralizedIterativeClosestPoint<PointSource, PointTarget> >;
 #endif
@@ -71,13 +76,19 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
       return;
     }
     pcl::IterativeClosestPoint<PointSource, PointTarget>::setInputSource(cloud);
+    input_covariances_.reset();
     check(gicp_set_input_source(handle_, cloud->points.data(), cloud->points.size(), sizeof(PointSource)), "gicp_set_input_source");
   }
+  /** :165-168 -- used by the next align instead of the k-NN covariances, until setInputSource */
+  inline void setSourceCovariances(const MatricesVectorPtr& covariances) { input_covariances_ = covariances; }
   /** :156-160 */
   inline void setInputTarget(const PointCloudTargetConstPtr& target) override {
     pcl::IterativeClosestPoint<PointSource, PointTarget>::setInputTarget(target);
+    target_covariances_.reset();
     check(gicp_set_input_target(handle_, target->points.data(), target->points.size(), sizeof(PointTarget)), "gicp_set_input_target");
   }
+  /** :186-189 */
+  inline void setTargetCovariances(const MatricesVectorPtr& covariances) { target_covariances_ = covariances; }
 
   inline void setRotationEpsilon(double epsilon) { rotation_epsilon_ = epsilon; }  // :213
   inline double getRotationEpsilon() { return rotation_epsilon_; }                 // :219
@@ -118,6 +129,9 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
     gicp_set_transformation_epsilon(handle_, transformation_epsilon_);
     gicp_set_maximum_iterations(handle_, max_iterations_);
     gicp_set_max_correspondence_distance(handle_, corr_dist_threshold_);
+    // caller-supplied covariances (:386,392: the class computes its own only while these are missing or empty)
+    push_covariances(target_covariances_, false);
+    push_covariances(input_covariances_, true);
     int conv = 0, iters = 0;
     float final_T[16];
     std::vector<float> moved(input_->points.size() * 4);
@@ -136,11 +150,21 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
   int k_correspondences_;
   double rotation_epsilon_;
   int max_inner_iterations_;
+  MatricesVectorPtr input_covariances_, target_covariances_;
 
  private:
   static int default_device() {
     const char* v = std::getenv("NDT_MI355_DEVICE");
     return v ? std::atoi(v) : 0;
+  }
+  void push_covariances(const MatricesVectorPtr& c, bool source) {
+    if (!c || c->empty()) return;
+    std::vector<double> flat(c->size() * 9);
+    for (size_t i = 0; i < c->size(); i++)
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) flat[i * 9 + r * 3 + k] = (*c)[i](r, k);
+    check(source ? gicp_set_source_covariances(handle_, flat.data(), c->size()) : gicp_set_target_covariances(handle_, flat.data(), c->size()),
+          source ? "gicp_set_source_covariances" : "gicp_set_target_covariances");
   }
   static void check(ndt_status s, const char* what) {
     // the reference's only error channels are PCL_ERROR and hasConverged(); a missing GPU or an invalid

@@ -50,6 +50,14 @@ void gicp_oracle_set_source(void* h, const float* pts, size_t n, size_t stride_f
   static_cast<Session*>(h)->g.set_source(pts_of(pts, n, stride_floats));
 }
 
+// setTargetCovariances / setSourceCovariances (gicp_omp.h:165-168,186-189): caller-supplied [n][9] row-major matrices replace the
+// lazily computed ones until the cloud is set again (which == 0 target, 1 source; n == 0 clears them)
+void gicp_oracle_set_covariances(void* h, int which, const double* cov, size_t n) {
+  std::vector<M3>& dst = which == 0 ? static_cast<Session*>(h)->g.target_cov : static_cast<Session*>(h)->g.source_cov;
+  dst.resize(n);
+  if (n) std::memcpy(dst.data(), cov, n * sizeof(M3));
+}
+
 // covariances of a cloud: out [n][9] row-major; returns 0 when k exceeds the cloud
 int gicp_oracle_covariances(const float* pts, size_t n, size_t stride_floats, int k, double eps, double* out) {
   std::vector<M3> cov;

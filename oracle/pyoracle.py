@@ -64,6 +64,7 @@ def lib():
         L.gicp_oracle_set_target.argtypes = [vp, fp, C.c_size_t, C.c_size_t]
         L.gicp_oracle_set_source.argtypes = [vp, fp, C.c_size_t, C.c_size_t]
         L.gicp_oracle_covariances.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, dp]
+        L.gicp_oracle_set_covariances.argtypes = [vp, C.c_int, dp, C.c_size_t]
         L.gicp_oracle_knn.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_int, ip, fp]
         L.gicp_oracle_align.argtypes = [vp, fp, fp, ip, ip, fp]
         L.gicp_oracle_prepare.argtypes = [vp, fp]
@@ -273,6 +274,16 @@ class OracleGICP:
         pts = _xyz(pts)
         self.ns = pts.shape[0]
         self._L.gicp_oracle_set_source(self._h, _f(pts), pts.shape[0], pts.shape[1])
+
+    def setTargetCovariances(self, cov):
+        """gicp_omp.h:186-189; cov: (n, 3, 3), None clears (they are computed again at the next align)."""
+        c = np.zeros((0, 3, 3)) if cov is None else np.ascontiguousarray(cov, dtype=np.float64)
+        self._L.gicp_oracle_set_covariances(self._h, 0, _d(c), len(c))
+
+    def setSourceCovariances(self, cov):
+        """gicp_omp.h:165-168."""
+        c = np.zeros((0, 3, 3)) if cov is None else np.ascontiguousarray(cov, dtype=np.float64)
+        self._L.gicp_oracle_set_covariances(self._h, 1, _d(c), len(c))
 
     def align(self, guess=None, want_cloud=False):
         g = None if guess is None else np.asfortranarray(guess, dtype=np.float32)

@@ -90,5 +90,22 @@ int main(int argc, char** argv) {
   print("gicp_app", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
   std::printf("gicp_aligned0 %.9g %.9g %.9g %.9g\n", aligned3->points[0].x, aligned3->points[0].y, aligned3->points[0].z, aligned3->points[0].pad);
   std::printf("gicp_fitness %.12g\n", gicp_omp->getFitnessScore());
+  // gicp_omp.h:165-168,186-189 -- caller-supplied covariances (isotropic 0.01 I on both clouds), used until the clouds are set again
+  {
+    GICP::MatricesVectorPtr cs(new GICP::MatricesVector(source->points.size())), ct(new GICP::MatricesVector(target->points.size()));
+    for (auto* v : {cs.get(), ct.get()})
+      for (auto& m : *v) {
+        for (int i = 0; i < 9; i++) m(i) = 0.0;
+        m(0, 0) = m(1, 1) = m(2, 2) = 0.01;
+      }
+    gicp_omp->setSourceCovariances(cs);
+    gicp_omp->setTargetCovariances(ct);
+    pcl::PointCloud<PointT>::Ptr aligned4(new pcl::PointCloud<PointT>());
+    reg2->align(*aligned4);
+    print("gicp_user_cov", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
+    reg2->setInputSource(source);  // resets the source's covariances: k-NN ones again, the target keeps the supplied ones
+    reg2->align(*aligned4);
+    print("gicp_mixed_cov", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
+  }
   return 0;
 }

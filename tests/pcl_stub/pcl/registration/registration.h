@@ -38,6 +38,9 @@ struct Matrix {
   bool operator!=(const Matrix& o) const { return std::memcmp(v, o.v, sizeof(v)) != 0; }
 };
 typedef Matrix<float, 4, 4> Matrix4f;
+typedef Matrix<double, 3, 3> Matrix3d;
+template <class T>
+using aligned_allocator = std::allocator<T>;
 struct Affine3f {
   Matrix4f m;
   Matrix4f& matrix() { return m; }

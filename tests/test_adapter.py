@@ -100,6 +100,21 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     moved = po.transform_cloud(np.c_[s, np.ones(len(s), np.float32)].astype(np.float32), Tg.astype(np.float32))[:, :3]
     d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
     assert float(rows["gicp_fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-4)
+    # setSourceCovariances / setTargetCovariances (gicp_omp.h:165-168,186-189): isotropic covariances on both clouds, then the
+    # source set again (its covariances come from its neighbours again, the target keeps the supplied ones)
+    iso_s, iso_t = np.tile(0.01 * np.eye(3), (len(s), 1, 1)), np.tile(0.01 * np.eye(3), (len(t), 1, 1))
+    og.setSourceCovariances(iso_s)
+    og.setTargetCovariances(iso_t)
+    ru = og.align()
+    conv, _, Tu = parse("gicp_user_cov")
+    assert conv == int(ru["converged"])
+    assert rot_err(Tu, ru["T"]) < 1e-4 and trans_err(Tu, ru["T"]) < 1e-3
+    assert trans_err(Tu, Tg) > 1e-4  # (a different objective: it must not end exactly where the k-NN covariances end)
+    og.setInputSource(s)
+    rm = og.align()
+    conv, _, Tm = parse("gicp_mixed_cov")
+    assert conv == int(rm["converged"])
+    assert rot_err(Tm, rm["T"]) < 1e-4 and trans_err(Tm, rm["T"]) < 1e-3
 
 
 @pytest.mark.gpu

@@ -157,6 +157,70 @@ def test_align_matches_oracle(gmod, scene, case):
     assert np.array_equal(cloud, po.transform_cloud(src4, T))
 
 
+def test_caller_supplied_covariances(gmod, scene):
+    """setSourceCovariances / setTargetCovariances (gicp_omp.h:165-168,186-189): supplied matrices replace the k-NN
+    covariances until the cloud is set again; the registration follows the oracle given the same matrices -- for random
+    symmetric positive definite covariances, for the class's own covariances passed back in (same result as computing
+    them), and after a reset (cloud set again / None).  A change of k between two aligns does not recompute covariances
+    that exist (computeTransformation only computes them while they are empty, gicp_omp_impl.hpp:386-397)."""
+    tgt, src = scene
+    rng = np.random.default_rng(5)
+
+    def spd(n):
+        a = rng.normal(0, 1, (n, 3, 3))
+        return (a @ a.transpose(0, 2, 1)) * 0.01 + 1e-3 * np.eye(3)
+
+    def same(g, o, guess=None):
+        ro = o.align(guess)
+        g.align(guess)
+        T = g.getFinalTransformation()
+        assert rot_err(T, ro["T"]) < ROT_TOL and trans_err(T, ro["T"]) < TRANS_TOL
+        assert g.hasConverged() == ro["converged"] and g.getFinalNumIteration() == ro["iterations"]
+        st = g.stats()
+        assert (st["n_f"], st["n_df"], st["n_fdf"]) == (ro["n_f"], ro["n_df"], ro["n_fdf"])
+        return T
+
+    g, o = both(gmod, tgt, src)
+    T_knn = same(g, o)
+    cs, ct = spd(len(src)), spd(len(tgt))
+    for x in (g, o):
+        x.setSourceCovariances(cs)
+        x.setTargetCovariances(ct)
+    T_user = same(g, o)
+    assert trans_err(T_user, T_knn) > 1e-5  # another objective
+    assert np.array_equal(g.covariances(1), cs) or np.abs(g.covariances(1) - cs).max() < 1e-15  # returned as supplied
+    with pytest.raises(RuntimeError):
+        g.setSourceCovariances(cs[:-1])  # one matrix per point
+    # the source set again: its covariances are the k-NN ones again, the target keeps the supplied ones
+    for x in (g, o):
+        x.setInputSource(src)
+    same(g, o)
+    # the class's own covariances passed back in: the registration of the k-NN covariances
+    g2, o2 = both(gmod, tgt, src)
+    own_s, own_t = g2.covariances(1), g2.covariances(0)
+    g2.setInputSource(src)
+    g2.setInputTarget(tgt)
+    g2.setSourceCovariances(own_s)
+    g2.setTargetCovariances(own_t)
+    g2.align()
+    assert np.array_equal(g2.getFinalTransformation(), T_knn)
+    # None clears; k changed between two aligns: existing covariances stay (reference semantics), new clouds use the new k
+    g2.setSourceCovariances(None)
+    g2.setTargetCovariances(None)
+    g2.align()
+    assert np.array_equal(g2.getFinalTransformation(), T_knn)
+    g2.setCorrespondenceRandomness(10)
+    o2.align()
+    o2_k10 = po.OracleGICP(k=10)
+    g2.align()
+    assert np.array_equal(g2.getFinalTransformation(), T_knn)  # covariances of k = 20 still in place
+    g2.setInputSource(src)
+    g2.setInputTarget(tgt)
+    o2_k10.setInputTarget(tgt)
+    o2_k10.setInputSource(src)
+    same(g2, o2_k10)
+
+
 def test_randomised_scenes_follow_the_oracle(gmod):
     """tools/fuzz_gicp.py, short and well-conditioned (structured scenes, default gate): random sizes, k, guesses and
     iteration caps -- identical neighbours and correspondences, the oracle's registration within tolerance."""

@@ -131,6 +131,8 @@ SIGNATURES = {
     "gicp_set_max_correspondence_distance": (C.c_int, [vp, C.c_double]),
     "gicp_set_input_target": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
     "gicp_set_input_source": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "gicp_set_source_covariances": (C.c_int, [vp, dp, C.c_size_t]),
+    "gicp_set_target_covariances": (C.c_int, [vp, dp, C.c_size_t]),
     "gicp_align": (C.c_int, [vp, fp, fp, ip, ip, vp]),
     "gicp_get_result": (C.c_int, [vp, fp, ip, ip]),
     "gicp_get_fitness_score": (C.c_int, [vp, C.c_double, dp]),

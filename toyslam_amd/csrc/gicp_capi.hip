@@ -18,6 +18,7 @@ struct gicp_context {
   gicp::Params prm;
   bool have_tgt = false, have_src = false;
   bool have_cov_tgt = false, have_cov_src = false;
+  bool user_cov_tgt = false, user_cov_src = false;  // supplied through gicp_set_*_covariances
   DevBuf<double> cov_tgt, cov_src;  // [n][6]
   DevBuf<float4> output;            // the source moved by the guess
   DevBuf<int> corr;
@@ -415,7 +416,8 @@ void gicp_destroy(gicp_handle h) {
 
 ndt_status gicp_set_correspondence_randomness(gicp_handle h, int k) {
   if (!h || k < 1 || k > gicp::kMaxK) return fail(NDT_ERR_INVALID, "k_correspondences must be in [1, 64]");
-  if (k != h->prm.k_correspondences) h->have_cov_tgt = h->have_cov_src = false;
+  // (covariances already computed stay, as in the reference: computeTransformation only computes them while they are
+  // empty, gicp_omp_impl.hpp:386-397, and only setInputSource / setInputTarget reset them)
   h->prm.k_correspondences = k;
   return NDT_OK;
 }
@@ -448,7 +450,7 @@ ndt_status gicp_set_max_correspondence_distance(gicp_handle h, double d) {
 ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_t stride_bytes) {
   if (!h) return fail(NDT_ERR_INVALID, "null");
   h->have_tgt = false;
-  h->have_cov_tgt = false;  // target_covariances_.reset()
+  h->have_cov_tgt = h->user_cov_tgt = false;  // target_covariances_.reset()
   h->step_ready = false;
   if (h->tgt.device_ready) {  // kernels of an earlier align may still read the old index
     HIP_TRY(hipSetDevice(h->tgt.device));
@@ -463,7 +465,7 @@ ndt_status gicp_set_input_target(gicp_handle h, const void* pts, size_t n, size_
 ndt_status gicp_set_input_source(gicp_handle h, const void* pts, size_t n, size_t stride_bytes) {
   if (!h) return fail(NDT_ERR_INVALID, "null");
   h->have_src = false;
-  h->have_cov_src = false;  // input_covariances_.reset()
+  h->have_cov_src = h->user_cov_src = false;  // input_covariances_.reset()
   h->step_ready = false;
   if (h->tgt.device_ready) {
     HIP_TRY(hipSetDevice(h->tgt.device));
@@ -539,11 +541,50 @@ ndt_status gicp_get_stats(gicp_handle h, int* n_f, int* n_df, int* n_fdf, int* c
   return NDT_OK;
 }
 
+// setTargetCovariances / setSourceCovariances (gicp_omp.h:165-168,186-189): caller-supplied covariances take the place of
+// the k-NN ones until the cloud is set again.  cov: [n][9] row-major 3x3 (symmetric: the upper triangle is kept).
+static ndt_status gicp_set_covariances(gicp_handle h, int which, const double* cov, size_t n) {
+  if (!h) return fail(NDT_ERR_INVALID, "null");
+  if (!(which == 0 ? h->have_tgt : h->have_src)) return fail(NDT_ERR_NO_INPUT, "set the cloud before its covariances");
+  bool& have = which == 0 ? h->have_cov_tgt : h->have_cov_src;
+  bool& user = which == 0 ? h->user_cov_tgt : h->user_cov_src;
+  if (!cov || n == 0) {  // an empty vector: computed again by the next align (:386,392)
+    have = user = false;
+    return NDT_OK;
+  }
+  ndt_context* c = which == 0 ? &h->tgt : &h->src;
+  if (n != c->target->n) return fail(NDT_ERR_INVALID, "one covariance per point of the cloud is required");
+  ndt_status s = ensure_device(&h->tgt);
+  if (s) return s;
+  std::vector<double> c6(n * 6);
+  for (size_t i = 0; i < n; i++) {
+    const double* m = cov + i * 9;
+    double* o = &c6[i * 6];
+    o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[4]; o[4] = m[5]; o[5] = m[8];
+  }
+  DevBuf<double>& dst = which == 0 ? h->cov_tgt : h->cov_src;
+  HIP_TRY(dst.reserve(n * 6));
+  HIP_TRY(hipStreamSynchronize(h->tgt.stream));  // kernels of an earlier align may still read the old covariances
+  HIP_TRY(hipMemcpy(dst.p, c6.data(), n * 6 * sizeof(double), hipMemcpyHostToDevice));
+  have = user = true;
+  h->step_ready = false;
+  return NDT_OK;
+}
+ndt_status gicp_set_target_covariances(gicp_handle h, const double* cov, size_t n) { return gicp_set_covariances(h, 0, cov, n); }
+ndt_status gicp_set_source_covariances(gicp_handle h, const double* cov, size_t n) { return gicp_set_covariances(h, 1, cov, n); }
+
 ndt_status gicp_covariances(gicp_handle h, int which, double* cov, int* nn_idx, float* nn_d2) {
   if (!h || !cov || which < 0 || which > 1) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!(which == 0 ? h->have_tgt : h->have_src)) return fail(NDT_ERR_NO_INPUT, "cloud not set");
   ndt_status s = ensure_device(&h->tgt);
   if (s) return s;
+  // inspection: the k-NN covariances for the CURRENT k (caller-supplied ones are returned as they are; neighbours cannot
+  // be asked for then)
+  if (which == 0 ? h->user_cov_tgt : h->user_cov_src) {
+    if (nn_idx || nn_d2) return fail(NDT_ERR_INVALID, "caller-supplied covariances have no neighbour lists");
+  } else {
+    (which == 0 ? h->have_cov_tgt : h->have_cov_src) = false;
+  }
   const bool want_nn = nn_idx && nn_d2;
   s = gicp_cloud_covariances(h, which, want_nn);
   if (s) return s;

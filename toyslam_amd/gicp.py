@@ -59,6 +59,16 @@ class GeneralizedIterativeClosestPoint:
         check(self._L.gicp_set_input_source(self._h, c.ctypes.data, c.shape[0], c.strides[0]))
         self._n[1] = c.shape[0]
 
+    def setSourceCovariances(self, cov):
+        """gicp_omp.h:165-168.  cov: (n, 3, 3) symmetric matrices, one per source point; None clears them."""
+        c = None if cov is None else np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9)
+        check(self._L.gicp_set_source_covariances(self._h, None if c is None else _d(c), 0 if c is None else len(c)))
+
+    def setTargetCovariances(self, cov):
+        """gicp_omp.h:186-189."""
+        c = None if cov is None else np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 9)
+        check(self._L.gicp_set_target_covariances(self._h, None if c is None else _d(c), 0 if c is None else len(c)))
+
     def align(self, guess=None, want_cloud=False):
         g = None if guess is None else _colmajor(guess)
         T = np.zeros(16, dtype=np.float32)
