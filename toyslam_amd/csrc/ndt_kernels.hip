@@ -1,31 +1,17 @@
-// ndt_kernels.hip -- hand-written HIP kernels of the MI355X NDT core (gfx950, wave64): the grid build
-// and the throughput side of the evaluation.  (The single-scan latency path -- one-launch evaluation and
-// the persistent evaluation server -- lives in ndt_latency.hip; both units share ndt_device.hpp.)
+// ndt_kernels.hip -- hand-written HIP kernels of the MI355X NDT core (gfx950, wave64): the throughput side of the
+// evaluation.  (K1, everything that builds voxel structures, is ndt_grid_kernels.hip / ndt_sparse.hip; the single-scan
+// latency path -- one-launch evaluation and the persistent evaluation server -- is ndt_latency.hip; all share ndt_device.hpp.)
 //
-//  K1  target voxel grid  (VoxelGridCovariance::applyFilter,
-//      voxel_grid_covariance_omp_impl.hpp:48-370):
-//        bbox -> per-cell count (int atomics on the dense cell array)
-//             -> 3-phase exclusive scan over cells (leaf ordinals, segment
-//                offsets, record ordinals, LUT init)
-//             -> counting-sort scatter of point indices
-//             -> per-leaf finalize: index-ordered f64 sums (bit-identical to
-//                the reference's sequential accumulation), mean, covariance
-//                with the reference's quirks, 3x3 symmetric eigen-solve,
-//                eigenvalue inflation, inverse, validity -> 64-B VoxelRec.
-//      The same count / scan / scatter machinery serves the scan prefilter (N1, k_voxel_centroids),
-//      the global-map update (N2) and the spatial ordering of source scans (k_sort_gather).
-//  K2  per-evaluation score / gradient / Hessian (computeDerivatives,
-//      ndt_omp_impl.hpp:179-285 with updateDerivatives :484-537 fused with the
-//      f32 point transform): k_derivatives (one launch per evaluation, also over
-//      a whole lock-step batch), k_batch_step (mixed-kind batch steps), the all-f64
-//      Hessian k_hessian64 (computeHessian :540-645), k_reduce (fixed-order sum of
-//      the per-block rows), calculateScore (:935-983), getFitnessScore (k_fitness).
+//  K2  per-evaluation score / gradient / Hessian (computeDerivatives, ndt_omp_impl.hpp:179-285 with updateDerivatives
+//      :484-537 fused with the f32 point transform): k_derivatives (one launch per evaluation, also over a whole lock-step
+//      batch), k_batch_step (mixed-kind batch steps), the all-f64 Hessian k_hessian64 (computeHessian :540-645), k_reduce
+//      (fixed-order sum of the per-block rows), calculateScore (:935-983), getFitnessScore (k_fitness) and the search index
+//      it walks (k_cell_ranges, k_gather_points).
 //
-// Gather work: no MFMA (there is no dense contraction).  Loads are 16 B per lane
-// (float4 points, 3 x dwordx4 per 64-B voxel record), the LUT probe + record gather
-// is served from L2 / Infinity Cache for the target sizes of interest, and the 29 f64
-// accumulators are reduced with a VALU-only wave64 fold, then LDS across the waves of
-// a block, then a fixed-order sum over the blocks.
+// Gather work: no MFMA (there is no dense contraction).  Loads are 16 B per lane (float4 points, 3 x dwordx4 per 64-B
+// voxel record), the LUT probe + record gather is served from L2 / Infinity Cache for the target sizes of interest, and the
+// 29 f64 accumulators are reduced with a VALU-only wave64 fold, then LDS across the waves of a block, then a fixed-order
+// sum over the blocks.
 #include "ndt_device.hpp"
 #include "ndt_search.hpp"
 
@@ -43,1262 +29,6 @@ __global__ __launch_bounds__(kBlock) void k_selftest_reduce(double* __restrict__
   block_reduce_store<kNumAcc>(acc, out + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
 }
 
-
-// ---------------------------------------------------------------------------
-// repack: arbitrary-stride xyz records -> dense float4 (x,y,z,1)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_repack(const unsigned char* __restrict__ src, size_t n, size_t stride,
-                                                   float4* __restrict__ dst) {
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const float* p = reinterpret_cast<const float*>(src + i * stride);
-    dst[i] = make_float4(p[0], p[1], p[2], 1.0f);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K1.a  bounding box  ([PCL] getMinMax3D, _impl.hpp:72)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bbox(const float4* __restrict__ pts, int n, int dense,
-                                                 float* __restrict__ block_minmax) {
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 p = pts[i];
-    if (!dense && !finite3(p.x, p.y, p.z)) continue;
-    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-  }
-  __shared__ float s[kBlock / kWave][6];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    float a = wave_min(mn[k]), b = wave_max(mx[k]);
-    if (lane == 0) { s[wave][k] = a; s[wave][3 + k] = b; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = s[0][threadIdx.x];
-    for (int w = 1; w < kBlock / kWave; w++) v = (threadIdx.x < 3) ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    block_minmax[blockIdx.x * 6 + threadIdx.x] = v;
-  }
-}
-
-// repack + both bounding boxes in one pass over the upload: block_minmax[block][12] =
-// {min xyz, max xyz} over the points that are not NaN (what getMinMax3D sees for an is_dense cloud) and
-// {min xyz, max xyz} over the finite points (the !is_dense rule).  The host reduces the per-block rows
-// behind the synchronisation the upload needs anyway, so no consumer launches k_bbox or waits again.
-__global__ __launch_bounds__(kBlock) void k_repack_bbox(const unsigned char* __restrict__ src, size_t n, size_t stride,
-                                                        float4* __restrict__ dst, float* __restrict__ block_minmax) {
-  float mn[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
-  float mx[6] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const float* p = reinterpret_cast<const float*>(src + i * stride);
-    const float x = p[0], y = p[1], z = p[2];
-    dst[i] = make_float4(x, y, z, 1.0f);
-    mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);  // fminf / fmaxf drop NaN operands
-    mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
-    mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
-    if (finite3(x, y, z)) {
-      mn[3] = fminf(mn[3], x); mx[3] = fmaxf(mx[3], x);
-      mn[4] = fminf(mn[4], y); mx[4] = fmaxf(mx[4], y);
-      mn[5] = fminf(mn[5], z); mx[5] = fmaxf(mx[5], z);
-    }
-  }
-  __shared__ float s[kBlock / kWave][12];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float a = wave_min(mn[k]), b = wave_max(mx[k]);
-    const int base = (k < 3) ? 0 : 6, c = k % 3;
-    if (lane == 0) { s[wave][base + c] = a; s[wave][base + 3 + c] = b; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 12) {
-    const bool is_min = (threadIdx.x % 6) < 3;
-    float v = s[0][threadIdx.x];
-    for (int w = 1; w < kBlock / kWave; w++) v = is_min ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    block_minmax[blockIdx.x * 12 + threadIdx.x] = v;
-  }
-}
-
-// linear voxel index of a target point while BUILDING the grid:
-// floor(x * inv_leaf) - float(min_b), _impl.hpp:218-223 (f32, trap 2)
-__device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, float z) {
-  // plain operators under contract(off): the product must be rounded to f32 before floor()
-#pragma clang fp contract(off)
-  const float fx = x * g.inv_leaf[0], fy = y * g.inv_leaf[1], fz = z * g.inv_leaf[2];
-  const int i0 = static_cast<int>(floorf(fx) - static_cast<float>(g.min_b[0]));
-  const int i1 = static_cast<int>(floorf(fy) - static_cast<float>(g.min_b[1]));
-  const int i2 = static_cast<int>(floorf(fz) - static_cast<float>(g.min_b[2]));
-  return i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2];
-}
-
-// ---------------------------------------------------------------------------
-// K1.b  per-cell point count
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_count(const float4* __restrict__ pts, int n, int dense, GridGeom g,
-                                                  int* __restrict__ key, unsigned* __restrict__ rank,
-                                                  unsigned* __restrict__ cell_count) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 p = pts[i];
-    int c = -1;
-    if (dense || finite3(p.x, p.y, p.z)) {
-      c = build_cell(g, p.x, p.y, p.z);
-      // points are inside the bbox by construction; guard against NaN/garbage
-      if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;
-    }
-    key[i] = c;
-    // the returned count is the point's arrival rank inside its cell: the scatter needs no second
-    // round of atomics
-    if (c >= 0) rank[i] = atomicAdd(&cell_count[c], 1u);
-  }
-}
-
-// Batch variant for the source ordering of many scans at once: blockIdx.y = scan, composite key = the scan's base + its
-// cell on the scan's OWN lattice (ScanLattice), so one count / scan / scatter pass orders every scan inside its own
-// segment and a scan's order is a function of its own points only.
-__device__ __forceinline__ int enc_f32(float f) {  // order-preserving: a < b  <=>  enc(a) < enc(b)  (finite values)
-  const int b = __float_as_int(f);
-  return b ^ ((b >> 31) & 0x7fffffff);
-}
-__global__ __launch_bounds__(kBlock) void k_scan_bboxes(const float4* __restrict__ pts, const int* __restrict__ scan_off, int* __restrict__ out) {
-  const int lo = scan_off[blockIdx.y], hi = scan_off[blockIdx.y + 1];
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
-    const float4 p = pts[i];
-    if (!finite3(p.x, p.y, p.z)) continue;
-    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, kWave));
-      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, kWave));
-    }
-  }
-  if ((threadIdx.x & (kWave - 1)) == 0 && mn[0] <= mx[0]) {
-    int* o = out + 6 * blockIdx.y;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      atomicMin(o + k, enc_f32(mn[k]));
-      atomicMax(o + 3 + k, enc_f32(mx[k]));
-    }
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_count_batch(const float4* __restrict__ pts, const int* __restrict__ scan_off,
-                                                        const ScanLattice* __restrict__ lat, int* __restrict__ key,
-                                                        unsigned* __restrict__ rank, unsigned* __restrict__ cell_count) {
-#pragma clang fp contract(off)
-  const int lo = scan_off[blockIdx.y], hi = scan_off[blockIdx.y + 1];
-  const ScanLattice L = lat[blockIdx.y];
-  for (int i = lo + blockIdx.x * kBlock + threadIdx.x; i < hi; i += gridDim.x * kBlock) {
-    const float4 p = pts[i];
-    int c = -1;
-    if (L.n_cells > 0 && finite3(p.x, p.y, p.z)) {
-      const int i0 = static_cast<int>(floorf(p.x * L.inv_leaf)) - L.min_b[0];
-      const int i1 = static_cast<int>(floorf(p.y * L.inv_leaf)) - L.min_b[1];
-      const int i2 = static_cast<int>(floorf(p.z * L.inv_leaf)) - L.min_b[2];
-      const int cell = i0 + i1 * L.mul1 + i2 * L.mul2;
-      if (i0 >= 0 && i1 >= 0 && i2 >= 0 && cell >= 0 && cell < L.n_cells) c = static_cast<int>(L.base + cell);
-    }
-    key[i] = c;
-    if (c >= 0) rank[i] = atomicAdd(&cell_count[c], 1u);
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_pick(const unsigned* __restrict__ cell_count, const long long* __restrict__ bases,
-                                                 unsigned* __restrict__ out, int n) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) out[i] = cell_count[bases[i]];
-}
-
-// ---------------------------------------------------------------------------
-// K1.c  exclusive scan over cells of {points, occupied, candidate} counters
-// ---------------------------------------------------------------------------
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kBlock * kScanItems;  // 2048 cells per block
-
-struct U3 {
-  unsigned pts, occ, cand;
-};
-__device__ __forceinline__ U3 operator+(const U3& a, const U3& b) { return {a.pts + b.pts, a.occ + b.occ, a.cand + b.cand}; }
-
-// exclusive block scan of one U3 per thread; returns the exclusive prefix and the block total
-__device__ __forceinline__ U3 block_exclusive_scan(U3 v, U3& total, U3* lds /*[kBlock/kWave]*/) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  U3 inc = v;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    unsigned a = __shfl_up(inc.pts, off, kWave), b = __shfl_up(inc.occ, off, kWave), c = __shfl_up(inc.cand, off, kWave);
-    if (lane >= off) { inc.pts += a; inc.occ += b; inc.cand += c; }
-  }
-  if (lane == kWave - 1) lds[wave] = inc;
-  __syncthreads();
-  U3 wave_off = {0, 0, 0};
-  U3 tot = {0, 0, 0};
-#pragma unroll
-  for (int w = 0; w < kBlock / kWave; w++) {
-    if (w < wave) wave_off = wave_off + lds[w];
-    tot = tot + lds[w];
-  }
-  __syncthreads();
-  total = tot;
-  return {wave_off.pts + inc.pts - v.pts, wave_off.occ + inc.occ - v.occ, wave_off.cand + inc.cand - v.cand};
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(const unsigned* __restrict__ cell_count, long long n_cells,
-                                                        unsigned min_pts, unsigned* __restrict__ block_sums) {
-  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
-  U3 t = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < kScanItems; k++) {
-    const long long c = base + k;
-    if (c < n_cells) {
-      const unsigned v = cell_count[c];
-      t.pts += v;
-      t.occ += (v > 0);
-      t.cand += (v >= min_pts);
-    }
-  }
-  __shared__ U3 lds[kBlock / kWave];
-  U3 total;
-  block_exclusive_scan(t, total, lds);
-  if (threadIdx.x == 0) {
-    block_sums[blockIdx.x * 3 + 0] = total.pts;
-    block_sums[blockIdx.x * 3 + 1] = total.occ;
-    block_sums[blockIdx.x * 3 + 2] = total.cand;
-  }
-}
-
-// single block: in-place exclusive scan of the per-tile sums; totals[3] out
-__global__ __launch_bounds__(kBlock) void k_scan_blocks(unsigned* __restrict__ block_sums, int n_tiles,
-                                                        unsigned* __restrict__ totals) {
-  __shared__ U3 lds[kBlock / kWave];
-  U3 carry = {0, 0, 0};
-  for (int base = 0; base < n_tiles; base += kBlock) {
-    const int i = base + threadIdx.x;
-    U3 v = {0, 0, 0};
-    if (i < n_tiles) v = {block_sums[i * 3 + 0], block_sums[i * 3 + 1], block_sums[i * 3 + 2]};
-    U3 total;
-    U3 ex = block_exclusive_scan(v, total, lds);
-    if (i < n_tiles) {
-      block_sums[i * 3 + 0] = carry.pts + ex.pts;
-      block_sums[i * 3 + 1] = carry.occ + ex.occ;
-      block_sums[i * 3 + 2] = carry.cand + ex.cand;
-    }
-    carry = carry + total;
-  }
-  if (threadIdx.x == 0) {
-    totals[0] = carry.pts;
-    totals[1] = carry.occ;
-    totals[2] = carry.cand;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_apply(unsigned* __restrict__ cell_count /* -> cursor */,
-                                                       long long n_cells, unsigned min_pts,
-                                                       const unsigned* __restrict__ block_sums,
-                                                       int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
-                                                       int* __restrict__ leaf_count, int* __restrict__ leaf_rec) {
-  const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
-  unsigned cnt[kScanItems];
-  U3 t = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < kScanItems; k++) {
-    const long long c = base + k;
-    cnt[k] = (c < n_cells) ? cell_count[c] : 0u;
-    t.pts += cnt[k];
-    t.occ += (cnt[k] > 0);
-    t.cand += (cnt[k] >= min_pts);
-  }
-  __shared__ U3 lds[kBlock / kWave];
-  U3 total;
-  U3 ex = block_exclusive_scan(t, total, lds);
-  U3 run = {block_sums[blockIdx.x * 3 + 0] + ex.pts, block_sums[blockIdx.x * 3 + 1] + ex.occ,
-            block_sums[blockIdx.x * 3 + 2] + ex.cand};
-#pragma unroll
-  for (int k = 0; k < kScanItems; k++) {
-    const long long c = base + k;
-    if (c < n_cells) {
-      cell_count[c] = run.pts;  // scatter cursor
-      if (cnt[k] > 0) {
-        leaf_cell[run.occ] = static_cast<int>(c);
-        leaf_start[run.occ] = run.pts;
-        leaf_count[run.occ] = static_cast<int>(cnt[k]);
-        leaf_rec[run.occ] = (cnt[k] >= min_pts) ? static_cast<int>(run.cand) : -1;
-      }
-      run.pts += cnt[k];
-      run.occ += (cnt[k] > 0);
-      run.cand += (cnt[k] >= min_pts);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K1.d  counting-sort scatter of point indices into per-cell segments
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_scatter(const int* __restrict__ key, const unsigned* __restrict__ rank, int n,
-                                                    const unsigned* __restrict__ cell_start, int* __restrict__ sorted_idx) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const int c = key[i];
-    if (c >= 0) sorted_idx[cell_start[c] + rank[i]] = i;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K1.e  per-leaf finalize (second pass of applyFilter, _impl.hpp:282-367)
-// ---------------------------------------------------------------------------
-struct Sym3 {
-  double xx, xy, xz, yy, yz, zz;
-};
-
-constexpr int kSortLimit = 64;      // up to here: insertion sort
-constexpr int kSortGiveUp = 65536;  // beyond: left in arrival order (one thread would stall for too long)
-
-// in-place ascending sort of a small index segment by ONE thread
-__device__ __forceinline__ void sort_segment(int* seg, int cnt) {
-  if (cnt <= kSortLimit) {
-    for (int i = 1; i < cnt; i++) {
-      const int v = seg[i];
-      int j = i - 1;
-      while (j >= 0 && seg[j] > v) { seg[j + 1] = seg[j]; j--; }
-      seg[j + 1] = v;
-    }
-  } else if (cnt <= kSortGiveUp) {  // heap sort
-    auto sift = [&](int root, int end) {
-      for (;;) {
-        int child = 2 * root + 1;
-        if (child > end) break;
-        if (child + 1 <= end && seg[child] < seg[child + 1]) child++;
-        if (seg[root] < seg[child]) { const int t = seg[root]; seg[root] = seg[child]; seg[child] = t; root = child; }
-        else break;
-      }
-    };
-    for (int s0 = (cnt - 2) / 2; s0 >= 0; s0--) sift(s0, cnt - 1);
-    for (int end = cnt - 1; end > 0; end--) {
-      const int t = seg[0]; seg[0] = seg[end]; seg[end] = t;
-      sift(0, end - 1);
-    }
-  }
-}
-
-// Leaves with more points than the register path of k_finalize takes (real scans: a 1 m voxel of a 0.1 m-filtered
-// cloud holds hundreds): one WAVE per leaf restores ascending point order -- rank sort in LDS, every lane places its
-// elements by counting the smaller ones -- and gathers the points into `big_pts` in that order, so that k_finalize's
-// strictly sequential f64 sums read contiguous memory with many loads in flight instead of sorting the segment in
-// global memory with one thread and chasing index -> point per addition (measured on the reference pair: 583 us per
-// target build, almost all of it in that one-thread path).
-constexpr int kPresortMin = 16;    // <= this many points: k_finalize's register path
-constexpr int kPresortLds = 8192;  // segments up to here are sorted in LDS; longer ones by lane 0 (heap sort) as before
-constexpr int kPresortRank = 256;  // up to here: rank sort (one element per thread, n comparisons each); above: bitonic network
-__global__ __launch_bounds__(kBlock) void k_presort_large(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                         const int* __restrict__ leaf_count, int n_leaves_host,
-                                                         const unsigned* __restrict__ d_totals, int* __restrict__ sorted_idx,
-                                                         float4* __restrict__ big_pts, int chunk) {
-  __shared__ int s_idx[kPresortLds];
-  __shared__ int s_cnt[kWave];
-  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;
-  const int tid = threadIdx.x;
-  // `chunk` (1..64, the launcher picks it so that the grid stays within 8192 blocks) leaves are looked at per step (one
-  // load of their counts); the crowded ones among them are taken one after the other by the whole block -- few leaves:
-  // about one crowded leaf per block; many leaves without crowded ones: a short pass over leaf_count
-  for (int base = blockIdx.x * chunk; base < n_leaves; base += gridDim.x * chunk) {
-    __syncthreads();  // s_cnt / s_idx of the previous step are done with
-    if (tid < chunk) s_cnt[tid] = (base + tid < n_leaves) ? leaf_count[base + tid] : 0;
-    __syncthreads();
-    for (int pick = 0; pick < chunk; pick++) {
-      const int cnt = s_cnt[pick];  // uniform across the block
-      if (cnt <= kPresortMin) continue;
-      const int leaf = base + pick;
-      const unsigned start = leaf_start[leaf];
-      int* seg = sorted_idx + start;
-      if (cnt <= kPresortRank) {
-        for (int i = tid; i < cnt; i += kBlock) s_idx[i] = seg[i];
-        __syncthreads();
-        for (int i = tid; i < cnt; i += kBlock) {
-          const int v = s_idx[i];
-          int rank = 0;
-          for (int j = 0; j < cnt; j++) rank += (s_idx[j] < v) ? 1 : 0;  // point indices are unique
-          seg[rank] = v;
-          big_pts[start + rank] = pts[v];
-        }
-        __syncthreads();  // s_idx is reused by the next leaf
-      } else if (cnt <= kPresortLds) {
-        int m = 1;
-        while (m < cnt) m <<= 1;  // padded with INT_MAX to a power of two
-        for (int i = tid; i < m; i += kBlock) s_idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
-        __syncthreads();
-        for (int span = 2; span <= m; span <<= 1)
-          for (int j = span >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m; i += kBlock) {
-              const int partner = i ^ j;
-              if (partner > i) {
-                const int a = s_idx[i], b = s_idx[partner];
-                const bool ascending = (i & span) == 0;
-                if ((a > b) == ascending) {
-                  s_idx[i] = b;
-                  s_idx[partner] = a;
-                }
-              }
-            }
-            __syncthreads();
-          }
-        for (int i = tid; i < cnt; i += kBlock) {
-          const int v = s_idx[i];
-          seg[i] = v;
-          big_pts[start + i] = pts[v];
-        }
-        __syncthreads();
-      } else {
-        if (tid == 0) sort_segment(seg, cnt);
-        __threadfence();
-        __syncthreads();
-        for (int i = tid; i < cnt; i += kBlock) big_pts[start + i] = pts[__hip_atomic_load(seg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
-      }
-    }
-  }
-}
-
-// Source ordering: after the counting sort by lattice cell, sort each cell's indices (stable,
-// hence deterministic) and gather the points, so that consecutive lanes of K2 touch the same or
-// adjacent target voxels (coalesced LUT probes and record gathers).
-__global__ __launch_bounds__(kBlock) void k_sort_gather(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                        const int* __restrict__ leaf_count, int n_leaves_host, const unsigned* __restrict__ d_totals,
-                                                        int* __restrict__ sorted_idx, float4* __restrict__ out) {
-  const int o = blockIdx.x * kBlock + threadIdx.x;
-  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
-  if (o >= n_leaves) return;
-  const unsigned start = leaf_start[o];
-  const int cnt = leaf_count[o];
-  if (cnt > kPresortMin) return;  // crowded cells: k_presort_large has sorted and gathered them straight into `out`
-  int* seg = sorted_idx + start;
-  sort_segment(seg, cnt);
-  for (int i = 0; i < cnt; i++) out[start + i] = pts[seg[i]];
-}
-
-// ---------------------------------------------------------------------------
-// N1  centroid voxel down-sample -- [PCL] pcl::VoxelGrid<PointT>::applyFilter, the prefilter every
-// caller runs before NDT (ndt_omp/apps/align.cpp:60-69, ndt_omp_mapping_node.cpp:142-148,203-210).
-// Same count / scan / scatter machinery as K1; one thread per occupied voxel sums its points in
-// f32 (CentroidPoint / AccumulatorXYZ) in ascending point order and divides by the count.  Leaves
-// are enumerated in cell order, so the output is in ascending voxel-index order like PCL's.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_voxel_centroids(const float4* __restrict__ pts, const unsigned* __restrict__ leaf_start,
-                                                            const int* __restrict__ leaf_count, int n_leaves_host, const unsigned* __restrict__ d_totals,
-                                                            int* __restrict__ sorted_idx, float4* __restrict__ out,
-                                                            const float4* __restrict__ big_pts) {
-  const int o = blockIdx.x * kBlock + threadIdx.x;
-  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
-  if (o >= n_leaves) return;
-  const unsigned start = leaf_start[o];
-  const int cnt = leaf_count[o];
-  int* seg = sorted_idx + start;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  int i = 0;
-  if (big_pts && cnt > kPresortMin) {  // crowded voxel: sorted and laid out in order by k_presort_large
-    const float4* bp = big_pts + start;
-    for (; i + 8 <= cnt; i += 8) {
-      const float4 p0 = bp[i], p1 = bp[i + 1], p2 = bp[i + 2], p3 = bp[i + 3], p4 = bp[i + 4], p5 = bp[i + 5], p6 = bp[i + 6], p7 = bp[i + 7];
-      sx += p0.x; sy += p0.y; sz += p0.z;
-      sx += p1.x; sy += p1.y; sz += p1.z;
-      sx += p2.x; sy += p2.y; sz += p2.z;
-      sx += p3.x; sy += p3.y; sz += p3.z;
-      sx += p4.x; sy += p4.y; sz += p4.z;
-      sx += p5.x; sy += p5.y; sz += p5.z;
-      sx += p6.x; sy += p6.y; sz += p6.z;
-      sx += p7.x; sy += p7.y; sz += p7.z;
-    }
-    for (; i < cnt; i++) {
-      const float4 p = bp[i];
-      sx += p.x; sy += p.y; sz += p.z;
-    }
-  } else {
-    sort_segment(seg, cnt);
-  }
-  for (; i + 4 <= cnt; i += 4) {
-    const float4 p0 = pts[seg[i]], p1 = pts[seg[i + 1]], p2 = pts[seg[i + 2]], p3 = pts[seg[i + 3]];
-    sx += p0.x; sy += p0.y; sz += p0.z;
-    sx += p1.x; sy += p1.y; sz += p1.z;
-    sx += p2.x; sy += p2.y; sz += p2.z;
-    sx += p3.x; sy += p3.y; sz += p3.z;
-  }
-  for (; i < cnt; i++) {
-    const float4 p = pts[seg[i]];
-    sx += p.x; sy += p.y; sz += p.z;
-  }
-  const float nf = static_cast<float>(cnt);
-  out[o] = make_float4(sx / nf, sy / nf, sz / nf, 1.0f);
-}
-
-// First-pass sums of one voxel (applyFilter's first loop, _impl.hpp:209-263): mean_ += pt ; cov_ += pt*pt^T with cov_
-// seeded Identity (.h:107); centroid.head<4>() += pt in f32 (:240-244).  Points must be added in ascending point
-// order: the f64 sums then round exactly like the reference's sequential pass.
-struct VoxelSums {
-  double sx = 0, sy = 0, sz = 0;
-  double cxx = 1, cxy = 0, cxz = 0, cyy = 1, cyz = 0, czz = 1;
-  float fx = 0, fy = 0, fz = 0;
-  __device__ __forceinline__ void add(float px, float py, float pz) {
-#pragma clang fp contract(off)
-    const double x = px, y = py, z = pz;
-    sx += x; sy += y; sz += z;
-    cxx += x * x; cxy += x * y; cxz += x * z; cyy += y * y; cyz += y * z; czz += z * z;
-    fx += px; fy += py; fz += pz;
-  }
-};
-
-// Second pass of applyFilter for one voxel (_impl.hpp:282-367): mean, covariance with the reference's quirks, 3x3
-// eigen-solve, eigenvalue inflation, inverse, validity; writes the 64-B record, the centroid, the look-up table slot
-// and (dump mode) the per-leaf outputs.  o: leaf ordinal, r: record ordinal (-1: fewer than min_pts points).
-// Returns whether the voxel is valid for the DIRECT searches.
-__device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o, int r, int cell, int min_pts, double eig_ratio,
-                                             VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
-                                             const GridGeom& geom, const FinalizeDump& dump) {
-  // No FMA contraction: the reference target (SSE4.2) never fuses, and its covariance formula (_impl.hpp:329-330)
-  // cancels catastrophically when the coordinates are large against the voxel size, so a single fused multiply-add
-  // shows up in the 7th digit of cov / icov.
-#pragma clang fp contract(off)
-  const double sx = S.sx, sy = S.sy, sz = S.sz;
-  const double cxx = S.cxx, cxy = S.cxy, cxz = S.cxz, cyy = S.cyy, cyz = S.cyz, czz = S.czz;
-  float fx = S.fx, fy = S.fy, fz = S.fz;
-  const double n = cnt;
-  const double ps[3] = {sx, sy, sz};
-  const double mean[3] = {sx / n, sy / n, sz / n};  // :293
-  fx /= static_cast<float>(cnt); fy /= static_cast<float>(cnt); fz /= static_cast<float>(cnt);  // :289
-
-  double cov[3][3] = {{cxx, cxy, cxz}, {cxy, cyy, cyz}, {cxz, cyz, czz}};
-  double icov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  double evals[3] = {0, 0, 0};
-  int nr_points = cnt;
-  bool is_valid = false;
-
-  if (cnt >= min_pts) {
-    // :329-330
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) cov[i][j] = (cov[i][j] - 2 * (ps[i] * mean[j])) / n + mean[i] * mean[j];
-    const double f = (n - 1.0) / n;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) cov[i][j] *= f;
-    double w[3] = {0, 0, 0}, V[3][3];
-    // The eigen-decomposition is needed only (a) to reject a voxel with a non-positive eigenvalue and (b) to inflate
-    // the small eigenvalues of a flat or thin one; a voxel that is PROVABLY positive definite with
-    // lambda_min >= eig_ratio lambda_max goes straight to the inverse of the untouched covariance -- bit for bit what
-    // the full path computes for it.  Proof used: leading minors > 0 (Sylvester); lambda_max <= trace;
-    // lambda_min = det / (lambda_mid lambda_max) >= det / (trace / 2)^2.  (Dump mode reports the eigenvalues: full path.)
-    bool well_conditioned = false;
-    if (!dump.nr_points) {
-      const double m2 = cov[0][0] * cov[1][1] - cov[0][1] * cov[0][1];
-      const double det = cov[0][0] * (cov[1][1] * cov[2][2] - cov[1][2] * cov[1][2]) - cov[0][1] * (cov[0][1] * cov[2][2] - cov[1][2] * cov[0][2]) +
-                         cov[0][2] * (cov[0][1] * cov[1][2] - cov[1][1] * cov[0][2]);
-      const double tr = cov[0][0] + cov[1][1] + cov[2][2];
-      well_conditioned = cov[0][0] > 0 && m2 > 1e-12 * cov[0][0] * cov[1][1] && det > 0 && 4.0 * det > 1.05 * eig_ratio * tr * tr * tr && eig_ratio < 0.9;
-    }
-    if (well_conditioned) {
-      w[0] = w[1] = w[2] = 1.0;  // (placeholders: positive, no inflation)
-    } else {
-      eig3_jacobi(cov, w, V);
-    }
-    if (w[0] < 0 || w[1] < 0 || w[2] <= 0) {  // :337-341
-      nr_points = -1;
-    } else {
-      const double min_ev = eig_ratio * w[2];  // :345-356
-      if (!well_conditioned && w[0] < min_ev) {
-        w[0] = min_ev;
-        if (w[1] < min_ev) w[1] = min_ev;
-        double Vi[3][3], VL[3][3];
-        inv3_cofactor(V, Vi);
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) VL[i][j] = V[i][j] * w[j];
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) cov[i][j] = (VL[i][0] * Vi[0][j] + VL[i][1] * Vi[1][j]) + VL[i][2] * Vi[2][j];
-      }
-      evals[0] = w[0]; evals[1] = w[1]; evals[2] = w[2];
-      inv3_cofactor(cov, icov);  // :359
-      double mx = -DBL_MAX, mn = DBL_MAX;
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) { mx = fmax(mx, icov[i][j]); mn = fmin(mn, icov[i][j]); }
-      if (mx == static_cast<double>(INFINITY) || mn == -static_cast<double>(INFINITY)) nr_points = -1;  // :360-364
-    }
-    {
-      // Every voxel that reached min_points_per_voxel gets a record: the reference pushes its
-      // centroid to the KD-tree BEFORE the eigenvalue / inverse checks (_impl.hpp:302-326 vs
-      // :337-341,:360-364), so KDTREE search still returns a rejected voxel (trap 7), with the
-      // icov_ it was left with (zero, or the inf-bearing inverse).  DIRECT searches skip it
-      // (nr_points = -1): the LUT entry is lut_rejected(r).
-      VoxelRec rec;
-      rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
-      const float c00 = static_cast<float>(icov[0][0]), c01 = static_cast<float>(icov[0][1]), c02 = static_cast<float>(icov[0][2]);
-      const float c11 = static_cast<float>(icov[1][1]), c12 = static_cast<float>(icov[1][2]), c22 = static_cast<float>(icov[2][2]);
-      rec.p0[0] = c00; rec.p0[1] = c01;
-      rec.p1[0] = c01; rec.p1[1] = c11;
-      rec.p2[0] = c02; rec.p2[1] = c12;
-      rec.p3[0] = c11; rec.p3[1] = c22;
-      rec.n = cnt;
-      rec.pad = 0;
-      recs[r] = rec;
-      centroids[r] = make_float4(fx, fy, fz, 0.0f);
-      const int entry = (nr_points >= min_pts) ? r : lut_rejected(r);
-      is_valid = nr_points >= min_pts;
-      if (geom.hash_bits) {
-        // sparse grid: claim a slot of the hash table (keys are unique: one insert per voxel)
-        int2* tab = reinterpret_cast<int2*>(lut);
-        const unsigned mask = (1u << geom.hash_bits) - 1u;
-        for (unsigned hslot = hash_slot(cell, geom.hash_bits);; hslot = (hslot + 1u) & mask) {
-          const int seen = atomicCAS(&tab[hslot].x, -1, cell);
-          if (seen == -1 || seen == cell) {
-            tab[hslot].y = entry;
-            break;
-          }
-        }
-      } else {
-        // the cell's slot in the padded look-up table
-        const int c = cell;
-        const int cz = c / geom.mul[2], cy = (c - cz * geom.mul[2]) / geom.mul[1], cx = c - cz * geom.mul[2] - cy * geom.mul[1];
-        const long long slot = static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * geom.pmul[1] +
-                               static_cast<long long>(cz + kLutBorder) * geom.pmul[2];
-        lut[slot] = entry;
-      }
-    }
-  }
-  if (dump.nr_points) {
-    dump.nr_points[o] = nr_points;
-    for (int k = 0; k < 3; k++) {
-      dump.mean[o * 3 + k] = mean[k];
-      dump.evals[o * 3 + k] = evals[k];
-    }
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        dump.cov[o * 9 + i * 3 + j] = cov[i][j];
-        dump.icov[o * 9 + i * 3 + j] = icov[i][j];
-      }
-  }
-  return is_valid;
-}
-
-__global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ pts, const int* __restrict__ leaf_cell,
-                                                     const unsigned* __restrict__ leaf_start,
-                                                     const int* __restrict__ leaf_count,
-                                                     const int* __restrict__ leaf_rec, int n_leaves_host, const unsigned* __restrict__ d_totals,
-                                                     int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
-                                                     VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
-                                                     GridGeom geom, unsigned* __restrict__ n_valid, FinalizeDump dump,
-                                                     const float4* __restrict__ big_pts, unsigned* __restrict__ crowd) {
-  // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
-  // covariance formula (_impl.hpp:329-330) cancels catastrophically when the coordinates are large
-  // against the voxel size (sum of squares ~ n x^2 against a spread of millimetres), so a single fused
-  // multiply-add in the sums shows up in the 7th digit of cov / icov.  With it off, the f64 sums and
-  // the covariance are bit-identical to the reference's sequential pass.
-#pragma clang fp contract(off)
-  const int o = blockIdx.x * kBlock + threadIdx.x;
-  const int n_leaves = d_totals ? static_cast<int>(d_totals[1]) : n_leaves_host;  // device-side count: no host round trip
-  if (o >= n_leaves) return;
-  const unsigned start = leaf_start[o];
-  const int cnt = leaf_count[o];
-  int* seg = sorted_idx + start;
-
-  // The counting sort leaves the segment in arrival order; restore ascending point order so
-  // the f64 sums below round exactly like the reference's sequential first pass
-  // (_impl.hpp:209-263).
-  // first-pass sums: mean_ += pt ; cov_ += pt*pt^T with cov_ seeded Identity (.h:107)
-  VoxelSums S;
-  auto add_point = [&](const float4& p) { S.add(p.x, p.y, p.z); };
-  constexpr int kReg = 16;
-  if (cnt <= kReg) {
-    // typical voxel: indices in registers (all loads in flight at once), odd-even transposition
-    // sort, then all point gathers in flight at once -- two memory latencies per voxel instead
-    // of two per point
-    int idx[kReg];
-#pragma unroll
-    for (int i = 0; i < kReg; i++) idx[i] = (i < cnt) ? seg[i] : 0x7fffffff;
-#pragma unroll
-    for (int pass = 0; pass < kReg; pass++) {
-#pragma unroll
-      for (int i = pass & 1; i + 1 < kReg; i += 2) {
-        const int a = idx[i], b = idx[i + 1];
-        idx[i] = min(a, b);
-        idx[i + 1] = max(a, b);
-      }
-    }
-    float4 pp[kReg];
-#pragma unroll
-    for (int i = 0; i < kReg; i++) pp[i] = pts[(i < cnt) ? idx[i] : idx[0]];
-#pragma unroll
-    for (int i = 0; i < kReg; i++) {
-      if (i < cnt) {
-        seg[i] = idx[i];  // keep the sorted order for the dump pass
-        add_point(pp[i]);
-      }
-    }
-  } else if (big_pts) {
-    // k_presort_large has sorted the segment and laid its points out in order: eight contiguous loads in flight
-    const float4* bp = big_pts + start;
-    int i = 0;
-    for (; i + 8 <= cnt; i += 8) {
-      const float4 p0 = bp[i], p1 = bp[i + 1], p2 = bp[i + 2], p3 = bp[i + 3], p4 = bp[i + 4], p5 = bp[i + 5], p6 = bp[i + 6], p7 = bp[i + 7];
-      add_point(p0); add_point(p1); add_point(p2); add_point(p3); add_point(p4); add_point(p5); add_point(p6); add_point(p7);
-    }
-    for (; i < cnt; i++) add_point(bp[i]);
-  } else {
-    sort_segment(seg, cnt);
-    int i = 0;
-    for (; i + 4 <= cnt; i += 4) {  // four gathers in flight
-      const float4 p0 = pts[seg[i]], p1 = pts[seg[i + 1]], p2 = pts[seg[i + 2]], p3 = pts[seg[i + 3]];
-      add_point(p0); add_point(p1); add_point(p2); add_point(p3);
-    }
-    for (; i < cnt; i++) add_point(pts[seg[i]]);
-  }
-  const bool is_valid = finish_voxel(S, cnt, o, leaf_rec[o], leaf_cell[o], min_pts, eig_ratio, recs, centroids, lut, geom, dump);
-  {  // one counter update per wave instead of ~10^5 atomics on one word
-    const unsigned long long vm = __ballot(is_valid);
-    if (vm != 0 && (threadIdx.x & (kWave - 1)) == static_cast<unsigned>(__ffsll(static_cast<long long>(vm)) - 1))
-      atomicAdd(n_valid, static_cast<unsigned>(__popcll(vm)));
-    if (crowd) {  // points in crowded cells (the host's hint for the next build's choice of path)
-      unsigned cp = (static_cast<unsigned>(cnt) > 48u) ? static_cast<unsigned>(cnt) : 0u;
-#pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) cp += __shfl_xor(cp, off, kWave);
-      if ((threadIdx.x & (kWave - 1)) == 0 && cp) atomicAdd(crowd, cp);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K1, bucket form (the default for dense grids; the count / scan / scatter / finalize chain above stays as the general
-// path and serves the prefilter and the scan ordering).
-//
-// Binning 1M points into 10^5 voxel counters with global atomics costs ~43 us whatever their scope -- integer atomics
-// execute at the memory side on gfx950, ~23 G/s (tools/probes/atomic_probe.cpp) -- and the per-voxel pass then gathers
-// its points at random from the whole cloud (64-B sectors for 16-B points).  Here the voxel index space is cut into
-// K buckets of C = 2^shift consecutive cells and everything per-voxel is staged through LDS:
-//   k1_hist     per block of points: LDS histogram over the buckets, ONE returning global atomic per (block, bucket)
-//               claims the block's run inside the bucket; the last block to finish scans the bucket totals
-//   k1_scatter  the same blocks move their points (x, y, z, point index) to their runs: bucket-contiguous copy
-//   k1_count    one block per bucket: LDS per-cell counters -> occupied / candidate cells of the bucket; the last
-//               block scans those totals (leaf ordinals and record ordinals stay in ascending cell order)
-//   k1_finalize one block per bucket: LDS counting sort of the bucket's points by cell, rank sort by point index inside
-//               every cell (one thread per point; any cell size), then one thread per cell: sums in ascending point
-//               order (bit-identical to the reference's sequential pass), second pass of applyFilter -> record,
-//               centroid, look-up table slot, leaf arrays, sorted_idx
-// Points are read three times and written once, contiguously; no per-point global atomic.
-// ---------------------------------------------------------------------------
-constexpr int kK1Threads = 512;   // k1_hist / k1_scatter
-
-__device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int dense) {
-  int c = -1;
-  if (dense || finite3(p.x, p.y, p.z)) {
-    c = build_cell(g, p.x, p.y, p.z);
-    if (c < 0 || static_cast<long long>(c) >= g.n_cells) c = -1;  // inside the box by construction; NaN / garbage guard
-  }
-  return c;
-}
-
-// exclusive scan of n (<= 16 * nthreads) u32 values src[] -> dst[] by one block; dst[n] = total.  lds: nthreads / 64 words
-__device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n, int nthreads,
-                                                 unsigned* lds, bool agent_loads) {
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int per = (n + nthreads - 1) / nthreads;
-  const int lo = tid * per, hi = min(n, lo + per);
-  unsigned sum = 0;
-  for (int i = lo; i < hi; i++) sum += agent_loads ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i];
-  unsigned inc = sum;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned a = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += a;
-  }
-  __syncthreads();
-  if (lane == kWave - 1) lds[wave] = inc;
-  __syncthreads();
-  unsigned base = 0, total = 0;
-  for (int w = 0; w < nthreads / kWave; w++) {
-    if (w < wave) base += lds[w];
-    total += lds[w];
-  }
-  unsigned run = base + inc - sum;
-  for (int i = lo; i < hi; i++) {
-    const unsigned v = agent_loads ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i];
-    dst[i] = run;
-    run += v;
-  }
-  if (tid == 0) dst[n] = total;
-}
-
-// the padded look-up table starts out empty, the control words and the four counters at zero: one launch instead of
-// three hipMemsetAsync calls (each costs the host ~7 us)
-__global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long long lut_cells, unsigned* __restrict__ ctrl, int n_ctrl,
-                                                  unsigned* __restrict__ counts) {
-  const long long tid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x, nt = static_cast<long long>(gridDim.x) * kBlock;
-  int4* l4 = reinterpret_cast<int4*>(lut);
-  const long long n4 = lut_cells / 4;
-  for (long long i = tid; i < n4; i += nt) l4[i] = make_int4(kLutEmpty, kLutEmpty, kLutEmpty, kLutEmpty);
-  for (long long i = n4 * 4 + tid; i < lut_cells; i += nt) lut[i] = kLutEmpty;
-  for (long long i = tid; i < n_ctrl; i += nt) ctrl[i] = 0;
-  if (tid < 5) counts[tid] = 0;  // [4]: points in crowded cells
-}
-
-__global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int shift, int K,
-                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
-                                                      unsigned* __restrict__ ticket, unsigned* __restrict__ bucket_base,
-                                                      unsigned* __restrict__ counts) {
-  extern __shared__ unsigned k1_lds[];
-  __shared__ unsigned s_scan[kK1Threads / kWave];
-  __shared__ int s_last;
-  unsigned* h = k1_lds;
-  for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
-  __syncthreads();
-  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
-  for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {  // eight loads in flight per thread
-    float4 p[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
-      p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int c = (base + u * kK1Threads < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) atomicAdd(&h[c >> shift], 1u);
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kK1Threads) {
-    const unsigned v = h[k];
-    // the block's run inside bucket k starts where the bucket's counter stood (arrival order of the blocks: any)
-    blockbase[static_cast<size_t>(blockIdx.x) * K + k] = v ? __hip_atomic_fetch_add(bucket_count + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  block_scan_array(bucket_count, bucket_base, K, kK1Threads, s_scan, true);
-  __syncthreads();
-  if (threadIdx.x == 0) counts[0] = bucket_base[K];  // points binned
-}
-
-__global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int shift, int K,
-                                                         int ppb, const unsigned* __restrict__ bucket_base,
-                                                         const unsigned* __restrict__ blockbase, float4* __restrict__ bpts) {
-  extern __shared__ unsigned k1_lds[];
-  unsigned* cursor = k1_lds;
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] = bucket_base[k] + blockbase[static_cast<size_t>(blockIdx.x) * K + k];
-  __syncthreads();
-  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
-  for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {
-    float4 p[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
-      p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
-      const int c = (i < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) bpts[atomicAdd(&cursor[c >> shift], 1u)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
-    }
-  }
-}
-
-// per-bucket cell histogram in LDS (cnt[C], zeroed here)
-__device__ __forceinline__ void k1_cell_histogram(const float4* __restrict__ bpts, unsigned bb, unsigned be, const GridGeom& g,
-                                                  int cell0, int C, unsigned* cnt) {
-  for (int c = threadIdx.x; c < C; c += kBlock) cnt[c] = 0;
-  __syncthreads();
-  for (unsigned j = bb + threadIdx.x; j < be; j += kBlock) {
-    const float4 p = bpts[j];
-    atomicAdd(&cnt[build_cell(g, p.x, p.y, p.z) - cell0], 1u);
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bpts, GridGeom g, int shift, int K, int C, unsigned min_pts,
-                                                   const unsigned* __restrict__ bucket_base, unsigned* __restrict__ tot,
-                                                   unsigned* __restrict__ ticket, unsigned* __restrict__ occ_base,
-                                                   unsigned* __restrict__ cand_base, unsigned* __restrict__ counts) {
-  extern __shared__ unsigned k1_lds[];
-  __shared__ U3 s_u3[kBlock / kWave];
-  __shared__ unsigned s_scan[kBlock / kWave];
-  __shared__ int s_last;
-  const int k = blockIdx.x;
-  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  U3 t = {0, 0, 0};
-  if (be > bb) {  // uniform
-    k1_cell_histogram(bpts, bb, be, g, k << shift, C, k1_lds);
-    for (int c = threadIdx.x; c < C; c += kBlock) {
-      const unsigned v = k1_lds[c];
-      t.occ += (v > 0);
-      t.cand += (v >= min_pts);
-    }
-  }
-  U3 total;
-  block_exclusive_scan(t, total, s_u3);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(tot + 2 * k, total.occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(tot + 2 * k + 1, total.cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // exclusive scans of the per-bucket (occupied, candidate) counts, interleaved in tot[]
-  {
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int per = (K + kBlock - 1) / kBlock, lo = tid * per, hi = min(K, lo + per);
-    for (int which = 0; which < 2; which++) {
-      unsigned* dst = which ? cand_base : occ_base;
-      unsigned sum = 0;
-      for (int i = lo; i < hi; i++) sum += __hip_atomic_load(tot + 2 * i + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned inc = sum;
-#pragma unroll
-      for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned a = __shfl_up(inc, off, kWave);
-        if (lane >= off) inc += a;
-      }
-      __syncthreads();
-      if (lane == kWave - 1) s_scan[wave] = inc;
-      __syncthreads();
-      unsigned base = 0, all = 0;
-      for (int w = 0; w < kBlock / kWave; w++) {
-        if (w < wave) base += s_scan[w];
-        all += s_scan[w];
-      }
-      unsigned run = base + inc - sum;
-      for (int i = lo; i < hi; i++) {
-        dst[i] = run;
-        run += __hip_atomic_load(tot + 2 * i + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (tid == 0) {
-        dst[K] = all;
-        counts[1 + which] = all;  // [1] occupied voxels, [2] candidates (>= min_pts)
-      }
-    }
-  }
-}
-
-// exclusive scan of cnt[0..C) into cend[0..C) by the block (C a power of two >= 32)
-__device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cend, int C, U3* s_u3) {
-  const int per = C / kBlock > 0 ? C / kBlock : 1;
-  const int lo = threadIdx.x * per;
-  U3 t = {0, 0, 0};
-  for (int c = lo; c < lo + per && c < C; c++) t.pts += cnt[c];
-  U3 total;
-  U3 run = block_exclusive_scan(t, total, s_u3);
-  for (int c = lo; c < lo + per && c < C; c++) {
-    cend[c] = run.pts;
-    run.pts += cnt[c];
-  }
-  __syncthreads();
-}
-
-constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
-constexpr unsigned kCrowdedCell = 48;             // a cell with more points counts as crowded (see build_grid's choice of path)
-constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
-// Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
-// three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
-// _impl.hpp:233-244) -- one thread walking a 400-point voxel of a real scan issues 15 f64 instructions per point by
-// itself (~20 us per voxel), a lane per chain issues two.
-constexpr int kTeamCell = 32, kTeamLanes = 16;
-constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
-
-__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int shift, int K, int C, int min_pts,
-                                                      double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
-                                                      int* __restrict__ sorted_idx,
-                                                      VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
-                                                      unsigned* __restrict__ n_valid, unsigned* __restrict__ scratch /* 5 x n words */,
-                                                      unsigned n_total) {
-  extern __shared__ unsigned k1_lds[];
-  __shared__ U3 s_u3[kBlock / kWave];
-  __shared__ int s_hi;
-  __shared__ int s_nteam;                     // team cells of the current pass ...
-  __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells ...
-  __shared__ double s_team64[kMaxTeamCells][9];  // ... and their sums (sx sy sz cxx cxy cxz cyy cyz czz)
-  __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
-  __shared__ float s_one;
-  const int k = blockIdx.x;
-  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  if (be == bb) return;  // empty bucket (uniform)
-  const unsigned nb = be - bb;
-  if (threadIdx.x == 0) s_one = 1.0f;
-  unsigned* cnt = k1_lds;          // [C] points per cell
-  unsigned* cstart = k1_lds + C;   // [C] start of the cell's segment inside the bucket (exclusive prefix of cnt)
-  unsigned* cur = k1_lds + 2 * C;  // [C] scatter cursors of the current pass
-  // per point of the current pass, in cell order (slot q) and then, in place, in (cell, point index) order:
-  unsigned* oidx = k1_lds + 3 * C;  // point index
-  unsigned* ocell = oidx + lds_cap;
-  float* ox = reinterpret_cast<float*>(ocell + lds_cap);
-  float* oy = ox + lds_cap;
-  float* oz = oy + lds_cap;
-  const int cell0 = k << shift;
-  k1_cell_histogram(bpts, bb, be, g, cell0, C, cnt);
-  k1_scan_cells(cnt, cstart, C, s_u3);
-  const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned n_ok = 0;
-  {  // how crowded is this cloud?  (points living in cells of more than kCrowdedCell points: the host's hint for the NEXT build)
-    unsigned cp = 0;
-    for (int c = threadIdx.x; c < C; c += kBlock) cp += (cnt[c] > kCrowdedCell) ? cnt[c] : 0u;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cp += __shfl_xor(cp, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && cp) atomicAdd(n_valid + 1, cp);
-  }
-  // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
-  // bucket of a uniform cloud, several for a crowded one (clustered data: a ground plane fills "its" buckets with many
-  // times the mean).  A pass selects its points from the bucket, sorts them by (cell, point index) in LDS and finishes
-  // its cells.
-  for (int c_lo = 0; c_lo < C;) {
-    if (threadIdx.x == 0) {
-      int c = c_lo;
-      if (nb <= static_cast<unsigned>(lds_cap)) {
-        c = C;
-      } else {
-        unsigned tot = 0;
-        while (c < C && tot + cnt[c] <= static_cast<unsigned>(lds_cap)) tot += cnt[c++];
-        if (c == c_lo) c = c_lo + 1;  // a single cell with more points than a pass holds: the crowded-cell path below
-      }
-      s_hi = c;
-    }
-    __syncthreads();
-    const int c_hi = s_hi;
-    const unsigned base = cstart[c_lo];
-    const unsigned n_pass = ((c_hi < C) ? cstart[c_hi] : nb) - base;
-    if (n_pass == 0) {  // (uniform)
-      c_lo = c_hi;
-      __syncthreads();
-      continue;
-    }
-    const bool giant = n_pass > static_cast<unsigned>(lds_cap);  // then c_hi == c_lo + 1
-    // arrays of this pass: LDS, or (one cell too crowded for LDS) the bucket's slices of the global scratch
-    unsigned* pidx = giant ? scratch + bb + base : oidx;
-    float* px = giant ? reinterpret_cast<float*>(scratch + n_total + bb + base) : ox;
-    float* py = giant ? reinterpret_cast<float*>(scratch + 2 * static_cast<size_t>(n_total) + bb + base) : oy;
-    float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
-    unsigned* pcell = giant ? nullptr : ocell;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
-    __syncthreads();
-    for (unsigned j0 = 0; j0 < nb; j0 += kK1PerThread * kBlock) {  // select this pass's points, eight loads in flight
-      float4 p[kK1PerThread];
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned j = j0 + threadIdx.x + u * kBlock;
-        p[u] = (j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned j = j0 + threadIdx.x + u * kBlock;
-        if (j >= nb) continue;
-        const int c = build_cell(g, p[u].x, p[u].y, p[u].z) - cell0;
-        if (c < c_lo || c >= c_hi) continue;
-        const unsigned q = atomicAdd(&cur[c], 1u);
-        pidx[q] = static_cast<unsigned>(__float_as_int(p[u].w));
-        if (pcell) pcell[q] = static_cast<unsigned>(c);
-        px[q] = p[u].x;
-        py[q] = p[u].y;
-        pz[q] = p[u].z;
-      }
-    }
-    if (giant) __threadfence_block();
-    __syncthreads();
-    if (!giant) {
-      // rank sort inside every cell's segment, one thread per point: a point's rank is the number of points of its
-      // cell with a smaller point index (indices are unique).  The sorted copy goes back IN PLACE: every thread
-      // reads its points' data first, the block synchronises, then everybody writes.
-      unsigned dst[kK1PerThread], di[kK1PerThread];
-      float rx[kK1PerThread], ry[kK1PerThread], rz[kK1PerThread];
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned q = threadIdx.x + u * kBlock;
-        dst[u] = ~0u;
-        if (q < n_pass) {
-          const unsigned c = ocell[q], beg = cstart[c] - base, end = beg + cnt[c], mine = oidx[q];
-          unsigned r = 0, t = beg;
-          for (; t + 4 <= end; t += 4) {  // four independent LDS reads per step (a dependent read per step costs its full latency)
-            const unsigned a0 = oidx[t], a1 = oidx[t + 1], a2 = oidx[t + 2], a3 = oidx[t + 3];
-            r += (a0 < mine ? 1u : 0u) + (a1 < mine ? 1u : 0u) + (a2 < mine ? 1u : 0u) + (a3 < mine ? 1u : 0u);
-          }
-          for (; t < end; t++) r += (oidx[t] < mine) ? 1u : 0u;
-          dst[u] = beg + r;
-          di[u] = mine;
-          rx[u] = ox[q];
-          ry[u] = oy[q];
-          rz[u] = oz[q];
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        if (dst[u] != ~0u) {
-          ox[dst[u]] = rx[u];
-          oy[dst[u]] = ry[u];
-          oz[dst[u]] = rz[u];
-          sorted_idx[bb + base + dst[u]] = static_cast<int>(di[u]);
-        }
-      }
-      __syncthreads();
-    } else {
-      // one cell with more points than LDS holds (thousands per voxel): rank sort through global scratch into a second
-      // set of slices.  O(n^2) reads by the block: slow, and rare.
-      unsigned* sidx = scratch + 4 * static_cast<size_t>(n_total) + bb + base;  // ranks
-      for (unsigned q = threadIdx.x; q < n_pass; q += kBlock) {
-        const unsigned mine = pidx[q];
-        unsigned r = 0, t = 0;
-        for (; t + 8 <= n_pass; t += 8) {
-          unsigned a[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) a[u] = pidx[t + u];
-#pragma unroll
-          for (int u = 0; u < 8; u++) r += (a[u] < mine) ? 1u : 0u;
-        }
-        for (; t < n_pass; t++) r += (pidx[t] < mine) ? 1u : 0u;
-        sidx[r] = q;
-        sorted_idx[bb + base + r] = static_cast<int>(mine);
-      }
-      __threadfence_block();
-      __syncthreads();
-      if (threadIdx.x == 0 && static_cast<int>(n_pass) >= min_pts) {
-        VoxelSums S;
-        unsigned i = 0;
-        for (; i + 8 <= n_pass; i += 8) {
-          float x[8], y[8], z[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) { const unsigned q = sidx[i + u]; x[u] = px[q]; y[u] = py[q]; z[u] = pz[q]; }
-#pragma unroll
-          for (int u = 0; u < 8; u++) S.add(x[u], y[u], z[u]);
-        }
-        for (; i < n_pass; i++) { const unsigned q = sidx[i]; S.add(px[q], py[q], pz[q]); }
-        const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
-        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, cell0 + c_lo, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
-      }
-      c_lo = c_hi;
-      __syncthreads();
-      continue;
-    }
-    // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
-    if (threadIdx.x == 0) s_nteam = 0;
-    __syncthreads();
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
-      const int n_c = static_cast<int>(cnt[c]);
-      if (n_c > kTeamCell && n_c >= min_pts) {
-        const int slot = atomicAdd(&s_nteam, 1);
-        s_team_cell[slot] = c;
-        cur[c] = static_cast<unsigned>(slot);  // (the scatter cursors are free again)
-      }
-    }
-    __syncthreads();
-    if (s_nteam > 0) {
-#pragma clang fp contract(off)
-      const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
-      // lane -> (a, b): 0-2 mean sums a * 1; 3-8 the products xx xy xz yy yz zz; 9-11 the f32 centroid sums
-      const int ia = (tl < 3) ? tl : (tl < 6) ? 0 : (tl < 8) ? 1 : (tl == 8) ? 2 : (tl < 12) ? tl - 9 : 0;
-      const int ib = (tl == 3) ? 0 : (tl == 4 || tl == 6) ? 1 : (tl == 5 || tl == 7 || tl == 8) ? 2 : -1;
-      const float* pa = (ia == 0) ? ox : (ia == 1) ? oy : oz;
-      const float* pb = (ib == 0) ? ox : (ib == 1) ? oy : (ib == 2) ? oz : &s_one;
-      const unsigned sb = (ib < 0) ? 0u : 1u;  // mean / centroid lanes multiply by the constant 1.0f (exact)
-      const int n_team = s_nteam;
-      for (int s = team; s < n_team; s += kBlock / kTeamLanes) {
-        const int c = s_team_cell[s];
-        const unsigned beg = cstart[c] - base, n_c = cnt[c];
-        double acc = (tl == 3 || tl == 6 || tl == 8) ? 1.0 : 0.0;  // cov_ starts as Identity (voxel_grid_covariance_omp.h:107)
-        float acc32 = 0.f;
-        unsigned i = 0;
-        for (; i + 4 <= n_c; i += 4) {
-          float a[4], b[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { a[u] = pa[beg + i + u]; b[u] = pb[(beg + i + u) * sb]; }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const double prod = static_cast<double>(a[u]) * static_cast<double>(b[u]);
-            acc += prod;
-            acc32 += a[u];
-          }
-        }
-        for (; i < n_c; i++) {
-          const float a = pa[beg + i], b = pb[(beg + i) * sb];
-          const double prod = static_cast<double>(a) * static_cast<double>(b);
-          acc += prod;
-          acc32 += a;
-        }
-        if (tl < 9) s_team64[s][tl] = acc;
-        else if (tl < 12) s_team32[s][tl - 9] = acc32;
-      }
-    }
-    __syncthreads();
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
-      const int n_c = static_cast<int>(cnt[c]);
-      if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
-      const unsigned beg = cstart[c] - base;
-      // record slot: candidates' segments start at least min_pts apart, so start / min_pts is unique per candidate --
-      // no scan over the buckets is needed to number the records (k1_leaves numbers the LEAVES when somebody asks)
-      const int r = static_cast<int>((bb + cstart[c]) / static_cast<unsigned>(min_pts));
-      VoxelSums S;
-      if (n_c > kTeamCell) {
-        const unsigned slot = cur[c];
-        S.sx = s_team64[slot][0]; S.sy = s_team64[slot][1]; S.sz = s_team64[slot][2];
-        S.cxx = s_team64[slot][3]; S.cxy = s_team64[slot][4]; S.cxz = s_team64[slot][5];
-        S.cyy = s_team64[slot][6]; S.cyz = s_team64[slot][7]; S.czz = s_team64[slot][8];
-        S.fx = s_team32[slot][0]; S.fy = s_team32[slot][1]; S.fz = s_team32[slot][2];
-      } else {
-        int i = 0;
-        for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
-          float x[4], y[4], z[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { x[u] = ox[beg + i + u]; y[u] = oy[beg + i + u]; z[u] = oz[beg + i + u]; }
-#pragma unroll
-          for (int u = 0; u < 4; u++) S.add(x[u], y[u], z[u]);
-        }
-        for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
-      }
-      n_ok += finish_voxel(S, n_c, 0, r, cell0 + c, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
-    }
-    c_lo = c_hi;
-    __syncthreads();  // the LDS arrays are reused by the next pass
-  }
-  {  // one counter update per wave
-    unsigned v = n_ok;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(n_valid, v);
-  }
-}
-
-// Leaf arrays of a bucket-form build (ascending cell order: leaf_cell / leaf_start / leaf_count / leaf_rec), written only
-// when somebody asks for them (ndt_grid_dump, getFitnessScore's index, ndt_grid_size): after k1_count has numbered
-// the buckets' occupied cells.
-__global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ bpts, GridGeom g, int shift, int C, int min_pts,
-                                                    const unsigned* __restrict__ bucket_base, const unsigned* __restrict__ occ_base,
-                                                    int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
-                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec) {
-  extern __shared__ unsigned k1_lds[];
-  __shared__ U3 s_u3[kBlock / kWave];
-  const int k = blockIdx.x;
-  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  if (be == bb) return;
-  unsigned* cnt = k1_lds;
-  const int cell0 = k << shift;
-  k1_cell_histogram(bpts, bb, be, g, cell0, C, cnt);
-  const int per = C / kBlock > 0 ? C / kBlock : 1;
-  const int lo = threadIdx.x * per;
-  U3 t = {0, 0, 0};
-  for (int c = lo; c < lo + per && c < C; c++) {
-    t.pts += cnt[c];
-    t.occ += (cnt[c] > 0);
-  }
-  U3 total;
-  U3 run = block_exclusive_scan(t, total, s_u3);
-  const unsigned ob = occ_base[k];
-  for (int c = lo; c < lo + per && c < C; c++) {
-    const unsigned v = cnt[c];
-    if (v > 0) {
-      const unsigned o = ob + run.occ;
-      leaf_cell[o] = cell0 + c;
-      leaf_start[o] = bb + run.pts;
-      leaf_count[o] = static_cast<int>(v);
-      leaf_rec[o] = (v >= static_cast<unsigned>(min_pts)) ? static_cast<int>((bb + run.pts) / static_cast<unsigned>(min_pts)) : -1;
-    }
-    run.pts += v;
-    run.occ += (v > 0);
-  }
-}
 
 // Diagnostic build of the DIRECT7 derivative kernel with s_memtime stamps (never used by the
 // product path): per wave, cycles at entry / point arrived / LUT arrived / first record arrived /
@@ -1655,10 +385,6 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
   block_reduce_store<1>(acc, partials + static_cast<size_t>(blockIdx.x) * kEvalStride, lds);
 }
 
-// k_presort_large: leaves per wave-step and grid (one leaf per wave while that stays within 8192 waves)
-inline int presort_chunk(int n_leaves) { return max(1, min(64, (n_leaves + 8191) / 8192)); }
-inline int presort_grid(int n_leaves) { return max(1, min(8192, (n_leaves + presort_chunk(n_leaves) - 1) / presort_chunk(n_leaves))); }
-
 inline int grid_for(size_t n, int max_blocks) {
   size_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -1686,159 +412,8 @@ int derivative_blocks(int n, int search) {
   return grid_for(static_cast<size_t>(n), cap);
 }
 
-hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_repack, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream,
-                     static_cast<const unsigned char*>(d_src), n, stride_bytes, d_dst);
-  return hipGetLastError();
-}
-
-hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
-                              int n_blocks, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
-                     stride_bytes, d_dst, d_block_minmax);
-  return hipGetLastError();
-}
-
-hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(k_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, pts, n, dense, d_block_minmax);
-  return hipGetLastError();
-}
-
-hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
-                        unsigned* d_cell_count, hipStream_t stream) {
-  hipLaunchKernelGGL(k_count, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, pts, n, dense, g, d_key, d_rank, d_cell_count);
-  return hipGetLastError();
-}
-
-hipError_t launch_scan_reduce(const unsigned* d_cell_count, long long n_cells, int min_pts, unsigned* d_block_sums,
-                              int n_tiles, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_reduce, dim3(n_tiles), dim3(kBlock), 0, stream, d_cell_count, n_cells,
-                     static_cast<unsigned>(min_pts), d_block_sums);
-  return hipGetLastError();
-}
-
-hipError_t launch_scan_blocks(unsigned* d_block_sums, int n_tiles, unsigned* d_totals, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kBlock), 0, stream, d_block_sums, n_tiles, d_totals);
-  return hipGetLastError();
-}
-
-hipError_t launch_scan_apply(unsigned* d_cell_count_to_cursor, long long n_cells, int min_pts,
-                             const unsigned* d_block_sums, int n_tiles, int* d_leaf_cell,
-                             unsigned* d_leaf_start, int* d_leaf_count, int* d_leaf_rec, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(kBlock), 0, stream, d_cell_count_to_cursor, n_cells,
-                     static_cast<unsigned>(min_pts), d_block_sums, d_leaf_cell, d_leaf_start, d_leaf_count,
-                     d_leaf_rec);
-  return hipGetLastError();
-}
-
-hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const unsigned* d_cell_start, int* d_sorted_idx,
-                          hipStream_t stream) {
-  hipLaunchKernelGGL(k_scatter, dim3(grid_for(n, 2048)), dim3(kBlock), 0, stream, d_key, d_rank, n, d_cell_start, d_sorted_idx);
-  return hipGetLastError();
-}
-
-hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
-                           const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
-                           int min_pts, double eig_ratio, VoxelRec* d_recs, float4* d_centroids, int* d_lut, const GridGeom& geom,
-                           unsigned* d_n_valid, FinalizeDump dump, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
-  // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
-  if (n_leaves == 0) return hipSuccess;
-  if (d_big_pts)  // leaves with many points: sorted and gathered by one wave each, ahead of the per-leaf pass
-    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, d_leaf_start, d_leaf_count, n_leaves,
-                       d_totals, d_sorted_idx, d_big_pts, presort_chunk(n_leaves));
-  hipLaunchKernelGGL(k_finalize, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, d_leaf_cell,
-                     d_leaf_start, d_leaf_count, d_leaf_rec, n_leaves, d_totals, d_sorted_idx, min_pts, eig_ratio, d_recs, d_centroids,
-                     d_lut, geom, d_n_valid, dump, d_big_pts, dump.nr_points ? nullptr : d_n_valid + 1);
-  return hipGetLastError();
-}
-
-static int pow2_ceil(long long v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
-bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
-  constexpr int kMaxBuckets = 8192, kMaxCells = 4096;
-  if (n_points <= 0 || n_cells <= 0 || n_cells > static_cast<long long>(kMaxBuckets) * kMaxCells) return false;
-  // ~1000 points per bucket: a bucket's per-point arrays then live in LDS and there are several blocks per CU
-  // ... and at least a bucket per CU: a small cloud (the mapping nodes' 16 k points) is latency-bound on its fullest bucket
-  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 8; }();
-  const long long k_small = std::min<long long>(4096, n_points / small_div);  // small clouds: crowded cells spread over many blocks
-  const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / 1024));
-  int C = pow2_ceil((n_cells + k_target - 1) / k_target);
-  static const int min_c = [] { const char* v = getenv("NDT_K1_MIN_C"); return v ? std::max(1, atoi(v)) : 32; }();
-  C = std::max(n_points <= 262144 ? min_c : 32, std::min(kMaxCells, C));
-  while ((n_cells + C - 1) / C > kMaxBuckets) C <<= 1;
-  if (C > kMaxCells) return false;
-  P.cells_per_bucket = C;
-  P.shift = 0;
-  while ((1 << P.shift) < C) P.shift++;
-  P.n_buckets = static_cast<int>((n_cells + C - 1) / C);
-  P.pts_per_block = std::max(1024, std::min(16384, pow2_ceil((n_points + 383) / 384)));  // >= one block per CU: the LDS atomics of a block run at ~0.7 G/s
-  P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
-  return true;
-}
-
-hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& P, int min_pts,
-                                     double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, float4* centroids,
-                                     int* lut, unsigned* counts, hipStream_t stream) {
-  const int K = P.n_buckets, C = P.cells_per_bucket;
-  const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
-  hipLaunchKernelGGL(k1_init, dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>(2048, g.lut_cells / (4 * kBlock) + 1)))), dim3(kBlock), 0,
-                     stream, lut, g.lut_cells, S.tickets, 4 + K, counts);
-  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_count, S.blockbase, S.tickets, S.bucket_base, counts);
-  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_base, S.blockbase, S.bpts);
-  // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
-  // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
-  // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
-  // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
-  const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
-  int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));  // a power of two: the bitonic sort of a crowded pass
-  if (K <= 512 || n <= 262144) lds_cap = kK1LdsCap;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
-  while (lds_cap > 256 && lds_cap > (60 * 1024 / 4 - 3 * C) / 5) lds_cap >>= 1;
-  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
-  if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
-  hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
-                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut, counts + 3,
-                     S.order, static_cast<unsigned>(n));
-  return hipGetLastError();
-}
-
-hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min_pts, const float4* bpts, const unsigned* bucket_base,
-                              unsigned* scratch /* 4 K + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count, int* leaf_rec,
-                              unsigned* counts, hipStream_t stream) {
-  const int K = P.n_buckets, C = P.cells_per_bucket;
-  unsigned* ticket = scratch;
-  unsigned* tot = scratch + 2;
-  unsigned* occ_base = tot + 2 * K;
-  unsigned* cand_base = occ_base + (K + 1);
-  hipError_t e = hipMemsetAsync(ticket, 0, 2 * sizeof(unsigned), stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k1_count, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, K, C,
-                     static_cast<unsigned>(min_pts), bucket_base, tot, ticket, occ_base, cand_base, counts);
-  hipLaunchKernelGGL(k1_leaves, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, C, min_pts,
-                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec);
-  return hipGetLastError();
-}
-
 hipError_t launch_selftest_reduce(int n_blocks, double* out, hipStream_t stream) {
   hipLaunchKernelGGL(k_selftest_reduce, dim3(n_blocks), dim3(kBlock), 0, stream, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                              int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals) {
-  if (n_leaves == 0) return hipSuccess;
-  // crowded cells first, one wave each (sorted and gathered straight into `out`); k_sort_gather takes the rest
-  hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
-                     sorted_idx, out, presort_chunk(n_leaves));
-  hipLaunchKernelGGL(k_sort_gather, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
-                     leaf_count, n_leaves, d_totals, sorted_idx, out);
   return hipGetLastError();
 }
 
@@ -1847,40 +422,6 @@ hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& 
   hipLaunchKernelGGL(k_derivatives_stamped, dim3(n_blocks), dim3(kBlock), 0, stream, src, n, gv, P, partials, stamps);
   return hipGetLastError();
 }
-
-hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
-                                  int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
-  if (n_leaves == 0) return hipSuccess;
-  if (d_big_pts)
-    hipLaunchKernelGGL(k_presort_large, dim3(presort_grid(n_leaves)), dim3(kBlock), 0, stream, pts, leaf_start, leaf_count, n_leaves, d_totals,
-                       sorted_idx, d_big_pts, presort_chunk(n_leaves));
-  hipLaunchKernelGGL(k_voxel_centroids, dim3((n_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, pts, leaf_start,
-                     leaf_count, n_leaves, d_totals, sorted_idx, out, d_big_pts);
-  return hipGetLastError();
-}
-
-hipError_t launch_scan_bboxes(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, int* d_out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_bboxes, dim3(grid_for(max_scan_points, 64), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, d_out);
-  return hipGetLastError();
-}
-float scan_bbox_decode(int v) {
-  const int b = v ^ ((v >> 31) & 0x7fffffff);
-  float f;
-  std::memcpy(&f, &b, sizeof(f));
-  return f;
-}
-hipError_t launch_count_batch(const float4* pts, const int* d_scan_off, int n_scans, int max_scan_points, const ScanLattice* d_lat,
-                              int* d_key, unsigned* d_rank, unsigned* d_cell_count, hipStream_t stream) {
-  hipLaunchKernelGGL(k_count_batch, dim3(grid_for(max_scan_points, 256), n_scans), dim3(kBlock), 0, stream, pts, d_scan_off, d_lat,
-                     d_key, d_rank, d_cell_count);
-  return hipGetLastError();
-}
-hipError_t launch_pick(const unsigned* cell_count, const long long* d_bases, unsigned* d_out, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(k_pick, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cell_count, d_bases, d_out, n);
-  return hipGetLastError();
-}
-
-int scan_tiles(long long n_cells) { return static_cast<int>((n_cells + kScanTile - 1) / kScanTile); }
 
 template <int NNB, bool WANT_H>
 static void launch_deriv_t(const float4* src, int n, const GridView& gv, const EvalParams& P, const ScanDesc* descs,
