@@ -3,6 +3,8 @@
 // (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
 #include "ndt_internal.hpp"
 
+#include <type_traits>
+
 namespace ndtc {
 
 // upload + repack to dense float4
@@ -385,19 +387,11 @@ ndt_status build_grid(ndt_context* h) {
     return NDT_OK;
   }
   HIP_TRY(g->lut.reserve(static_cast<size_t>(geo.lut_cells)));
-  // Which form of K1?  The bucket form wins on clouds of moderate density (synthetic sets, maps: 2.5 x at 1M points); clouds
-  // whose points crowd into few voxels (a 0.1 m-filtered scan in 1 m voxels: hundreds per voxel) are built faster by the
-  // general chain, which gives every crowded voxel a workgroup of its own.  A build reports how crowded its cloud was
-  // (counts[4], copied to pinned memory without waiting); the NEXT build of the handle -- the nodes register scan after
-  // scan of the same sensor -- reads that number: by then the upload's synchronisation has long passed it.
   static const int k1_mode = [] { const char* v = getenv("NDT_K1"); return !v ? 0 : std::strcmp(v, "old") == 0 ? 1 : std::strcmp(v, "new") == 0 ? 2 : 0; }();
-  if (h->k1_feedback && h->k1_feedback_valid) {
-    const unsigned binned = h->k1_feedback[0], crowded = h->k1_feedback[4];
-    if (binned > 0) h->k1_crowded_hint = (static_cast<double>(crowded) > 0.3 * static_cast<double>(binned)) ? 1 : 0;
-  }
-  // (small clouds -- the mapping nodes' 16 k points -- are launch-latency-bound: the 4-launch bucket form wins there however
-  // crowded the voxels are, its crowded cells being summed by lane teams: 101 -> 74 us on the reference pair)
-  const bool buckets_on = k1_mode == 2 || (k1_mode == 0 && (h->k1_crowded_hint != 1 || n <= 65536));
+  // The bucket form builds every dense grid (NDT_K1=old: the general chain, kept for index-only builds -- GICP's search
+  // index -- and as the cross-check of tools/fuzz_grid.py).  With its cells dealt to the buckets in short runs (k1_bucket)
+  // it is the faster form for every cloud shape measured, uniform to heavily clustered (tools/time_k1_forms.py).
+  const bool buckets_on = k1_mode != 1;
   ndt::GridBuildPlan plan{};
   if (buckets_on && !h->index_only && ndt::grid_build_plan(geo.n_cells, n, plan)) {
     // ---- bucket form (ndt_kernels.hip "K1, bucket form"): no per-point global atomic, per-voxel work staged through LDS
@@ -405,6 +399,14 @@ ndt_status build_grid(ndt_context* h) {
     const size_t rec_slots = static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1;  // slot = segment start / min_pts
     HIP_TRY(g->recs.reserve(rec_slots));
     HIP_TRY(g->centroids.reserve(rec_slots));
+    DevBuf<ndt::VoxelRec> recs_by_slot;  // as k1_finalize numbers them (gaps, bucket by bucket); compacted into g->recs below
+    DevBuf<float4> centroids_by_slot;
+    DevBuf<unsigned> tile_sums;
+    if (n > 65536) {
+      HIP_TRY(recs_by_slot.reserve(rec_slots));
+      HIP_TRY(centroids_by_slot.reserve(rec_slots));
+      HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(geo.lut_cells) + 1));
+    }
     DevBuf<unsigned> ctrl, blockbase, order;
     HIP_TRY(ctrl.reserve(4 + K));  // tickets[2], pad[2], bucket_count[K]: zeroed by the build's first kernel
     HIP_TRY(g->bucket_base.reserve(K + 1));
@@ -418,8 +420,16 @@ ndt_status build_grid(ndt_context* h) {
     S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
     S.order = order.p;
+    // Records dense and in ascending cell order (launch_compact_records: three small launches, ~25 us) pay for themselves as
+    // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
+    // The mapping nodes' clouds (16 k points, one registration of ~6 evaluations per target, records that fit L2 many
+    // times over) keep k1_finalize's own numbering.
+    const bool compact = n > 65536;
     HIP_TRY(ndt::launch_grid_build_buckets(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
-                                           g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
+                                           compact ? recs_by_slot.p : g->recs.p, compact ? centroids_by_slot.p : g->centroids.p, g->lut.p,
+                                           g->counts.p, st));
+    if (compact)
+      HIP_TRY(ndt::launch_compact_records(g->lut.p, geo.lut_cells, recs_by_slot.p, centroids_by_slot.p, g->recs.p, g->centroids.p, tile_sums.p, st));
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
   } else {
@@ -458,11 +468,6 @@ ndt_status build_grid(ndt_context* h) {
                                  g->lut.p, geo, g->counts.p + 3, nodump, st, g->counts.p, big_pts.p));
   }
   }
-  if (!h->index_only) {  // this build's crowding report for the next one (no wait: see above)
-    if (!h->k1_feedback) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->k1_feedback), 8 * sizeof(unsigned), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(h->k1_feedback, g->counts.p, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    h->k1_feedback_valid = true;
-  }
   // the temporaries (cell_count, key, rank, block_sums) go back to the caching pool at scope exit; the
   // pool hands memory out again only to work queued on the same stream, i.e. after these kernels
   g->counts_known = false;
@@ -481,7 +486,7 @@ ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
     DevBuf<unsigned> scratch;
     HIP_TRY(scratch.reserve(4 * K + 4));
     HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->bpts.p, g->bucket_base.p, scratch.p, g->leaf_cell.p, g->leaf_start.p,
-                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, h->stream));
+                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     g->leaves_pending = false;
     g->bpts.release();
@@ -918,6 +923,28 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
   if (icov) HIP_TRY(hipMemcpyAsync(icov, d_icov.p, V * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (evals) HIP_TRY(hipMemcpyAsync(evals, d_evals.p, V * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  // ascending voxel index, the order of the reference's std::map (a bucket-form build numbers its leaves bucket by bucket)
+  bool ascending = true;
+  for (size_t i = 1; i < V && ascending; i++) ascending = cell[i - 1] < cell[i];
+  if (!ascending) {
+    std::vector<size_t> perm(V);
+    for (size_t i = 0; i < V; i++) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return cell[a] < cell[b]; });
+    auto apply = [&](auto* arr, size_t width) {
+      if (!arr) return;
+      using T = std::remove_pointer_t<decltype(arr)>;
+      std::vector<T> tmp(arr, arr + V * width);
+      for (size_t i = 0; i < V; i++) std::copy(tmp.begin() + perm[i] * width, tmp.begin() + (perm[i] + 1) * width, arr + i * width);
+    };
+    apply(nr_points, 1);
+    apply(mean, 3);
+    apply(cov, 9);
+    apply(icov, 9);
+    apply(evals, 3);
+    std::vector<int> sorted_cell(V);
+    for (size_t i = 0; i < V; i++) sorted_cell[i] = cell[perm[i]];
+    cell.swap(sorted_cell);
+  }
   if (idx)
     for (size_t i = 0; i < V; i++) idx[i] = cell[i];
   return NDT_OK;

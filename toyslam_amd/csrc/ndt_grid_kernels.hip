@@ -745,19 +745,35 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
 //
 // Binning 1M points into 10^5 voxel counters with global atomics costs ~43 us whatever their scope -- integer atomics
 // execute at the memory side on gfx950, ~23 G/s (tools/probes/atomic_probe.cpp) -- and the per-voxel pass then gathers
-// its points at random from the whole cloud (64-B sectors for 16-B points).  Here the voxel index space is cut into
-// K buckets of C = 2^shift consecutive cells and everything per-voxel is staged through LDS:
+// its points at random from the whole cloud (64-B sectors for 16-B points).  Here the voxel index space is dealt out to
+// K buckets of C cells each (short runs of consecutive cells, round-robin: k1_bucket below) and everything per-voxel is
+// staged through LDS:
 //   k1_hist     per block of points: LDS histogram over the buckets, ONE returning global atomic per (block, bucket)
 //               claims the block's run inside the bucket; the last block to finish scans the bucket totals
 //   k1_scatter  the same blocks move their points (x, y, z, point index) to their runs: bucket-contiguous copy
 //   k1_count    one block per bucket: LDS per-cell counters -> occupied / candidate cells of the bucket; the last
-//               block scans those totals (leaf ordinals and record ordinals stay in ascending cell order)
+//               block scans those totals (leaf ordinals: bucket by bucket, ascending local cell inside a bucket)
 //   k1_finalize one block per bucket: LDS counting sort of the bucket's points by cell, rank sort by point index inside
 //               every cell (one thread per point; any cell size), then one thread per cell: sums in ascending point
 //               order (bit-identical to the reference's sequential pass), second pass of applyFilter -> record,
 //               centroid, look-up table slot, leaf arrays, sorted_idx
 // Points are read three times and written once, contiguously; no per-point global atomic.
 // ---------------------------------------------------------------------------
+// Cell <-> (bucket, local cell).  Buckets are NOT ranges of the linear cell index: a clustered scene (a ground plane) would
+// fill a few of those with many times the mean and leave the rest empty.  Runs of 2^rb consecutive cells (neighbours in x,
+// whose points a spatially ordered cloud delivers together) are dealt round-robin to the K = 2^kb buckets:
+//   bucket = (cell >> rb) mod K,   local = ((cell >> rb) / K) << rb | (cell mod 2^rb)
+// `map` packs rb (bits 0-7) and kb (bits 8-15).
+__device__ __forceinline__ int k1_bucket(int cell, int map) { return (cell >> (map & 255)) & ((1 << (map >> 8)) - 1); }
+__device__ __forceinline__ int k1_local(int cell, int map) {
+  const int rb = map & 255, kb = map >> 8;
+  return ((cell >> (rb + kb)) << rb) | (cell & ((1 << rb) - 1));
+}
+__device__ __forceinline__ int k1_cell(int bucket, int local, int map) {
+  const int rb = map & 255, kb = map >> 8;
+  return ((((local >> rb) << kb) | bucket) << rb) | (local & ((1 << rb) - 1));
+}
+
 constexpr int kK1Threads = 512;   // k1_hist / k1_scatter
 
 __device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int dense) {
@@ -813,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long lo
   if (tid < 5) counts[tid] = 0;  // [4]: points in crowded cells
 }
 
-__global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int shift, int K,
+__global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                       int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
                                                       unsigned* __restrict__ ticket, unsigned* __restrict__ bucket_base,
                                                       unsigned* __restrict__ counts) {
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int c = (base + u * kK1Threads < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) atomicAdd(&h[c >> shift], 1u);
+      if (c >= 0) atomicAdd(&h[k1_bucket(c, map)], 1u);
     }
   }
   __syncthreads();
@@ -853,7 +869,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
   if (threadIdx.x == 0) counts[0] = bucket_base[K];  // points binned
 }
 
-__global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int shift, int K,
+__global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                          int ppb, const unsigned* __restrict__ bucket_base,
                                                          const unsigned* __restrict__ blockbase, float4* __restrict__ bpts) {
   extern __shared__ unsigned k1_lds[];
@@ -872,24 +888,24 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
     for (int u = 0; u < 8; u++) {
       const int i = base + u * kK1Threads;
       const int c = (i < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) bpts[atomicAdd(&cursor[c >> shift], 1u)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
+      if (c >= 0) bpts[atomicAdd(&cursor[k1_bucket(c, map)], 1u)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
     }
   }
 }
 
 // per-bucket cell histogram in LDS (cnt[C], zeroed here)
 __device__ __forceinline__ void k1_cell_histogram(const float4* __restrict__ bpts, unsigned bb, unsigned be, const GridGeom& g,
-                                                  int cell0, int C, unsigned* cnt) {
+                                                  int map, int C, unsigned* cnt) {
   for (int c = threadIdx.x; c < C; c += kBlock) cnt[c] = 0;
   __syncthreads();
   for (unsigned j = bb + threadIdx.x; j < be; j += kBlock) {
     const float4 p = bpts[j];
-    atomicAdd(&cnt[build_cell(g, p.x, p.y, p.z) - cell0], 1u);
+    atomicAdd(&cnt[k1_local(build_cell(g, p.x, p.y, p.z), map)], 1u);
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bpts, GridGeom g, int shift, int K, int C, unsigned min_pts,
+__global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, unsigned min_pts,
                                                    const unsigned* __restrict__ bucket_base, unsigned* __restrict__ tot,
                                                    unsigned* __restrict__ ticket, unsigned* __restrict__ occ_base,
                                                    unsigned* __restrict__ cand_base, unsigned* __restrict__ counts) {
@@ -901,7 +917,7 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   U3 t = {0, 0, 0};
   if (be > bb) {  // uniform
-    k1_cell_histogram(bpts, bb, be, g, k << shift, C, k1_lds);
+    k1_cell_histogram(bpts, bb, be, g, map, C, k1_lds);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       const unsigned v = k1_lds[c];
       t.occ += (v > 0);
@@ -978,7 +994,7 @@ constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass c
 constexpr int kTeamCell = 32, kTeamLanes = 16;
 constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
-__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int shift, int K, int C, int min_pts,
+__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
                                                       double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
                                                       int* __restrict__ sorted_idx,
                                                       VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
@@ -1006,8 +1022,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   float* ox = reinterpret_cast<float*>(ocell + lds_cap);
   float* oy = ox + lds_cap;
   float* oz = oy + lds_cap;
-  const int cell0 = k << shift;
-  k1_cell_histogram(bpts, bb, be, g, cell0, C, cnt);
+  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
   k1_scan_cells(cnt, cstart, C, s_u3);
   const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
@@ -1028,8 +1043,16 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       if (nb <= static_cast<unsigned>(lds_cap)) {
         c = C;
       } else {
-        unsigned tot = 0;
-        while (c < C && tot + cnt[c] <= static_cast<unsigned>(lds_cap)) tot += cnt[c++];
+        // the last cell whose END stays within lds_cap points of c_lo's start: binary search in the prefix sums
+        // (cstart[c] = points before cell c; a linear walk by one thread cost 30 us per pass at C = 4096)
+        const unsigned limit = cstart[c_lo] + static_cast<unsigned>(lds_cap);
+        int lo = c_lo, hi = C;  // invariant: cells [c_lo, lo) fit; answer in [lo, hi]
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;  // candidate: cells [c_lo, mid) -- they end at cstart[mid] (mid < C) or nb
+          const unsigned end = (mid < C) ? cstart[mid] : nb;
+          if (end <= limit) lo = mid; else hi = mid - 1;
+        }
+        c = lo;
         if (c == c_lo) c = c_lo + 1;  // a single cell with more points than a pass holds: the crowded-cell path below
       }
       s_hi = c;
@@ -1063,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       for (int u = 0; u < kK1PerThread; u++) {
         const unsigned j = j0 + threadIdx.x + u * kBlock;
         if (j >= nb) continue;
-        const int c = build_cell(g, p[u].x, p[u].y, p[u].z) - cell0;
+        const int c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map);
         if (c < c_lo || c >= c_hi) continue;
         const unsigned q = atomicAdd(&cur[c], 1u);
         pidx[q] = static_cast<unsigned>(__float_as_int(p[u].w));
@@ -1143,7 +1166,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_pass; i++) { const unsigned q = sidx[i]; S.add(px[q], py[q], pz[q]); }
         const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
-        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, cell0 + c_lo, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
       c_lo = c_hi;
       __syncthreads();
@@ -1224,7 +1247,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       }
-      n_ok += finish_voxel(S, n_c, 0, r, cell0 + c, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
@@ -1237,21 +1260,91 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// Record compaction of a bucket-form build.  k1_finalize numbers a voxel's record by where its points sit in the bucket
+// order (unique without a scan over voxels) -- slots with gaps, bucket by bucket.  The evaluation kernels gather records
+// through the look-up table for points that arrive in lattice order, and they run measurably faster (+5 % on the headline
+// registration) when the records are dense and in ascending cell order, as the general chain leaves them: neighbouring
+// voxels then share cache lines and a wave's gathers walk the array forwards.  Three small launches over the padded
+// table: count the records per tile, scan the tile sums, then give every record its ordinal in table order, move the
+// 64-B record + centroid there and rewrite the table entry.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool lut_has_record(int e) { return e >= 0 || e <= -2; }
+__global__ __launch_bounds__(kBlock) void k_rc_count(const int* __restrict__ lut, long long n, unsigned* __restrict__ tile_sums) {
+  __shared__ unsigned s_w[kBlock / kWave];
+  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
+  unsigned c = 0;
+#pragma unroll
+  for (int u = 0; u < kScanItems; u++) c += (base + u < n && lut_has_record(lut[base + u])) ? 1u : 0u;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < kBlock / kWave; w++) t += s_w[w];
+    tile_sums[blockIdx.x] = t;
+  }
+}
+// exclusive scan of the tile sums in place, by one block; total -> total_out[0]
+__global__ __launch_bounds__(kBlock) void k_rc_scan(unsigned* __restrict__ tile_sums, int n_tiles, unsigned* __restrict__ total_out) {
+  __shared__ unsigned s_scan[kBlock / kWave];
+  block_scan_array(tile_sums, tile_sums, n_tiles, kBlock, s_scan, false);
+  (void)total_out;
+}
+__global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long long n, const unsigned* __restrict__ tile_base,
+                                                     const VoxelRec* __restrict__ recs_in, const float4* __restrict__ cent_in,
+                                                     VoxelRec* __restrict__ recs_out, float4* __restrict__ cent_out) {
+  __shared__ unsigned s_w[kBlock / kWave];
+  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
+  int e[kScanItems];
+  unsigned c = 0;
+#pragma unroll
+  for (int u = 0; u < kScanItems; u++) {
+    e[u] = (base + u < n) ? lut[base + u] : kLutEmpty;
+    c += lut_has_record(e[u]) ? 1u : 0u;
+  }
+  // exclusive scan of c over the block: wave scan, then the wave totals
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  unsigned inc = c;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned a = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += a;
+  }
+  if (lane == kWave - 1) s_w[wave] = inc;
+  __syncthreads();
+  unsigned before = tile_base[blockIdx.x];
+  for (int w = 0; w < wave; w++) before += s_w[w];
+  unsigned r_new = before + inc - c;
+#pragma unroll
+  for (int u = 0; u < kScanItems; u++) {
+    if (!lut_has_record(e[u])) continue;
+    const int r_old = (e[u] >= 0) ? e[u] : -(e[u] + 2);
+    const float4* src = reinterpret_cast<const float4*>(recs_in + r_old);
+    float4* dst = reinterpret_cast<float4*>(recs_out + r_new);
+    const float4 a = src[0], b = src[1], cc = src[2], d = src[3];
+    dst[0] = a; dst[1] = b; dst[2] = cc; dst[3] = d;
+    cent_out[r_new] = cent_in[r_old];
+    lut[base + u] = (e[u] >= 0) ? static_cast<int>(r_new) : lut_rejected(static_cast<int>(r_new));
+    r_new++;
+  }
+}
+
 // Leaf arrays of a bucket-form build (ascending cell order: leaf_cell / leaf_start / leaf_count / leaf_rec), written only
 // when somebody asks for them (ndt_grid_dump, getFitnessScore's index, ndt_grid_size): after k1_count has numbered
 // the buckets' occupied cells.
-__global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ bpts, GridGeom g, int shift, int C, int min_pts,
+__global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ bpts, GridGeom g, int map, int C, int min_pts,
                                                     const unsigned* __restrict__ bucket_base, const unsigned* __restrict__ occ_base,
                                                     int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
-                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec) {
+                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec, const int* __restrict__ lut) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) return;
   unsigned* cnt = k1_lds;
-  const int cell0 = k << shift;
-  k1_cell_histogram(bpts, bb, be, g, cell0, C, cnt);
+  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
   const int per = C / kBlock > 0 ? C / kBlock : 1;
   const int lo = threadIdx.x * per;
   U3 t = {0, 0, 0};
@@ -1266,10 +1359,18 @@ __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ b
     const unsigned v = cnt[c];
     if (v > 0) {
       const unsigned o = ob + run.occ;
-      leaf_cell[o] = cell0 + c;
+      leaf_cell[o] = k1_cell(k, c, map);
       leaf_start[o] = bb + run.pts;
       leaf_count[o] = static_cast<int>(v);
-      leaf_rec[o] = (v >= static_cast<unsigned>(min_pts)) ? static_cast<int>((bb + run.pts) / static_cast<unsigned>(min_pts)) : -1;
+      int rec = -1;
+      if (v >= static_cast<unsigned>(min_pts)) {  // the voxel's record: wherever the compaction put it (read back from the table)
+        const int cell = k1_cell(k, c, map);
+        const int cz = cell / g.mul[2], cy = (cell - cz * g.mul[2]) / g.mul[1], cx = cell - cz * g.mul[2] - cy * g.mul[1];
+        const int e = lut[static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * g.pmul[1] +
+                          static_cast<long long>(cz + kLutBorder) * g.pmul[2]];
+        rec = (e >= 0) ? e : (e <= -2 ? -(e + 2) : -1);
+      }
+      leaf_rec[o] = rec;
     }
     run.pts += v;
     run.occ += (v > 0);
@@ -1372,19 +1473,29 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   constexpr int kMaxBuckets = 8192, kMaxCells = 4096;
   if (n_points <= 0 || n_cells <= 0 || n_cells > static_cast<long long>(kMaxBuckets) * kMaxCells) return false;
   // ~1000 points per bucket: a bucket's per-point arrays then live in LDS and there are several blocks per CU
-  // ... and at least a bucket per CU: a small cloud (the mapping nodes' 16 k points) is latency-bound on its fullest bucket
-  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 8; }();
-  const long long k_small = std::min<long long>(4096, n_points / small_div);  // small clouds: crowded cells spread over many blocks
+  // ... and at least a bucket per CU; small clouds (the mapping nodes' 16 k points: latency-bound on their fullest bucket)
+  // get ~256 points per bucket (measured with the interleaved buckets: 16 k / 60 k / 200 k points 41 / 46 / 71 us per build,
+  // against 54 / 74 / 117 us with ~8 points per bucket and 67 / 80 / 100 us for the general chain)
+  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 256; }();
+  const long long k_small = std::min<long long>(4096, n_points / small_div);
   const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / 1024));
-  int C = pow2_ceil((n_cells + k_target - 1) / k_target);
-  static const int min_c = [] { const char* v = getenv("NDT_K1_MIN_C"); return v ? std::max(1, atoi(v)) : 32; }();
-  C = std::max(n_points <= 262144 ? min_c : 32, std::min(kMaxCells, C));
-  while ((n_cells + C - 1) / C > kMaxBuckets) C <<= 1;
-  if (C > kMaxCells) return false;
+  // cells are dealt to the buckets in runs of 2^rb (k1_bucket): K a power of two, C = slots per bucket << rb
+  static const int rb_env = [] { const char* v = getenv("NDT_K1_RUN_BITS"); return v ? std::max(0, std::min(8, atoi(v))) : 3; }();
+  const int rb = rb_env;
+  int K = std::min(kMaxBuckets, pow2_ceil(k_target));
+  const long long runs = (n_cells + (1ll << rb) - 1) >> rb;
+  int C;
+  for (;;) {
+    C = std::max(32, pow2_ceil((runs + K - 1) / K) << rb);
+    if (C <= kMaxCells) break;
+    if (K >= kMaxBuckets) return false;
+    K <<= 1;
+  }
   P.cells_per_bucket = C;
-  P.shift = 0;
-  while ((1 << P.shift) < C) P.shift++;
-  P.n_buckets = static_cast<int>((n_cells + C - 1) / C);
+  int kb = 0;
+  while ((1 << kb) < K) kb++;
+  P.shift = rb | (kb << 8);  // the packed cell <-> (bucket, local) map of the kernels
+  P.n_buckets = K;
   P.pts_per_block = std::max(1024, std::min(16384, pow2_ceil((n_points + 383) / 384)));  // >= one block per CU: the LDS atomics of a block run at ~0.7 G/s
   P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
   return true;
@@ -1417,9 +1528,19 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   return hipGetLastError();
 }
 
+size_t record_compaction_tiles(long long lut_cells) { return static_cast<size_t>((lut_cells + kScanTile - 1) / kScanTile); }
+hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const float4* cent_in, VoxelRec* recs_out,
+                                  float4* cent_out, unsigned* tile_sums, hipStream_t stream) {
+  const int n_tiles = static_cast<int>(record_compaction_tiles(lut_cells));
+  hipLaunchKernelGGL(k_rc_count, dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums);
+  hipLaunchKernelGGL(k_rc_scan, dim3(1), dim3(kBlock), 0, stream, tile_sums, n_tiles, static_cast<unsigned*>(nullptr));
+  hipLaunchKernelGGL(k_rc_apply, dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min_pts, const float4* bpts, const unsigned* bucket_base,
                               unsigned* scratch /* 4 K + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count, int* leaf_rec,
-                              unsigned* counts, hipStream_t stream) {
+                              unsigned* counts, const int* lut, hipStream_t stream) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
   unsigned* ticket = scratch;
   unsigned* tot = scratch + 2;
@@ -1430,7 +1551,7 @@ hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min
   hipLaunchKernelGGL(k1_count, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, K, C,
                      static_cast<unsigned>(min_pts), bucket_base, tot, ticket, occ_base, cand_base, counts);
   hipLaunchKernelGGL(k1_leaves, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, C, min_pts,
-                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec);
+                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec, lut);
   return hipGetLastError();
 }
 

@@ -280,9 +280,6 @@ struct ndt_context {
   DevBuf<float4> map_pts;
   size_t map_n = 0;
   int map_dense = 1;
-  unsigned* k1_feedback = nullptr;  // pinned: {binned, -, -, valid, points in crowded cells} of the previous target build
-  bool k1_feedback_valid = false;
-  int k1_crowded_hint = -1;         // -1 unknown, 0 moderate density (bucket form of K1), 1 crowded voxels (general chain)
   int voxel_index = 0;              // ndt_set_voxel_index: 0 automatic, 1 dense table, 2 sparse (sorted build + hash look-up)
   bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
@@ -333,7 +330,6 @@ struct ndt_context {
     if (host_pub) (void)hipHostFree(host_pub);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (bbox_rows) (void)hipHostFree(bbox_rows);
-    if (k1_feedback) (void)hipHostFree(k1_feedback);
     if (server_host_mbs) (void)(server_mbs_on_device ? hipFree(server_host_mbs) : hipHostFree(server_host_mbs));
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);

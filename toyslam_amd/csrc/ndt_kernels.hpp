@@ -149,7 +149,11 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                                      int* lut, unsigned* counts, hipStream_t stream);
 hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const float4* bpts, const unsigned* bucket_base,
                               unsigned* scratch /* 4 n_buckets + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count,
-                              int* leaf_rec, unsigned* counts, hipStream_t stream);
+                              int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream);
+// records of a bucket-form build -> dense, in ascending cell order (table entries rewritten); tile_sums: record_compaction_tiles words
+size_t record_compaction_tiles(long long lut_cells);
+hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const float4* cent_in, VoxelRec* recs_out,
+                                  float4* cent_out, unsigned* tile_sums, hipStream_t stream);
 
 // repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
