@@ -46,7 +46,7 @@ def launch_path_is_default():
     """False under the development switches that give the launch-per-evaluation path another thread
     partition / operation order than the evaluation server (results then agree to rounding only)."""
     e = os.environ
-    return e.get("NDT_K2_FUSED", "1") != "0" and e.get("NDT_SPIN_WAIT", "1") != "0" and e.get("NDT_K2_VARIANT", "0") == "0"
+    return e.get("NDT_K2_FUSED", "1") != "0" and e.get("NDT_SPIN_WAIT", "1") != "0"
 
 
 def same_transform(a, b):
@@ -393,8 +393,6 @@ def test_profiled_align_is_the_same_align(mods, pair):
     assert np.array_equal(g.getFinalTransformation(), T0) and g.getFinalNumIteration() == it0
     assert n0 + n1 == st0["n_evals"] and n2 == st0["n_hessian_recomputes"] and n0 >= 1 and ms0 > 0
     # mode 2: the persistent kernel of the registration between one event pair
-    if os.environ.get("NDT_K2_VARIANT", "0") != "0":
-        return  # validation builds of the body exist for the launch path only
     g.setEvaluationPath(True)  # (whatever NDT_PERSISTENT says)
     g.profile(2)
     g.profile_read(3)
