@@ -154,13 +154,18 @@ __global__ __launch_bounds__(kBlock) void k_scan_bboxes(const float4* __restrict
       mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, kWave));
     }
   }
-  if ((threadIdx.x & (kWave - 1)) == 0 && mn[0] <= mx[0]) {
+  // one set of atomics per block, not per wave (hundreds of waves meet on the six words of a scan)
+  __shared__ float s_mm[kBlock / kWave][6];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0)
+    for (int k = 0; k < 3; k++) { s_mm[wave][k] = mn[k]; s_mm[wave][3 + k] = mx[k]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = s_mm[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v = (threadIdx.x < 3) ? fminf(v, s_mm[w][threadIdx.x]) : fmaxf(v, s_mm[w][threadIdx.x]);
     int* o = out + 6 * blockIdx.y;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      atomicMin(o + k, enc_f32(mn[k]));
-      atomicMax(o + 3 + k, enc_f32(mx[k]));
-    }
+    if (threadIdx.x < 3) { if (v < INFINITY) atomicMin(o + threadIdx.x, enc_f32(v)); }
+    else if (v > -INFINITY) atomicMax(o + threadIdx.x, enc_f32(v));
   }
 }
 
@@ -383,8 +388,11 @@ __global__ __launch_bounds__(kBlock) void k_presort_large(const float4* __restri
   // about one crowded leaf per block; many leaves without crowded ones: a short pass over leaf_count
   for (int base = blockIdx.x * chunk; base < n_leaves; base += gridDim.x * chunk) {
     __syncthreads();  // s_cnt / s_idx of the previous step are done with
-    if (tid < chunk) s_cnt[tid] = (base + tid < n_leaves) ? leaf_count[base + tid] : 0;
-    __syncthreads();
+    const int mine = (tid < chunk && base + tid < n_leaves) ? leaf_count[base + tid] : 0;
+    if (tid < chunk) s_cnt[tid] = mine;
+    // (the barrier doubles as the vote: most steps of a cloud with ~1 point per cell -- a source scan being ordered -- hold
+    // no crowded leaf at all, and walking their 64 counts one by one was 200 us per 6.4 M leaves)
+    if (!__syncthreads_or(mine > kPresortMin)) continue;
     for (int pick = 0; pick < chunk; pick++) {
       const int cnt = s_cnt[pick];  // uniform across the block
       if (cnt <= kPresortMin) continue;
