@@ -339,7 +339,7 @@ __device__ __forceinline__ int probe_kd(const GridView& gv, int vi, int vj, int 
   const int e = lut_entry(gv, vi, vj, vk, centre, dx, dy, dz);
   if (e == kLutEmpty) return -1;
   const int rix = (e >= 0) ? e : -(e + 2);
-  const float4 c = gv.centroids[rix];
+  const float4 c = *reinterpret_cast<const float4*>(gv.centroids + rix);  // (cx, cy, cz, -)
   float d;
   {
 #pragma clang fp contract(off)
@@ -719,10 +719,12 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
       const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, centre, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
                                   : probe(gv, vi, vj, vk, centre, dx, dy, dz);
       if (rix < 0) continue;
-      const RecRegs r = load_rec(gv.recs, rix);
-      // the record keeps icov in its f32 rounding
-      const double c00 = r.p0.x, c01 = r.p0.y, c02 = r.p2.x, c11 = r.p1.y, c12 = r.p2.y, c22 = r.p3.y;
-      const double x0 = static_cast<double>(tx) - r.mx, x1 = static_cast<double>(ty) - r.my, x2 = static_cast<double>(tz) - r.mz;
+      // mean from the record, the inverse covariance in f64 from the record's side sector (the leaf's icov_, :592)
+      const double* mu = gv.recs[rix].mean;
+      const double* ic = gv.centroids[rix].icov;
+      const double mx = mu[0], my = mu[1], mz = mu[2];
+      const double c00 = ic[0], c01 = ic[1], c02 = ic[2], c11 = ic[3], c12 = ic[4], c22 = ic[5];
+      const double x0 = static_cast<double>(tx) - mx, x1 = static_cast<double>(ty) - my, x2 = static_cast<double>(tz) - mz;
       const double xc0 = (c00 * x0 + c01 * x1) + c02 * x2;
       const double xc1 = (c01 * x0 + c11 * x1) + c12 * x2;
       const double xc2 = (c02 * x0 + c12 * x1) + c22 * x2;

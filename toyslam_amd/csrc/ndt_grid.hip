@@ -400,7 +400,7 @@ ndt_status build_grid(ndt_context* h) {
     HIP_TRY(g->recs.reserve(rec_slots));
     HIP_TRY(g->centroids.reserve(rec_slots));
     DevBuf<ndt::VoxelRec> recs_by_slot;  // as k1_finalize numbers them (gaps, bucket by bucket); compacted into g->recs below
-    DevBuf<float4> centroids_by_slot;
+    DevBuf<ndt::VoxelSide> centroids_by_slot;
     DevBuf<unsigned> tile_sums;
     if (n > 65536) {
       HIP_TRY(recs_by_slot.reserve(rec_slots));

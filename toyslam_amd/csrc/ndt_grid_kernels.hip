@@ -538,7 +538,7 @@ struct VoxelSums {
 // and (dump mode) the per-leaf outputs.  o: leaf ordinal, r: record ordinal (-1: fewer than min_pts points).
 // Returns whether the voxel is valid for the DIRECT searches.
 __device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o, int r, int cell, int min_pts, double eig_ratio,
-                                             VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
+                                             VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                              const GridGeom& geom, const FinalizeDump& dump) {
   // No FMA contraction: the reference target (SSE4.2) never fuses, and its covariance formula (_impl.hpp:329-330)
   // cancels catastrophically when the coordinates are large against the voxel size, so a single fused multiply-add
@@ -622,7 +622,11 @@ __device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o,
       rec.n = cnt;
       rec.pad = 0;
       recs[r] = rec;
-      centroids[r] = make_float4(fx, fy, fz, 0.0f);
+      VoxelSide side;
+      side.cx = fx; side.cy = fy; side.cz = fz; side.pad = 0.0f;
+      side.icov[0] = icov[0][0]; side.icov[1] = icov[0][1]; side.icov[2] = icov[0][2];
+      side.icov[3] = icov[1][1]; side.icov[4] = icov[1][2]; side.icov[5] = icov[2][2];
+      centroids[r] = side;
       const int entry = (nr_points >= min_pts) ? r : lut_rejected(r);
       is_valid = nr_points >= min_pts;
       if (geom.hash_bits) {
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
                                                      const int* __restrict__ leaf_count,
                                                      const int* __restrict__ leaf_rec, int n_leaves_host, const unsigned* __restrict__ d_totals,
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
-                                                     VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
+                                                     VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                      GridGeom geom, unsigned* __restrict__ n_valid, FinalizeDump dump,
                                                      const float4* __restrict__ big_pts, unsigned* __restrict__ crowd) {
   // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
@@ -1005,7 +1009,7 @@ constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells on
 __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
                                                       double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
                                                       int* __restrict__ sorted_idx,
-                                                      VoxelRec* __restrict__ recs, float4* __restrict__ centroids, int* __restrict__ lut,
+                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                       unsigned* __restrict__ n_valid, unsigned* __restrict__ scratch /* 5 x n words */,
                                                       unsigned n_total) {
   extern __shared__ unsigned k1_lds[];
@@ -1301,8 +1305,8 @@ __global__ __launch_bounds__(kBlock) void k_rc_scan(unsigned* __restrict__ tile_
   (void)total_out;
 }
 __global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long long n, const unsigned* __restrict__ tile_base,
-                                                     const VoxelRec* __restrict__ recs_in, const float4* __restrict__ cent_in,
-                                                     VoxelRec* __restrict__ recs_out, float4* __restrict__ cent_out) {
+                                                     const VoxelRec* __restrict__ recs_in, const VoxelSide* __restrict__ cent_in,
+                                                     VoxelRec* __restrict__ recs_out, VoxelSide* __restrict__ cent_out) {
   __shared__ unsigned s_w[kBlock / kWave];
   const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
   int e[kScanItems];
@@ -1333,7 +1337,12 @@ __global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long
     float4* dst = reinterpret_cast<float4*>(recs_out + r_new);
     const float4 a = src[0], b = src[1], cc = src[2], d = src[3];
     dst[0] = a; dst[1] = b; dst[2] = cc; dst[3] = d;
-    cent_out[r_new] = cent_in[r_old];
+    {
+      const float4* cs = reinterpret_cast<const float4*>(cent_in + r_old);
+      float4* cd = reinterpret_cast<float4*>(cent_out + r_new);
+      const float4 s0 = cs[0], s1 = cs[1], s2 = cs[2], s3 = cs[3];
+      cd[0] = s0; cd[1] = s1; cd[2] = s2; cd[3] = s3;
+    }
     lut[base + u] = (e[u] >= 0) ? static_cast<int>(r_new) : lut_rejected(static_cast<int>(r_new));
     r_new++;
   }
@@ -1458,7 +1467,7 @@ hipError_t launch_scatter(const int* d_key, const unsigned* d_rank, int n, const
 
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
-                           int min_pts, double eig_ratio, VoxelRec* d_recs, float4* d_centroids, int* d_lut, const GridGeom& geom,
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, VoxelSide* d_centroids, int* d_lut, const GridGeom& geom,
                            unsigned* d_n_valid, FinalizeDump dump, hipStream_t stream, const unsigned* d_totals, float4* d_big_pts) {
   // d_totals != nullptr: n_leaves is an upper bound (grid size); the kernel reads the count itself
   if (n_leaves == 0) return hipSuccess;
@@ -1510,7 +1519,7 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
 }
 
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& P, int min_pts,
-                                     double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, float4* centroids,
+                                     double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
   const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
@@ -1537,8 +1546,8 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
 }
 
 size_t record_compaction_tiles(long long lut_cells) { return static_cast<size_t>((lut_cells + kScanTile - 1) / kScanTile); }
-hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const float4* cent_in, VoxelRec* recs_out,
-                                  float4* cent_out, unsigned* tile_sums, hipStream_t stream) {
+hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,
+                                  VoxelSide* cent_out, unsigned* tile_sums, hipStream_t stream) {
   const int n_tiles = static_cast<int>(record_compaction_tiles(lut_cells));
   hipLaunchKernelGGL(k_rc_count, dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums);
   hipLaunchKernelGGL(k_rc_scan, dim3(1), dim3(kBlock), 0, stream, tile_sums, n_tiles, static_cast<unsigned*>(nullptr));

@@ -198,7 +198,7 @@ struct DeviceGrid {
   std::shared_ptr<DeviceCloud> target;  // kept for the dump pass
   DevBuf<int> lut;
   DevBuf<ndt::VoxelRec> recs;
-  DevBuf<float4> centroids;  // per record: voxel centroid (KDTREE search)
+  DevBuf<ndt::VoxelSide> centroids;  // per record: voxel centroid (KDTREE search) + f64 inverse covariance
   DevBuf<int> leaf_cell, leaf_count, leaf_rec, sorted_idx;
   DevBuf<unsigned> leaf_start;
   size_t n_sorted = 0;  // target points that landed in a voxel (finite ones)

@@ -371,10 +371,10 @@ __global__ __launch_bounds__(kBlock) void k_calc_score(const float4* __restrict_
     }
     for (int k = 0; k < NNB; k++) {
       if (rec[k] < 0) continue;
-      const RecRegs r = load_rec(gv.recs, rec[k]);
-      const double x0 = static_cast<double>(pt.x) - r.mx, x1 = static_cast<double>(pt.y) - r.my,
-                   x2 = static_cast<double>(pt.z) - r.mz;
-      const double c00 = r.p0.x, c01 = r.p0.y, c02 = r.p2.x, c11 = r.p1.y, c12 = r.p2.y, c22 = r.p3.y;
+      const double* mu = gv.recs[rec[k]].mean;
+      const double* ic = gv.centroids[rec[k]].icov;  // the leaf's f64 icov_ (:966)
+      const double x0 = static_cast<double>(pt.x) - mu[0], x1 = static_cast<double>(pt.y) - mu[1], x2 = static_cast<double>(pt.z) - mu[2];
+      const double c00 = ic[0], c01 = ic[1], c02 = ic[2], c11 = ic[3], c12 = ic[4], c22 = ic[5];
       const double c0 = (c00 * x0 + c01 * x1) + c02 * x2;
       const double c1 = (c01 * x0 + c11 * x1) + c12 * x2;
       const double c2 = (c02 * x0 + c12 * x1) + c22 * x2;

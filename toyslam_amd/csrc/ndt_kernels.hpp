@@ -16,7 +16,7 @@ namespace ndt {
 //           (v_pk_fma_f32 takes both halves of an operand from ONE aligned register pair):
 //             p0 = (c00, c01)   p1 = (c01, c11)   p2 = (c02, c12)   p3 = (c11, c22)
 //           -- c01 and c11 are stored twice so that no pair has to be assembled with moves
-//   n     : point count.  (The voxel centroid, read only by the KDTREE search, lives in GridView::centroids.)
+//   n     : point count.  (The voxel centroid and the f64 inverse covariance live in the side sector, VoxelSide.)
 struct alignas(64) VoxelRec {
   double mean[3];
   float p0[2], p1[2], p2[2], p3[2];
@@ -24,6 +24,14 @@ struct alignas(64) VoxelRec {
   int pad;
 };
 static_assert(sizeof(VoxelRec) == 64, "VoxelRec must be one 64-B sector");
+// What the f32 evaluation does not read, one 64-B sector per record again: the voxel centroid (voxel_centroids_ entry,
+// KDTREE search) and the inverse covariance in f64 -- computeHessian (ndt_omp_impl.hpp:540-645) and calculateScore
+// (:935-983) multiply with the f64 icov_ of the leaf, not with its f32 rounding.  icov: c00 c01 c02 c11 c12 c22.
+struct alignas(64) VoxelSide {
+  float cx, cy, cz, pad;
+  double icov[6];
+};
+static_assert(sizeof(VoxelSide) == 64, "VoxelSide must be one 64-B sector");
 
 // VoxelGridCovariance geometry (voxel_grid_covariance_omp_impl.hpp:87-103).
 struct GridGeom {
@@ -71,7 +79,7 @@ __host__ __device__ inline unsigned hash_slot(int key, int bits) { return (stati
 struct GridView {
   const int* lut;            // padded table, g.lut_cells entries; sparse grids (g.hash_bits > 0): the hash table, int2 slots
   const VoxelRec* recs;      // one record per voxel with >= min_points_per_voxel points
-  const float4* centroids;   // per record: voxel centroid (voxel_centroids_ entry), KDTREE search only
+  const VoxelSide* centroids;  // per record: voxel centroid (KDTREE search) + f64 inverse covariance (f64 Hessian, calculateScore)
   GridGeom g;
 };
 
@@ -145,15 +153,15 @@ struct GridBuildScratch {
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
-                                     double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, float4* centroids,
+                                     double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream);
 hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const float4* bpts, const unsigned* bucket_base,
                               unsigned* scratch /* 4 n_buckets + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count,
                               int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream);
 // records of a bucket-form build -> dense, in ascending cell order (table entries rewritten); tile_sums: record_compaction_tiles words
 size_t record_compaction_tiles(long long lut_cells);
-hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const float4* cent_in, VoxelRec* recs_out,
-                                  float4* cent_out, unsigned* tile_sums, hipStream_t stream);
+hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,
+                                  VoxelSide* cent_out, unsigned* tile_sums, hipStream_t stream);
 
 // repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
@@ -205,7 +213,7 @@ struct FinalizeDump {  // optional per-leaf outputs for ndt_grid_dump
 };
 hipError_t launch_finalize(const float4* pts, const int* d_leaf_cell, const unsigned* d_leaf_start,
                            const int* d_leaf_count, const int* d_leaf_rec, int n_leaves, int* d_sorted_idx,
-                           int min_pts, double eig_ratio, VoxelRec* d_recs, float4* d_centroids, int* d_lut, const GridGeom& geom,
+                           int min_pts, double eig_ratio, VoxelRec* d_recs, VoxelSide* d_centroids, int* d_lut, const GridGeom& geom,
                            unsigned* d_n_valid, FinalizeDump dump, hipStream_t stream, const unsigned* d_totals = nullptr,
                            float4* d_big_pts = nullptr /* n points of scratch: enables the wave pre-sort of crowded leaves */);
 
