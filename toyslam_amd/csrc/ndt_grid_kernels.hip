@@ -533,27 +533,6 @@ struct VoxelSums {
   }
 };
 
-// What k1_finalize leaves per candidate voxel for k1_finish (the second pass of applyFilter in a kernel of its own: the
-// f64 eigen-solve inlined next to the bucket sort cost k1_finalize 232 VGPRs, two blocks per CU and a second round).
-struct VoxelSumRec {
-  double s[9];   // sx sy sz cxx cxy cxz cyy cyz czz
-  float f[3];    // fx fy fz
-  int cnt;
-  int cell;
-  int pad;
-};
-static_assert(sizeof(VoxelSumRec) == 96, "VoxelSumRec layout");
-__device__ __forceinline__ void emit_sums(const VoxelSums& S, int cnt, int cell, int r, VoxelSumRec* __restrict__ sums, int* __restrict__ slot_cell) {
-  VoxelSumRec o;
-  o.s[0] = S.sx; o.s[1] = S.sy; o.s[2] = S.sz; o.s[3] = S.cxx; o.s[4] = S.cxy; o.s[5] = S.cxz; o.s[6] = S.cyy; o.s[7] = S.cyz; o.s[8] = S.czz;
-  o.f[0] = S.fx; o.f[1] = S.fy; o.f[2] = S.fz;
-  o.cnt = cnt;
-  o.cell = cell;
-  o.pad = 0;
-  sums[r] = o;
-  slot_cell[r] = cell;
-}
-
 // Second pass of applyFilter for one voxel (_impl.hpp:282-367): mean, covariance with the reference's quirks, 3x3
 // eigen-solve, eigenvalue inflation, inverse, validity; writes the 64-B record, the centroid, the look-up table slot
 // and (dump mode) the per-leaf outputs.  o: leaf ordinal, r: record ordinal (-1: fewer than min_pts points).
@@ -851,8 +830,7 @@ __device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ sr
 
 // the padded look-up table starts out empty, the control words and the four counters at zero: one launch instead of
 // three hipMemsetAsync calls (each costs the host ~7 us)
-__global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long long lut_cells, int* __restrict__ slot_cell, long long n_slots,
-                                                  unsigned* __restrict__ ctrl, int n_ctrl,
+__global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long long lut_cells, unsigned* __restrict__ ctrl, int n_ctrl,
                                                   unsigned* __restrict__ counts) {
   const long long tid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x, nt = static_cast<long long>(gridDim.x) * kBlock;
   int4* l4 = reinterpret_cast<int4*>(lut);
@@ -860,7 +838,6 @@ __global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long lo
   for (long long i = tid; i < n4; i += nt) l4[i] = make_int4(kLutEmpty, kLutEmpty, kLutEmpty, kLutEmpty);
   for (long long i = n4 * 4 + tid; i < lut_cells; i += nt) lut[i] = kLutEmpty;
   for (long long i = tid; i < n_ctrl; i += nt) ctrl[i] = 0;
-  for (long long i = tid; i < n_slots; i += nt) slot_cell[i] = -1;  // no candidate voxel in this record slot (k1_finish)
   if (tid < 5) counts[tid] = 0;  // [4]: points in crowded cells
 }
 
@@ -1020,6 +997,7 @@ __device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cen
 }
 
 constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
+constexpr unsigned kCrowdedCell = 48;             // a cell with more points counts as crowded (see build_grid's choice of path)
 constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
 // Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
 // three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
@@ -1029,9 +1007,11 @@ constexpr int kTeamCell = 32, kTeamLanes = 16;
 constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
 __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
-                                                      int lds_cap, const unsigned* __restrict__ bucket_base, int* __restrict__ sorted_idx,
-                                                      VoxelSumRec* __restrict__ sums, int* __restrict__ slot_cell,
-                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total) {
+                                                      double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
+                                                      int* __restrict__ sorted_idx,
+                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                      unsigned* __restrict__ n_valid, unsigned* __restrict__ scratch /* 5 x n words */,
+                                                      unsigned n_total) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
@@ -1056,6 +1036,15 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   float* oz = oy + lds_cap;
   k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
   k1_scan_cells(cnt, cstart, C, s_u3);
+  const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned n_ok = 0;
+  {  // how crowded is this cloud?  (points living in cells of more than kCrowdedCell points: the host's hint for the NEXT build)
+    unsigned cp = 0;
+    for (int c = threadIdx.x; c < C; c += kBlock) cp += (cnt[c] > kCrowdedCell) ? cnt[c] : 0u;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cp += __shfl_xor(cp, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && cp) atomicAdd(n_valid + 1, cp);
+  }
   // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
   // bucket of a uniform cloud, several for a crowded one (clustered data: a ground plane fills "its" buckets with many
   // times the mean).  A pass selects its points from the bucket, sorts them by (cell, point index) in LDS and finishes
@@ -1189,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_pass; i++) { const unsigned q = sidx[i]; S.add(px[q], py[q], pz[q]); }
         const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
-        emit_sums(S, static_cast<int>(n_pass), k1_cell(k, c_lo, map), r, sums, slot_cell);
+        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
       c_lo = c_hi;
       __syncthreads();
@@ -1270,30 +1259,17 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       }
-      emit_sums(S, n_c, k1_cell(k, c, map), r, sums, slot_cell);
+      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
   }
-}
-
-// Second pass of applyFilter for the candidate voxels k1_finalize left sums for: one thread per record slot.
-__global__ __launch_bounds__(kBlock) void k1_finish(const VoxelSumRec* __restrict__ sums, const int* __restrict__ slot_cell, int n_slots, GridGeom g,
-                                                    int min_pts, double eig_ratio, VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids,
-                                                    int* __restrict__ lut, unsigned* __restrict__ n_valid) {
-  const int r = blockIdx.x * kBlock + threadIdx.x;
-  unsigned ok = 0;
-  if (r < n_slots && slot_cell[r] >= 0) {
-    const VoxelSumRec in = sums[r];
-    VoxelSums S;
-    S.sx = in.s[0]; S.sy = in.s[1]; S.sz = in.s[2]; S.cxx = in.s[3]; S.cxy = in.s[4]; S.cxz = in.s[5]; S.cyy = in.s[6]; S.cyz = in.s[7]; S.czz = in.s[8];
-    S.fx = in.f[0]; S.fy = in.f[1]; S.fz = in.f[2];
-    const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
-    ok = finish_voxel(S, in.cnt, 0, r, in.cell, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
-  }
+  {  // one counter update per wave
+    unsigned v = n_ok;
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) ok += __shfl_xor(ok, off, kWave);
-  if ((threadIdx.x & (kWave - 1)) == 0 && ok) atomicAdd(n_valid, ok);
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(n_valid, v);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1547,9 +1523,8 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                                      int* lut, unsigned* counts, hipStream_t stream) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
   const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
-  const long long n_slots = static_cast<long long>(n) / std::max(1, min_pts) + 1;  // record slot = segment start / min_pts
   hipLaunchKernelGGL(k1_init, dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>(2048, g.lut_cells / (4 * kBlock) + 1)))), dim3(kBlock), 0,
-                     stream, lut, g.lut_cells, S.slot_cell, n_slots, S.tickets, 4 + K, counts);
+                     stream, lut, g.lut_cells, S.tickets, 4 + K, counts);
   hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
                      S.bucket_count, S.blockbase, S.tickets, S.bucket_base, counts);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
@@ -1565,10 +1540,8 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
   if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
-                     S.bpts, g, P.shift, K, C, min_pts, lds_cap, S.bucket_base, sorted_idx, static_cast<VoxelSumRec*>(S.sums), S.slot_cell, S.order,
-                     static_cast<unsigned>(n));
-  hipLaunchKernelGGL(k1_finish, dim3(static_cast<unsigned>((n_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                     static_cast<const VoxelSumRec*>(S.sums), S.slot_cell, static_cast<int>(n_slots), g, min_pts, eig_ratio, recs, centroids, lut, counts + 3);
+                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut, counts + 3,
+                     S.order, static_cast<unsigned>(n));
   return hipGetLastError();
 }
 

@@ -149,10 +149,7 @@ struct GridBuildScratch {
   unsigned* blockbase;     // [n_blocks x n_buckets]
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
   unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
-  void* sums;              // [n / min_pts + 1] x kVoxelSumBytes: what k1_finalize leaves per candidate voxel for k1_finish
-  int* slot_cell;          // [n / min_pts + 1]: the slot's voxel, -1 none
 };
-constexpr size_t kVoxelSumBytes = 96;
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
