@@ -587,6 +587,13 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
           RecRegs nxt = cur;
+#ifdef NDT_THROUGHPUT_UNIT
+          // Throughput kernels (ndt_kernels.hip: batches): keep the compiler from hoisting all seven record loads to the top
+          // of the point -- with two records in flight instead of seven the with-Hessian kernel needs 126 VGPRs instead of
+          // 207, four waves per SIMD instead of two, and a 512-scan map build runs 13 % faster.  The latency unit (one block
+          // per CU by design) keeps every load in flight.
+          if (WANT_H) asm volatile("" ::: "memory");
+#endif
           if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
           if (rec[k] >= 0) {
             // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)

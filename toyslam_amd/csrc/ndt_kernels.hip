@@ -12,6 +12,7 @@
 // voxel record), the LUT probe + record gather is served from L2 / Infinity Cache for the target sizes of interest, and the
 // 29 f64 accumulators are reduced with a VALU-only wave64 fold, then LDS across the waves of a block, then a fixed-order
 // sum over the blocks.
+#define NDT_THROUGHPUT_UNIT 1  // see derivatives_body: records in flight per point
 #include "ndt_device.hpp"
 #include "ndt_search.hpp"
 
@@ -145,7 +146,9 @@ __global__ __launch_bounds__(kBlock) void k_hessian64(const float4* __restrict__
 }
 
 // One launch for a lock-step batch step in which the scans ask for DIFFERENT kinds of evaluation
-// (late in a batch: a few scans still in their line search, some recomputing the f64 Hessian).
+// (late in a batch: a few scans still in their line search, some recomputing the f64 Hessian).  (Measured: giving the f64
+// scans a launch of their own takes this kernel from 152 to 126 VGPRs -- four waves per SIMD instead of three -- but the
+// extra ~28 us launch in most tail steps costs more than that buys: 6.05k instead of 6.4k reg/s on the 512-scan build.)
 // grid.y walks all live scans; the kind is block-uniform (read from the scan's descriptor).  Three
 // separate launches of the specialised kernels serialise and each pays its own ramp-up; steps in which
 // every live scan wants the same kind keep using those.
