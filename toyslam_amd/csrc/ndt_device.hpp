@@ -548,7 +548,14 @@ __device__ __forceinline__ unsigned long long stamp() {
 // PRELOADED: the caller already holds src[first] (the evaluation server keeps each lane's first point in registers
 // across rounds: the scan does not change between the evaluations of a registration, and the load would otherwise
 // head every round's dependent chain)
-template <int NNB, bool WANT_H, bool STAMP = false, bool PRELOADED = false>
+#ifdef NDT_THROUGHPUT_UNIT
+constexpr bool kLimitRecordLoads = true;
+#else
+constexpr bool kLimitRecordLoads = false;
+#endif
+// LIMIT: at most two voxel records in flight per point (see the neighbour loop): the throughput kernels and the one-launch
+// kernel of the launch path, whose blocks share CUs with other blocks; not the evaluation server (one block per CU).
+template <int NNB, bool WANT_H, bool STAMP = false, bool PRELOADED = false, bool LIMIT = kLimitRecordLoads>
 __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const EvalParams& prm,
                                                  const PackedTables& tab, int first, int stride, double (&acc)[kNumAcc],
                                                  unsigned long long* st = nullptr, float4 first_pt = float4{0.f, 0.f, 0.f, 0.f}) {
@@ -587,13 +594,11 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
           RecRegs nxt = cur;
-#ifdef NDT_THROUGHPUT_UNIT
-          // Throughput kernels (ndt_kernels.hip: batches): keep the compiler from hoisting all seven record loads to the top
-          // of the point -- with two records in flight instead of seven the with-Hessian kernel needs 126 VGPRs instead of
-          // 207, four waves per SIMD instead of two, and a 512-scan map build runs 13 % faster.  The latency unit (one block
-          // per CU by design) keeps every load in flight.
-          if (WANT_H) asm volatile("" ::: "memory");
-#endif
+          // LIMIT: keep the compiler from hoisting all seven record loads to the top of the point -- with two records in
+          // flight instead of seven the with-Hessian kernel needs 126 VGPRs instead of 207, four waves per SIMD instead of
+          // two, and a 512-scan map build runs 9-13 % faster.  The evaluation server (one block per CU by design) keeps
+          // every load in flight: limited, a 2M-point registration through it is 11 % slower.
+          if (LIMIT && WANT_H) asm volatile("" ::: "memory");
           if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
           if (rec[k] >= 0) {
             // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
