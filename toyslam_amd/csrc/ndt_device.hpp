@@ -728,6 +728,9 @@ __device__ __forceinline__ void hessian64_body(const float4* __restrict__ src, i
     for (int k = 0; k < NNB; k++) {
       int dx, dy, dz;
       nb_offset<NNB>(k, dx, dy, dz);
+      // (throughput unit: one neighbour's nine f64 words at a time -- hoisted to the top of the point, the seven
+      // neighbours' loads alone are 126 VGPRs, and the mixed batch kernel that contains this body is sized by it)
+      if (kLimitRecordLoads) asm volatile("" ::: "memory");
       const int rix = (NNB == 27) ? probe_kd(gv, vi, vj, vk, centre, dx, dy, dz, tx, ty, tz, static_cast<float>(prm.r2))
                                   : probe(gv, vi, vj, vk, centre, dx, dy, dz);
       if (rix < 0) continue;
