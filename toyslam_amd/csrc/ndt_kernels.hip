@@ -406,7 +406,7 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 int derivative_variant() { return 0; }  // (the development variants of round 1 are gone: one body, spelled out by hand)
-// blocks a scan of n points is walked by inside a lock-step batch: four points per thread (the wave fold and the block
+// blocks a scan of n points is walked by inside a lock-step batch: two points per thread (the wave fold and the block
 // epilogue are paid once per thread), a function of the scan's size only
 int batch_blocks(int n) { return max(1, (n + kBatchPointsPerBlock - 1) / kBatchPointsPerBlock); }
 int derivative_blocks(int n, int search) {
