@@ -639,6 +639,7 @@ __device__ __forceinline__ void derivatives_body_kd(const float4* __restrict__ s
     for (int a = -1; a <= 1; a++)
       for (int b = -1; b <= 1; b++)
         for (int c = -1; c <= 1; c++) {
+          if (kLimitRecordLoads) asm volatile("" ::: "memory");  // one cell's probe / centroid / record loads at a time (VGPRs)
           const int rix = probe_kd(gv, vi, vj, vk, centre, a, b, c, tx, ty, tz, r2);
           if (rix < 0) continue;
           const RecRegs r = load_rec(gv.recs, rix);
