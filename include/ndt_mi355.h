@@ -291,7 +291,7 @@ ndt_status ndt_profile_enable(ndt_handle h, int on);
  * per evaluation through a pinned mailbox; 0 = one kernel launch per evaluation.  Both run the same
  * device code over the same thread partition and return bit-identical results (tests pin that);
  * the setting only trades latency.  The NDT_PERSISTENT environment variable sets the default.
- * By default (neither this call nor the variable) a registration that starts while another ndt_align of this process is
+ * Unless this call has insisted on 1, a registration that starts while another ndt_align of this process is
  * in flight on the same device uses the launch path: the persistent kernel holds its CUs for a whole registration, so
  * concurrent callers would otherwise take turns at it; calling this with 1 insists on the persistent kernel. */
 ndt_status ndt_set_evaluation_path(ndt_handle h, int persistent);
