@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
                                                      int* __restrict__ sorted_idx, int min_pts, double eig_ratio,
                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                      GridGeom geom, unsigned* __restrict__ n_valid, FinalizeDump dump,
-                                                     const float4* __restrict__ big_pts, unsigned* __restrict__ crowd) {
+                                                     const float4* __restrict__ big_pts, unsigned* __restrict__ /*unused*/) {
   // No FMA contraction anywhere in this kernel: the reference target (SSE4.2) never fuses, and its
   // covariance formula (_impl.hpp:329-330) cancels catastrophically when the coordinates are large
   // against the voxel size (sum of squares ~ n x^2 against a spread of millimetres), so a single fused
@@ -742,12 +742,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
     const unsigned long long vm = __ballot(is_valid);
     if (vm != 0 && (threadIdx.x & (kWave - 1)) == static_cast<unsigned>(__ffsll(static_cast<long long>(vm)) - 1))
       atomicAdd(n_valid, static_cast<unsigned>(__popcll(vm)));
-    if (crowd) {  // points in crowded cells (the host's hint for the next build's choice of path)
-      unsigned cp = (static_cast<unsigned>(cnt) > 48u) ? static_cast<unsigned>(cnt) : 0u;
-#pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) cp += __shfl_xor(cp, off, kWave);
-      if ((threadIdx.x & (kWave - 1)) == 0 && cp) atomicAdd(crowd, cp);
-    }
   }
 }
 
@@ -997,7 +991,6 @@ __device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cen
 }
 
 constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
-constexpr unsigned kCrowdedCell = 48;             // a cell with more points counts as crowded (see build_grid's choice of path)
 constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
 // Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
 // three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
@@ -1038,13 +1031,6 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   k1_scan_cells(cnt, cstart, C, s_u3);
   const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
-  {  // how crowded is this cloud?  (points living in cells of more than kCrowdedCell points: the host's hint for the NEXT build)
-    unsigned cp = 0;
-    for (int c = threadIdx.x; c < C; c += kBlock) cp += (cnt[c] > kCrowdedCell) ? cnt[c] : 0u;
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) cp += __shfl_xor(cp, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && cp) atomicAdd(n_valid + 1, cp);
-  }
   // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
   // bucket of a uniform cloud, several for a crowded one (clustered data: a ground plane fills "its" buckets with many
   // times the mean).  A pass selects its points from the bucket, sorts them by (cell, point index) in LDS and finishes
@@ -1534,7 +1520,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
   // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
   const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
-  int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));  // a power of two: the bitonic sort of a crowded pass
+  int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));
   if (K <= 512 || n <= 262144) lds_cap = kK1LdsCap;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
   while (lds_cap > 256 && lds_cap > (60 * 1024 / 4 - 3 * C) / 5) lds_cap >>= 1;
   static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
