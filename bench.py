@@ -553,7 +553,8 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                        "kernel": ("k_eval_server<DIRECT7> (persistent: all evaluations of one registration, "
                                   "their reductions, the f64 Hessian recompute and the output transform)") if server_used else
-                                 "k_derivatives_fused<DIRECT7> (one launch per evaluation: NDT_PERSISTENT=0)",
+                                 "k_derivatives_fused<DIRECT7> (one launch per evaluation: the launch path -- the library's choice for scans of "
+                                 "1.5M points and more, or NDT_PERSISTENT=0)",
                        "avg_kernel_us": avg_s * 1e6, "launches_timed": n_launch,
                        "evaluations_per_launch": evals_per_launch,
                        "algorithmic_bytes_per_evaluation": bytes_per_eval,
