@@ -420,7 +420,7 @@ ndt_status build_grid(ndt_context* h) {
     S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
     S.order = order.p;
-    // Records dense and in ascending cell order (launch_compact_records: three small launches, ~25 us) pay for themselves as
+    // Records dense and in ascending cell order (launch_compact_records: two small launches, ~13 us) pay for themselves as
     // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
     // The mapping nodes' clouds (16 k points, one registration of ~6 evaluations per target, records that fit L2 many
     // times over) keep k1_finalize's own numbering.

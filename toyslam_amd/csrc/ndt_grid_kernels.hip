@@ -1263,17 +1263,22 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
 // order (unique without a scan over voxels) -- slots with gaps, bucket by bucket.  The evaluation kernels gather records
 // through the look-up table for points that arrive in lattice order, and they run measurably faster (+5 % on the headline
 // registration) when the records are dense and in ascending cell order, as the general chain leaves them: neighbouring
-// voxels then share cache lines and a wave's gathers walk the array forwards.  Three small launches over the padded
-// table: count the records per tile, scan the tile sums, then give every record its ordinal in table order, move the
-// 64-B record + centroid there and rewrite the table entry.
+// voxels then share cache lines and a wave's gathers walk the array forwards.  Two launches over the padded table (three
+// for tables of more than kRcPrefixTiles tiles): count the records per tile; then every block sums the counts before its
+// own tile, gives the tile's records their ordinals in table order, moves the 64-B records + side sectors there and
+// rewrites the table entries.  (Measured and dropped: counting per tile from k1_finalize with one atomic per voxel --
+// 100 k atomics on 512 addresses took k1_finalize from 42 to 97 us; a single launch with a block ticket and look-back
+// over published tile counts -- the 512 same-address ticket atomics alone cost 10 us.)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool lut_has_record(int e) { return e >= 0 || e <= -2; }
+// records per tile of 256 x ITEMS table entries
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void k_rc_count(const int* __restrict__ lut, long long n, unsigned* __restrict__ tile_sums) {
   __shared__ unsigned s_w[kBlock / kWave];
-  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
+  const long long base = (static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x) * ITEMS;
   unsigned c = 0;
 #pragma unroll
-  for (int u = 0; u < kScanItems; u++) c += (base + u < n && lut_has_record(lut[base + u])) ? 1u : 0u;
+  for (int u = 0; u < ITEMS; u++) c += (base + u < n && lut_has_record(lut[base + u])) ? 1u : 0u;
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_xor(c, off, kWave);
   if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = c;
@@ -1284,26 +1289,41 @@ __global__ __launch_bounds__(kBlock) void k_rc_count(const int* __restrict__ lut
     tile_sums[blockIdx.x] = t;
   }
 }
-// exclusive scan of the tile sums in place, by one block; total -> total_out[0]
-__global__ __launch_bounds__(kBlock) void k_rc_scan(unsigned* __restrict__ tile_sums, int n_tiles, unsigned* __restrict__ total_out) {
+// big tables (more than kRcPrefixTiles tiles): exclusive scan of the tile sums in place, by one block
+__global__ __launch_bounds__(kBlock) void k_rc_scan(unsigned* __restrict__ tile_sums, int n_tiles) {
   __shared__ unsigned s_scan[kBlock / kWave];
   block_scan_array(tile_sums, tile_sums, n_tiles, kBlock, s_scan, false);
-  (void)total_out;
 }
-__global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long long n, const unsigned* __restrict__ tile_base,
+// One tile per block.  SCANNED: tile_sums[] already holds the tiles' first record ordinals (k_rc_scan); otherwise the block
+// adds up the counts of the tiles before its own (at most kRcPrefixTiles words, out of L2).
+template <int ITEMS, bool SCANNED>
+__global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long long n, const unsigned* __restrict__ tile_sums,
                                                      const VoxelRec* __restrict__ recs_in, const VoxelSide* __restrict__ cent_in,
                                                      VoxelRec* __restrict__ recs_out, VoxelSide* __restrict__ cent_out) {
-  __shared__ unsigned s_w[kBlock / kWave];
-  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
-  int e[kScanItems];
-  unsigned c = 0;
-#pragma unroll
-  for (int u = 0; u < kScanItems; u++) {
-    e[u] = (base + u < n) ? lut[base + u] : kLutEmpty;
-    c += lut_has_record(e[u]) ? 1u : 0u;
-  }
-  // exclusive scan of c over the block: wave scan, then the wave totals
+  __shared__ unsigned s_w[kBlock / kWave], s_pre[kBlock / kWave];
+  __shared__ int s_old[kBlock * ITEMS];  // old slot of the tile's k-th record
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (!SCANNED) {
+    unsigned pre = 0;
+    for (unsigned t = threadIdx.x; t < blockIdx.x; t += kBlock) pre += tile_sums[t];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) pre += __shfl_xor(pre, off, kWave);
+    if (lane == 0) s_pre[wave] = pre;
+  }
+  const long long base = (static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x) * ITEMS;
+  int e[ITEMS];
+  unsigned c = 0;
+  if (ITEMS == 8 && base + ITEMS <= n) {  // (base is a multiple of ITEMS: two aligned 16-B loads)
+    const int4 lo = *reinterpret_cast<const int4*>(lut + base), hi = *reinterpret_cast<const int4*>(lut + base + 4);
+    e[0] = lo.x; e[1 % ITEMS] = lo.y; e[2 % ITEMS] = lo.z; e[3 % ITEMS] = lo.w;
+    e[4 % ITEMS] = hi.x; e[5 % ITEMS] = hi.y; e[6 % ITEMS] = hi.z; e[7 % ITEMS] = hi.w;
+  } else {
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) e[u] = (base + u < n) ? lut[base + u] : kLutEmpty;
+  }
+#pragma unroll
+  for (int u = 0; u < ITEMS; u++) c += lut_has_record(e[u]) ? 1u : 0u;
+  // exclusive scan of c over the block: wave scan, then the wave totals
   unsigned inc = c;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
@@ -1312,25 +1332,34 @@ __global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long
   }
   if (lane == kWave - 1) s_w[wave] = inc;
   __syncthreads();
-  unsigned before = tile_base[blockIdx.x];
-  for (int w = 0; w < wave; w++) before += s_w[w];
-  unsigned r_new = before + inc - c;
+  unsigned before = 0, total = 0, first = 0;
 #pragma unroll
-  for (int u = 0; u < kScanItems; u++) {
+  for (int w = 0; w < kBlock / kWave; w++) {
+    if (w < wave) before += s_w[w];
+    total += s_w[w];
+    if (!SCANNED) first += s_pre[w];
+  }
+  if (SCANNED) first = tile_sums[blockIdx.x];
+  unsigned k = before + inc - c;  // ordinal inside the tile
+#pragma unroll
+  for (int u = 0; u < ITEMS; u++) {
     if (!lut_has_record(e[u])) continue;
-    const int r_old = (e[u] >= 0) ? e[u] : -(e[u] + 2);
-    const float4* src = reinterpret_cast<const float4*>(recs_in + r_old);
-    float4* dst = reinterpret_cast<float4*>(recs_out + r_new);
-    const float4 a = src[0], b = src[1], cc = src[2], d = src[3];
-    dst[0] = a; dst[1] = b; dst[2] = cc; dst[3] = d;
-    {
-      const float4* cs = reinterpret_cast<const float4*>(cent_in + r_old);
-      float4* cd = reinterpret_cast<float4*>(cent_out + r_new);
-      const float4 s0 = cs[0], s1 = cs[1], s2 = cs[2], s3 = cs[3];
-      cd[0] = s0; cd[1] = s1; cd[2] = s2; cd[3] = s3;
-    }
-    lut[base + u] = (e[u] >= 0) ? static_cast<int>(r_new) : lut_rejected(static_cast<int>(r_new));
-    r_new++;
+    s_old[k] = (e[u] >= 0) ? e[u] : -(e[u] + 2);
+    const int r_new = static_cast<int>(first + k);
+    lut[base + u] = (e[u] >= 0) ? r_new : lut_rejected(r_new);
+    k++;
+  }
+  __syncthreads();
+  // the moves, four lanes per 64-B record: a wave writes 1 KiB of consecutive bytes
+  const float4* rin = reinterpret_cast<const float4*>(recs_in);
+  const float4* cin = reinterpret_cast<const float4*>(cent_in);
+  float4* rout = reinterpret_cast<float4*>(recs_out) + static_cast<size_t>(first) * 4;
+  float4* cout = reinterpret_cast<float4*>(cent_out) + static_cast<size_t>(first) * 4;
+  for (unsigned j = threadIdx.x; j < total * 4; j += kBlock) {
+    const size_t from = static_cast<size_t>(s_old[j >> 2]) * 4 + (j & 3);
+    const float4 a = rin[from], b = cin[from];
+    rout[j] = a;
+    cout[j] = b;
   }
 }
 
@@ -1531,13 +1560,38 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   return hipGetLastError();
 }
 
-size_t record_compaction_tiles(long long lut_cells) { return static_cast<size_t>((lut_cells + kScanTile - 1) / kScanTile); }
+// tile of the record compaction: 256 x ITEMS table entries, ITEMS in {1, 2, 4, 8} so that a table of a few 100 k cells still
+// gives every CU a block (64 blocks of 2048 records each were 18 of the build's 125 us at 1 M points)
+constexpr int kRcPrefixTiles = 2048;
+static int rc_items(long long lut_cells) {
+  int items = 1;
+  while (items < 8 && lut_cells / (static_cast<long long>(kBlock) * items) >= kRcPrefixTiles) items <<= 1;
+  return items;
+}
+size_t record_compaction_tiles(long long lut_cells) {
+  const long long tile = static_cast<long long>(kBlock) * rc_items(lut_cells);
+  return static_cast<size_t>((lut_cells + tile - 1) / tile);
+}
+template <int ITEMS>
+static void launch_rc(int n_tiles, hipStream_t stream, int* lut, long long lut_cells, unsigned* tile_sums, const VoxelRec* recs_in,
+                      const VoxelSide* cent_in, VoxelRec* recs_out, VoxelSide* cent_out) {
+  hipLaunchKernelGGL((k_rc_count<ITEMS>), dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums);
+  if (n_tiles > kRcPrefixTiles) {
+    hipLaunchKernelGGL(k_rc_scan, dim3(1), dim3(kBlock), 0, stream, tile_sums, n_tiles);
+    hipLaunchKernelGGL((k_rc_apply<ITEMS, true>), dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out);
+  } else {
+    hipLaunchKernelGGL((k_rc_apply<ITEMS, false>), dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out);
+  }
+}
 hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,
                                   VoxelSide* cent_out, unsigned* tile_sums, hipStream_t stream) {
   const int n_tiles = static_cast<int>(record_compaction_tiles(lut_cells));
-  hipLaunchKernelGGL(k_rc_count, dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums);
-  hipLaunchKernelGGL(k_rc_scan, dim3(1), dim3(kBlock), 0, stream, tile_sums, n_tiles, static_cast<unsigned*>(nullptr));
-  hipLaunchKernelGGL(k_rc_apply, dim3(n_tiles), dim3(kBlock), 0, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out);
+  switch (rc_items(lut_cells)) {
+    case 1: launch_rc<1>(n_tiles, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out); break;
+    case 2: launch_rc<2>(n_tiles, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out); break;
+    case 4: launch_rc<4>(n_tiles, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out); break;
+    default: launch_rc<8>(n_tiles, stream, lut, lut_cells, tile_sums, recs_in, cent_in, recs_out, cent_out); break;
+  }
   return hipGetLastError();
 }
 
