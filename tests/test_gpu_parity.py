@@ -100,6 +100,70 @@ def test_grid_bit_exact_indices_and_sums(mods, pair, golden_grid):
     assert np.array_equal(gg["idx"], golden_grid["idx"]) and np.array_equal(gg["mean"], golden_grid["mean"])
 
 
+class _DeviceCopies:
+    """float32 arrays copied to HBM through the HIP runtime the library itself is linked to (not torch's bundled copy: in a
+    process where the library touched the device first, torch's runtime instance finds no GPU)."""
+
+    def __init__(self):
+        import ctypes as C
+        import re
+        from toyslam_amd import _lib
+        assert _lib.lib() is not None
+        linked = [m.group(1) for m in re.finditer(r"(/\S*libamdhip64\.so[.\d]*)", open("/proc/self/maps").read()) if "/torch/" not in m.group(1)]
+        self.C, self.held = C, []
+        self.hip = C.CDLL(linked[0] if linked else "libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+
+    def put(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        p = self.C.c_void_p()
+        assert self.hip.hipMalloc(self.C.byref(p), max(a.nbytes, 16)) == 0
+        assert self.hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        self.held.append(p)
+        return p.value
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for p in self.held:
+            self.hip.hipFree(p)
+
+
+@pytest.mark.parametrize("n,floats,dense", [(1, 3, 1), (777, 3, 0), (20000, 4, 1), (20000, 8, 0), (32768, 3, 0), (5000, 5, 1)])
+def test_small_host_clouds_route_equals_device_route(mods, n, floats, dense):
+    """Host clouds of up to 32 768 points are repacked and bounded on the host (upload_cloud: no repack kernel, no wait);
+    the same records handed over in HBM go through k_repack_bbox.  Both must give the same boxes and the same grid, with NaN /
+    inf coordinates, any record stride and garbage behind xyz."""
+    ndt, _, _ = mods
+    rng = np.random.default_rng(1000 + n + floats)
+    rec = rng.uniform(-1e3, 1e3, (n, floats)).astype(np.float32)  # (whatever follows xyz in a record must not matter)
+    rec[:, :3] = rng.uniform(-25, 25, (n, 3)).astype(np.float32) * np.array([1, 1, 0.2], np.float32)
+    if n > 100:
+        rec[3, 0] = np.nan
+        if not dense:  # (a dense cloud's box takes infinite coordinates as they are: "voxel grid too large" on either route)
+            rec[7, 1] = np.inf
+            rec[9, 2] = -np.inf
+        rec[11, :3] = np.nan
+        rec[n - 1, 1] = np.nan  # the last record (12-B records: read without leaving the buffer)
+    gh, gd = ndt.NormalDistributionsTransform(), ndt.NormalDistributionsTransform()
+    with _DeviceCopies() as dc:
+        gh.setInputTarget(rec, is_dense=bool(dense))
+        gd.setInputTargetDevice(dc.put(rec), n, floats * 4, is_dense=bool(dense))
+        a, b = gh.grid(), gd.grid()
+        for k in ("min_b", "max_b", "div_b", "idx", "n", "mean", "cov", "icov"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        # and as a source: the same evaluation
+        src = rec[: max(1, n // 2)].copy()
+        gh.setInputSource(src)
+        gd.setInputSourceDevice(dc.put(src), len(src), floats * 4)
+        p = np.array([0.1, -0.05, 0.02, 0.01, -0.02, 0.03])
+        (sh, gh_, Hh, nh), (sd, gd_, Hd, nd_) = gh.eval(p), gd.eval(p)
+        assert sh == sd and nh == nd_ and np.array_equal(gh_, gd_) and np.array_equal(Hh, Hd)
+
+
 @pytest.mark.parametrize("res", [0.5, 2.0])
 def test_grid_other_resolutions(mods, pair, res):
     t, s = pair

@@ -226,7 +226,7 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
 
   std::vector<ndt::ScanSolver> solvers(total);
   // per-step descriptors live in pinned host memory: the H2D copies are then truly asynchronous
-  const size_t pinned_need = total * sizeof(ndt::ScanDesc) + 4 * total * sizeof(int);  // + per-kind and all-kinds active lists
+  const size_t pinned_need = (total * sizeof(ndt::ScanDesc) + 4 * total * sizeof(int) + 15) & ~static_cast<size_t>(15);  // + per-kind and all-kinds active lists; whole 16-B words
   if (pinned_need > h->batch_pinned_bytes) {
     if (h->batch_pinned) (void)hipHostFree(h->batch_pinned);
     h->batch_pinned = nullptr;
@@ -310,7 +310,10 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       std::memset(h->host_result, 0, total * ndt::kEvalStride * sizeof(double));
     } else {
       // one H2D copy: descriptors and the three active lists are contiguous in the pinned block
-      HIP_TRY(hipMemcpyAsync(h->descs.p, descs, pinned_need, hipMemcpyHostToDevice, h->stream));
+      // (by a kernel reading the page-locked block: a few KB are in HBM before a DMA engine would have started)
+      static const bool desc_dma = [] { const char* v = getenv("NDT_BATCH_DESC_DMA"); return v && atoi(v) != 0; }();
+      if (desc_dma) HIP_TRY(hipMemcpyAsync(h->descs.p, descs, pinned_need, hipMemcpyHostToDevice, h->stream));
+      else HIP_TRY(ndt::launch_copy_records(reinterpret_cast<const float4*>(descs), reinterpret_cast<float4*>(h->descs.p), static_cast<int>(pinned_need / 16), h->stream));
       const int* d_active = reinterpret_cast<const int*>(h->descs.p + total);
       ndt::EvalParams dummy = {};
       ndt::Hess64Params dummy64 = {};

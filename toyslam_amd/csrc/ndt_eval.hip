@@ -241,8 +241,19 @@ ndt_status server_start(ndt_context* h) {
   h->server_host_mb = static_cast<unsigned char*>(h->server_host_mbs) + h->server_flip * mb_bytes;
   ndt::server_reset_mailbox(h->server_host_mb);
   void* dev_mb = h->server_dev_mb.p + h->server_flip * mb_bytes;
-  HIP_TRY(h->server_counter.reserve(32 * (1 + ndt::kServerParts)));  // one shard counter per 128-B line
-  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * (1 + ndt::kServerParts) * sizeof(unsigned), h->stream));
+  // two sets of shard counters (one per 128-B line), used alternately: a launch zeroes the set of the next one
+  {
+    const unsigned* before = h->server_counter.p;
+    HIP_TRY(h->server_counter.reserve(2 * ndt::kServerCounterWords));
+    if (h->server_counter.p != before) {  // fresh storage
+      HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 2 * ndt::kServerCounterWords * sizeof(unsigned), h->stream));
+      h->server_counter_set = 0;
+    } else {
+      h->server_counter_set ^= 1;
+    }
+  }
+  unsigned* const counter_now = h->server_counter.p + h->server_counter_set * ndt::kServerCounterWords;
+  unsigned* const counter_next = h->server_counter.p + (h->server_counter_set ^ 1) * ndt::kServerCounterWords;
   // one 512-thread block per CU at most: every block must be resident for the round to complete
   const int ppb = ndt::points_per_block(n);
   int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + ppb - 1) / ppb));
@@ -259,11 +270,11 @@ ndt_status server_start(ndt_context* h) {
   h->server_timed = h->profile_server;
   if (h->server_timed) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
-                                  h->partials.p, h->server_counter.p, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
+                                  h->partials.p, counter_now, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
                                   h->server_want_dbg ? h->server_dbg.p : nullptr,
                                   (h->server_mbs_on_device && !(std::getenv("NDT_SERVER_DIRECT") && std::atoi(std::getenv("NDT_SERVER_DIRECT")) == 0)) ? 1 : 0,
-                                  h->server_out_host));
+                                  h->server_out_host, counter_next));
   h->server_wrote_host = h->server_out_host != nullptr;
   undo.armed = false;
   return NDT_OK;
@@ -583,7 +594,7 @@ ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double*
   HIP_TRY(mb.reserve(mb_bytes));
   HIP_TRY(parts.reserve(static_cast<size_t>(ndt::kServerParts) * ndt::kEvalStride));
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
-  HIP_TRY(h->server_counter.reserve(32 * (1 + ndt::kServerParts)));
+  HIP_TRY(h->server_counter.reserve(2 * ndt::kServerCounterWords));
   HIP_TRY(ensure_host_rows(h, 1) == NDT_OK ? hipSuccess : hipErrorOutOfMemory);
   const ndt::Gauss gs = ndt::gauss_constants(h->resolution, h->outlier_ratio);
   const float r2 = kd_radius2(h->resolution);
@@ -617,6 +628,9 @@ ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double*
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  // (the evaluation server expects both of its counter sets at zero)
+  HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 2 * ndt::kServerCounterWords * sizeof(unsigned), h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   // the last round's row must be what the evaluation paths compute at this pose (the caller compares with ndt_eval)
   if (!pub_ready(h->host_pub, h->eval_seq)) return fail(NDT_ERR_HIP, "self-driven rounds did not publish their last row");
   pub_gather(h->host_pub, h->host_result);

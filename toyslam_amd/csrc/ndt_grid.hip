@@ -3,9 +3,43 @@
 // (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
 #include "ndt_internal.hpp"
 
+#include <emmintrin.h>
+
 #include <type_traits>
 
 namespace ndtc {
+
+// Host counterpart of k_repack_bbox for small clouds: records of `stride` bytes (x y z first) -> dense (x, y, z, 1) in dst,
+// and the two bounding boxes of the cloud -- [0]: NaN coordinates dropped (what min / max do with them), [1]: finite
+// points only (pcl::getMinMax3D for a cloud that is not dense).  min / max are exact and order-free, so the boxes are the
+// ones the kernel's per-block rows reduce to.
+static void host_repack_bbox(const unsigned char* src, size_t n, size_t stride, float* dst, float bb_min[2][3], float bb_max[2][3]) {
+  __m128 mn0 = _mm_set1_ps(FLT_MAX), mx0 = _mm_set1_ps(-FLT_MAX), mn1 = mn0, mx1 = mx0;
+  const __m128 keep_xyz = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1)), one_w = _mm_set_ps(1.0f, 0.0f, 0.0f, 0.0f);
+  const __m128 abs_mask = _mm_castsi128_ps(_mm_set1_epi32(0x7fffffff)), inf = _mm_set1_ps(INFINITY);
+  auto take = [&](__m128 v, float* out) {
+    v = _mm_or_ps(_mm_and_ps(v, keep_xyz), one_w);
+    _mm_store_ps(out, v);
+    mn0 = _mm_min_ps(v, mn0);  // (min / max hand back their SECOND operand when the first is NaN)
+    mx0 = _mm_max_ps(v, mx0);
+    if ((_mm_movemask_ps(_mm_cmplt_ps(_mm_and_ps(v, abs_mask), inf)) & 7) == 7) {
+      mn1 = _mm_min_ps(v, mn1);
+      mx1 = _mm_max_ps(v, mx1);
+    }
+  };
+  const size_t n_wide = (stride >= 16) ? n : (n ? n - 1 : 0);  // 12-B records: a 16-B load of the last one would leave the buffer
+  for (size_t i = 0; i < n_wide; i++) take(_mm_loadu_ps(reinterpret_cast<const float*>(src + i * stride)), dst + 4 * i);
+  for (size_t i = n_wide; i < n; i++) {
+    const float* p = reinterpret_cast<const float*>(src + i * stride);
+    take(_mm_set_ps(0.0f, p[2], p[1], p[0]), dst + 4 * i);
+  }
+  alignas(16) float a[4], b[4], c[4], d[4];
+  _mm_store_ps(a, mn0); _mm_store_ps(b, mx0); _mm_store_ps(c, mn1); _mm_store_ps(d, mx1);
+  for (int k = 0; k < 3; k++) {
+    bb_min[0][k] = a[k]; bb_max[0][k] = b[k];
+    bb_min[1][k] = c[k]; bb_max[1][k] = d[k];
+  }
+}
 
 // upload + repack to dense float4
 ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
@@ -18,7 +52,25 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
   auto c = std::make_shared<DeviceCloud>();
   HIP_TRY(c->pts.reserve(n));
   c->n = n;
-  if (n) {
+  // clouds of at most this many points take the host route (NDT_HOST_STAGE_MAX, 0 = never): the repack + bounding box pass
+  // costs the host ~1 ns per point, the device route a blocking pageable copy, a kernel and a wait (~35 us whatever the size)
+  static const size_t host_stage_max = [] {
+    const char* v = getenv("NDT_HOST_STAGE_MAX");
+    return std::min<size_t>(ndt_context::kStageSlotPoints, v ? static_cast<size_t>(std::max(0, atoi(v))) : 20480);
+  }();
+  if (n && !on_device && n <= host_stage_max) {
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) % ndt_context::kStageSlots;
+    if (!h->stage_host[slot]) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->stage_host[slot]), ndt_context::kStageSlotPoints * sizeof(float4), hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&h->stage_done[slot], hipEventDisableTiming));
+    } else {
+      HIP_TRY(hipEventSynchronize(h->stage_done[slot]));  // (four uploads ago: long done)
+    }
+    host_repack_bbox(static_cast<const unsigned char*>(pts), n, stride, h->stage_host[slot], c->bb_min, c->bb_max);
+    HIP_TRY(ndt::launch_copy_records(reinterpret_cast<const float4*>(h->stage_host[slot]), c->pts.p, static_cast<int>(n), h->stream));
+    HIP_TRY(hipEventRecord(h->stage_done[slot], h->stream));
+  } else if (n) {
     const void* d_src = pts;
     if (!on_device) {
       HIP_TRY(h->staging.reserve(n * stride));

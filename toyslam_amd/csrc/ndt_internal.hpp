@@ -262,6 +262,13 @@ struct ndt_context {
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
   float* bbox_rows = nullptr;     // pinned, per-block bounding-box rows of the last upload (k_repack_bbox)
+  // small host clouds (the mapping nodes' 16 k-point scans): repacked to float4 and bounded ON THE HOST into one of these
+  // page-locked slots and DMA'd from there -- no repack kernel, no wait for the device (upload_cloud)
+  static constexpr int kStageSlots = 4;
+  static constexpr size_t kStageSlotPoints = 65536;
+  float* stage_host[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};  // the slot's last DMA has been read
+  int stage_next = 0;
   double* host_pub = nullptr;     // pinned, tagged publication row of the single-scan paths (ndt_kernels.hip publish_row_tagged)
   size_t host_result_rows = 0;
   unsigned long long eval_seq = 0;
@@ -291,7 +298,8 @@ struct ndt_context {
   void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
   int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
-  DevBuf<unsigned> server_counter;
+  DevBuf<unsigned> server_counter;  // two sets of kServerCounterWords, used alternately (server_start)
+  int server_counter_set = 0;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
   bool server_want_dbg = false;
   int cu_count = 0;
@@ -330,6 +338,10 @@ struct ndt_context {
     if (host_pub) (void)hipHostFree(host_pub);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (bbox_rows) (void)hipHostFree(bbox_rows);
+    for (int k = 0; k < kStageSlots; k++) {
+      if (stage_host[k]) (void)hipHostFree(stage_host[k]);
+      if (stage_done[k]) (void)hipEventDestroy(stage_done[k]);
+    }
     if (server_host_mbs) (void)(server_mbs_on_device ? hipFree(server_host_mbs) : hipHostFree(server_host_mbs));
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);

@@ -163,6 +163,8 @@ size_t record_compaction_tiles(long long lut_cells);
 hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,
                                   VoxelSide* cent_out, unsigned* tile_sums, hipStream_t stream);
 
+// n dense records from page-locked host memory (read by the kernel itself) into HBM
+hipError_t launch_copy_records(const float4* src_host_pinned, float4* dst, int n, hipStream_t stream);
 // repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
                               int n_blocks, hipStream_t stream);
@@ -249,7 +251,8 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
-                              unsigned long long* dbg = nullptr, int direct = 0, float4* out_host = nullptr);
+                              unsigned long long* dbg, int direct, float4* out_host, unsigned* counter_next);
+constexpr int kServerCounterWords = 32 * (1 + kServerParts);  // one set of the server's shard counters (a 128-B line each)
 hipError_t launch_hessian64(const float4* src, int n, const GridView& gv, const Hess64Params& P, int search,
                             const ScanDesc* descs, const int* active, int n_active, int max_blocks, int n_blocks,
                             double* partials, hipStream_t stream);

@@ -203,8 +203,12 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
                                                             unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                                                             int param_pad, const float4* __restrict__ out_src,
                                                             float4* __restrict__ out_dst, int out_n, unsigned long long* dbg,
-                                                            int direct, float4* __restrict__ out_host, int ppb) {
+                                                            int direct, float4* __restrict__ out_host, int ppb,
+                                                            unsigned* __restrict__ counter_next) {
   constexpr int kWaves = kServerTPB / kWave, kParts = kServerTPB / kEvalStride;
+  // the shard counters of the NEXT launch (the other of two sets: nobody touches it during this one) start at zero --
+  // instead of a fill kernel in front of every registration's server
+  if (blockIdx.x == 0 && threadIdx.x < 1 + kParts) counter_next[32u * threadIdx.x] = 0u;
   __shared__ double lds[kWaves * 32];
   __shared__ EvalParams sP;
   __shared__ Hess64Params sP64;
@@ -639,22 +643,22 @@ hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int 
                               void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
-                              unsigned long long* dbg, int direct, float4* out_host) {
+                              unsigned long long* dbg, int direct, float4* out_host, unsigned* counter_next) {
   const int ppb = points_per_block(n);
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 0)
     hipLaunchKernelGGL(k_eval_server<27>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb, counter_next);
   else if (search == 1)
     hipLaunchKernelGGL(k_eval_server<26>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb, counter_next);
   else if (search == 3)
     hipLaunchKernelGGL(k_eval_server<1>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb, counter_next);
   else
     hipLaunchKernelGGL(k_eval_server<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, hm, dm, partials, counter,
-                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb);
+                       out_row, first_seq, idle_ticks, gauss_d1, gauss_d2, param_pad, out_src, out_dst, out_n, dbg, direct, out_host, ppb, counter_next);
   return hipGetLastError();
 }
 
