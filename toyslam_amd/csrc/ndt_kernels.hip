@@ -300,8 +300,12 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
   // The loop is uniform across the WAVE (a team without a query idles): the fallback below is a wave-wide operation.
   constexpr int kTeamsPerWave = kWave / kTeam;
   const int wave_in_block = threadIdx.x / kWave, team_in_wave = (threadIdx.x & (kWave - 1)) / kTeam;
-  for (int base = (blockIdx.x * (kBlock / kWave) + wave_in_block) * kTeamsPerWave; base < n; base += gridDim.x * kTeams) {
-    const int i = base + team_in_wave;
+  // Queries are dealt to the teams in BIT-REVERSED order: the eight teams of a wave take queries an eighth of the scan apart.
+  // The far queries of a scan come in runs (a wall the target does not cover), and a wave that held eight of them was the
+  // kernel's whole duration while the rest of the chip sat idle.
+  const int log_slots = 32 - __clz(max(n, 2) - 1), n_slots = 1 << log_slots;
+  for (int base = (blockIdx.x * (kBlock / kWave) + wave_in_block) * kTeamsPerWave; base < n_slots; base += gridDim.x * kTeams) {
+    const int i = static_cast<int>(__brev(static_cast<unsigned>(base + team_in_wave)) >> (32 - log_slots));
     float tx = 0.f, ty = 0.f, tz = 0.f;
     bool live = i < n;  // uniform within a team
     if (live) {
@@ -314,16 +318,19 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
     }
     float tb = INFINITY;
     bool done = !live;
+    int ci = 0, cj = 0, ck = 0;
+    float margin = 0.0f;
+    // shells 0 .. kTeamShells by the query's team of 8 lanes (a registered scan: nearly every query ends in its own cell or
+    // the 26 around it) ...
+    constexpr int kTeamShells = 2;
     if (live) {
       float best = INFINITY;  // this lane's share of the candidates
       auto consider = [&](float d, unsigned, bool ok) {
         if (ok) best = fminf(best, d);
       };
-      int ci, cj, ck;
-      float margin;
       query_cell(ix.geom, tx, ty, tz, ci, cj, ck, margin);
-      for (int r = 0; r <= r_max && !done; r++) {
-        team_shell(ix, ci, cj, ck, r, sub, tx, ty, tz, consider);
+      for (int r = 0; r <= min(r_max, kTeamShells) && !done; r++) {
+        team_shell(ix, ci, cj, ck, r, sub, tx, ty, tz, consider, tb);  // (tb: the team's best after the previous shell)
         tb = best;
 #pragma unroll
         for (int off = 1; off < kTeam; off <<= 1) tb = fminf(tb, __shfl_xor(tb, off, kWave));
@@ -333,15 +340,39 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const float4* __restrict__ s
         if ((reach > 0.0f && tb <= reach * reach) || r >= r_lim) done = true;
       }
     }
-    // sparse neighbourhoods: the wave scans everything, one unfinished query at a time
+    // ... the far queries (parts of the scan the target does not cover: metres to the nearest point, shells of hundreds of
+    // rows) by the WHOLE wave, one unfinished query at a time: 64 rows of a shell per step instead of 8.  602 such queries
+    // of the reference pair's 15 950 were 2/3 of this kernel's time when their teams walked the shells alone.
     unsigned long long open_teams = __ballot(!done && sub == 0);
+    const int lane = threadIdx.x & (kWave - 1);
     while (open_teams) {
       const int src_lane = __builtin_ctzll(open_teams);
       open_teams &= open_teams - 1;
-      float wd;
-      int wi;
-      wave_nearest(ix, __shfl(tx, src_lane, kWave), __shfl(ty, src_lane, kWave), __shfl(tz, src_lane, kWave), wd, wi);
-      if ((static_cast<int>(threadIdx.x) & (kWave - 1)) / kTeam == src_lane / kTeam) tb = wd;
+      const float qx = __shfl(tx, src_lane, kWave), qy = __shfl(ty, src_lane, kWave), qz = __shfl(tz, src_lane, kWave);
+      const int qi = __shfl(ci, src_lane, kWave), qj = __shfl(cj, src_lane, kWave), qk = __shfl(ck, src_lane, kWave);
+      const float q_margin = __shfl(margin, src_lane, kWave);
+      float wb = __shfl(tb, src_lane, kWave);  // what the team has found so far bounds the search
+      float wbest = INFINITY;
+      auto consider_w = [&](float d, unsigned, bool ok) {
+        if (ok) wbest = fminf(wbest, d);
+      };
+      bool wdone = false;
+      for (int r = kTeamShells + 1; r <= r_max && !wdone; r++) {
+        team_shell<kWave>(ix, qi, qj, qk, r, lane, qx, qy, qz, consider_w, wb);
+        float m = wbest;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) m = fminf(m, __shfl_xor(m, off, kWave));
+        wb = fminf(wb, m);
+        const float reach = static_cast<float>(r) * leaf + q_margin - ix.slack;
+        if ((reach > 0.0f && wb <= reach * reach) || r >= r_lim) wdone = true;
+      }
+      if (!wdone) {  // nothing within r_max shells: one scan over all points
+        float wd;
+        int wi;
+        wave_nearest(ix, qx, qy, qz, wd, wi);
+        wb = wd;
+      }
+      if (lane / kTeam == src_lane / kTeam) tb = wb;
     }
     if (live && sub == 0 && static_cast<double>(tb) <= max_range) {  // the squared distance against max_range, as PCL does
       acc[0] += static_cast<double>(tb);

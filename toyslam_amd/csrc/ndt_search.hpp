@@ -46,11 +46,11 @@ constexpr int kTeam = 8;
 // `first` (positions sub, sub + 8, ...), two loads in flight.  visit(d, position in the cell order, valid) is
 // called the same number of times by every lane of the team (valid = false past the end), so that a visitor may
 // use team-wide operations.
-template <class F>
+template <int TEAM = kTeam, class F>
 __device__ __forceinline__ void scan_run(const float4* __restrict__ sp, unsigned first, int count, int sub, float qx, float qy,
                                          float qz, F&& visit) {
-  for (int base = 0; base < count; base += 2 * kTeam) {
-    const int p0 = base + sub, p1 = p0 + kTeam;
+  for (int base = 0; base < count; base += 2 * TEAM) {
+    const int p0 = base + sub, p1 = p0 + TEAM;
     const bool v0 = p0 < count, v1 = p1 < count;
     // clamped, not predicated: both loads issue together (count >= 1 here)
     const float4 a = sp[first + min(p0, count - 1)], b = sp[first + min(p1, count - 1)];
@@ -110,24 +110,42 @@ __device__ __forceinline__ int team_sum(int v) {
 // to the eight lanes, each lane probes one cell of its row per step (face rows: every x; interior rows:
 // only x = -r and x = +r), and every occupied cell any lane finds is then scanned by the whole team.
 // consider(d, position) as in scan_run.  All control flow is uniform within the team.
-template <class F>
+// bound2 (optional): a squared distance the caller can no longer use -- rows and cells that cannot hold a point
+// nearer than that are not even looked up.  The distance from the query to a cell's box, less the index-rounding slack
+// (a point may sit that far outside the cell it was binned into), bounds every point of the cell from below; after the
+// query's own cell has given a neighbour at ~ the point spacing, that leaves one to three of a shell's 26 cells.
+__device__ __forceinline__ float axis_gap(float q, int cell_abs, float leaf, float slack) {
+  const float lo = static_cast<float>(cell_abs) * leaf, hi = lo + leaf;
+  return fmaxf(fmaxf(lo - q, q - hi) - slack, 0.0f);
+}
+template <int TEAM = kTeam, class F>
 __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj, int ck, int r, int sub, float qx, float qy,
-                                           float qz, F&& consider) {
+                                           float qz, F&& consider, float bound2 = INFINITY) {
+  // (TEAM = 8: the team search; TEAM = 64: a whole wave on one query -- the far queries of getFitnessScore, whose shells
+  // have hundreds of rows)
+  constexpr unsigned long long kTeamMask = TEAM >= 64 ? ~0ull : ((1ull << (TEAM & 63)) - 1ull);
   const GridGeom& g = ix.geom;
   const int w = 2 * r + 1, rows = w * w;
-  const int team_base = (threadIdx.x & (kWave - 1)) & ~(kTeam - 1);
-  for (int row0 = 0; row0 < rows; row0 += kTeam) {
+  const int team_base = (threadIdx.x & (kWave - 1)) & ~(TEAM - 1);
+  const bool prune = bound2 < INFINITY;
+  for (int row0 = 0; row0 < rows; row0 += TEAM) {
     const int row = row0 + sub;
     const int dz = row / w - r, dy = row % w - r;
     const int z = ck + dz, y = cj + dy;
     bool row_ok = row < rows && z >= 0 && z < g.div_b[2] && y >= 0 && y < g.div_b[1];
+    float row_d2 = 0.0f;
+    if (prune && row_ok) {
+      const float gy = axis_gap(qy, y + g.min_b[1], g.leaf[1], ix.slack), gz = axis_gap(qz, z + g.min_b[2], g.leaf[2], ix.slack);
+      row_d2 = gy * gy + gz * gz;
+      row_ok = row_d2 <= bound2;
+    }
     if (row_ok) row_ok = ix.row_any[y + z * g.div_b[1]] != 0;  // rows without a single occupied cell cost one load
-    if (((__ballot(row_ok) >> team_base) & 0xffull) == 0) continue;
+    if (((__ballot(row_ok) >> team_base) & kTeamMask) == 0) continue;
     const bool face = (dz == -r || dz == r || dy == -r || dy == r);  // r == 0: the single row is a face row
     const int nx = face ? w : 2;
     int steps = row_ok ? nx : 0;  // the longest occupied row of this batch sets the number of steps (interior rows: 2 cells)
 #pragma unroll
-    for (int off = 1; off < kTeam; off <<= 1) steps = max(steps, __shfl_xor(steps, off, kWave));
+    for (int off = 1; off < TEAM; off <<= 1) steps = max(steps, __shfl_xor(steps, off, kWave));
     for (int t = 0; t < steps; t += 2) {  // two cells of the row per step: both table loads are in flight together
       uint2 range[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #pragma unroll
@@ -135,20 +153,25 @@ __device__ __forceinline__ void team_shell(const PointIndex& ix, int ci, int cj,
         const int tt = t + u;
         if (row_ok && tt < nx) {
           const int x = ci + (face ? tt - r : (tt == 0 ? -r : r));
-          if (x >= 0 && x < g.div_b[0]) range[u] = ix.cell_range[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
+          bool cell_ok = x >= 0 && x < g.div_b[0];
+          if (prune && cell_ok) {
+            const float gx = axis_gap(qx, x + g.min_b[0], g.leaf[0], ix.slack);
+            cell_ok = row_d2 + gx * gx <= bound2;
+          }
+          if (cell_ok) range[u] = ix.cell_range[x * g.mul[0] + y * g.mul[1] + z * g.mul[2]];
         }
       }
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const unsigned first = range[u].x;
         const int count = static_cast<int>(range[u].y);
-        unsigned found = static_cast<unsigned>((__ballot(count > 0) >> team_base) & 0xffull);
+        unsigned long long found = (__ballot(count > 0) >> team_base) & kTeamMask;
         while (found) {
-          const int owner = __builtin_ctz(found);
+          const int owner = __builtin_ctzll(found);
           found &= found - 1;
           const unsigned fs = __shfl(first, team_base + owner, kWave);
           const int fc = __shfl(count, team_base + owner, kWave);
-          scan_run(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
+          scan_run<TEAM>(ix.sorted_pts, fs, fc, sub, qx, qy, qz, consider);
         }
       }
     }
