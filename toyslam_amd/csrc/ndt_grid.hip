@@ -41,6 +41,33 @@ static void host_repack_bbox(const unsigned char* src, size_t n, size_t stride, 
   }
 }
 
+// n dense float4 records from HBM into the caller's records of out_stride bytes: device -> the handle's page-locked
+// staging (one contiguous DMA) -> the caller's buffer by the CPU.  A strided copy straight into pageable memory goes
+// through the runtime's own staging in small pieces (measured 74 us for 256 KB; ~0.4 ms for the 1 MB of a filtered
+// 70 k-point scan, most of the N1 call).  Synchronises the handle's stream.
+ndt_status download_records(ndt_context* h, const float4* d_src, size_t n, void* out, size_t out_stride) {
+  if (n == 0) return NDT_OK;
+  const size_t bytes = n * sizeof(float4);
+  if (h->out_pinned_bytes < bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));  // (an earlier download may still be reading the old block)
+    if (h->out_pinned) (void)hipHostFree(h->out_pinned);
+    h->out_pinned = nullptr;
+    h->out_pinned_bytes = 0;
+    HIP_TRY(hipHostMalloc(&h->out_pinned, bytes + bytes / 4, hipHostMallocDefault));
+    h->out_pinned_bytes = bytes + bytes / 4;
+  }
+  HIP_TRY(hipMemcpyAsync(h->out_pinned, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out_stride == sizeof(float4)) {
+    std::memcpy(out, h->out_pinned, bytes);
+  } else {
+    const unsigned char* src = static_cast<const unsigned char*>(h->out_pinned);
+    unsigned char* dst = static_cast<unsigned char*>(out);
+    for (size_t i = 0; i < n; i++) std::memcpy(dst + i * out_stride, src + i * sizeof(float4), sizeof(float4));
+  }
+  return NDT_OK;
+}
+
 // upload + repack to dense float4
 ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
                         std::shared_ptr<DeviceCloud>& out) {
@@ -827,8 +854,8 @@ static ndt_status voxel_filter_impl(ndt_handle h, const void* pts, size_t n, siz
   if (s) return s;
   if (!on_device && n_written) {
     if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
-    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d_out, sizeof(float4), sizeof(float4), n_written, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    s = download_records(h, d_out, n_written, out, out_stride);
+    if (s) return s;
   }
   *n_out = n_written;
   if (overflow) return fail(NDT_ERR_GRID_OVERFLOW, "leaf size is too small for the input dataset: integer indices would overflow");
@@ -903,9 +930,7 @@ ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride) {
   if (!h || (h->map_n && !out)) return fail(NDT_ERR_INVALID, "bad arguments");
   if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
   if (h->map_n == 0) return NDT_OK;
-  HIP_TRY(hipMemcpy2DAsync(out, out_stride, h->map_pts.p, sizeof(float4), sizeof(float4), h->map_n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return NDT_OK;
+  return download_records(h, h->map_pts.p, h->map_n, out, out_stride);
 }
 ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts, size_t* n) {
   if (!h || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");

@@ -377,6 +377,7 @@ ndt_status build_grid(ndt_context* h);
 ndt_status grid_counts(ndt_context* h, DeviceGrid* g);
 ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g);
 float index_slack(const DeviceGrid* g);
+ndt_status download_records(ndt_context* h, const float4* d_src, size_t n, void* out, size_t out_stride);
 void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix);
 ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness);
 ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
