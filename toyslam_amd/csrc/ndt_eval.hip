@@ -81,8 +81,8 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   const int nblk = fused ? ndt::fused_blocks(n) : ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   if (!h->ticket.p) {
-    HIP_TRY(h->ticket.reserve(1));
-    HIP_TRY(hipMemsetAsync(h->ticket.p, 0, sizeof(unsigned), h->stream));
+    HIP_TRY(h->ticket.reserve(32 * 17));  // top counter + 16 shard counters, one per 128-B line (k_derivatives_fused)
+    HIP_TRY(hipMemsetAsync(h->ticket.p, 0, 32 * 17 * sizeof(unsigned), h->stream));
   }
   const ndt::GridView gv = h->grid->view();
   const auto tp0 = std::chrono::steady_clock::now();

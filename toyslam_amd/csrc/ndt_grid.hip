@@ -488,7 +488,7 @@ ndt_status build_grid(ndt_context* h) {
     }
     DevBuf<unsigned> ctrl, blockbase, order;
     HIP_TRY(ctrl.reserve(4 + K));  // tickets[2], pad[2], bucket_count[K]: zeroed by the build's first kernel
-    HIP_TRY(g->bucket_base.reserve(K + 1));
+    HIP_TRY(g->bucket_base.reserve(2 * K + 1));  // [K + 1] bucket bases, [K] valid voxels per bucket (k1_finalize -> k1_count)
     HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
     HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
     HIP_TRY(g->bpts.reserve(n));

@@ -836,12 +836,8 @@ __global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long lo
 }
 
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
-                                                      unsigned* __restrict__ ticket, unsigned* __restrict__ bucket_base,
-                                                      unsigned* __restrict__ counts) {
+                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase) {
   extern __shared__ unsigned k1_lds[];
-  __shared__ unsigned s_scan[kK1Threads / kWave];
-  __shared__ int s_last;
   unsigned* h = k1_lds;
   for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
   __syncthreads();
@@ -865,22 +861,28 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
     // the block's run inside bucket k starts where the bucket's counter stood (arrival order of the blocks: any)
     blockbase[static_cast<size_t>(blockIdx.x) * K + k] = v ? __hip_atomic_fetch_add(bucket_count + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  block_scan_array(bucket_count, bucket_base, K, kK1Threads, s_scan, true);
-  __syncthreads();
-  if (threadIdx.x == 0) counts[0] = bucket_base[K];  // points binned
+  // (no ticket, no last-block scan of the bucket counters: every block of k1_scatter scans the K counters itself --
+  // 245 returning atomics on one ticket word queued ~4 us behind each other at the end of this kernel)
 }
 
 __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                         int ppb, const unsigned* __restrict__ bucket_base,
-                                                         const unsigned* __restrict__ blockbase, float4* __restrict__ bpts) {
-  extern __shared__ unsigned k1_lds[];
+                                                         int ppb, const unsigned* __restrict__ bucket_count, unsigned* __restrict__ bucket_base,
+                                                         const unsigned* __restrict__ blockbase, float4* __restrict__ bpts,
+                                                         unsigned* __restrict__ counts) {
+  extern __shared__ unsigned k1_lds[];  // K + 1 words
+  __shared__ unsigned s_scan[kK1Threads / kWave];
   unsigned* cursor = k1_lds;
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] = bucket_base[k] + blockbase[static_cast<size_t>(blockIdx.x) * K + k];
+  // bucket bases = exclusive scan of the K bucket counters, by every block for itself (1 us); block 0 keeps them for
+  // k1_finalize and the leaf pass
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] = bucket_count[k];
+  __syncthreads();
+  block_scan_array(cursor, cursor, K, kK1Threads, s_scan, false);
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k <= K; k += kK1Threads) bucket_base[k] = cursor[k];
+    if (threadIdx.x == 0) counts[0] = cursor[K];  // points binned
+  }
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += blockbase[static_cast<size_t>(blockIdx.x) * K + k];
   __syncthreads();
   const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
   for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {
@@ -972,6 +974,20 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
         counts[1 + which] = all;  // [1] occupied voxels, [2] candidates (>= min_pts)
       }
     }
+    // [3] valid voxels: the words k1_finalize left behind the bucket bases
+    const unsigned* bucket_valid = bucket_base + K + 1;
+    unsigned v = 0;
+    for (int i = lo; i < hi; i++) v += bucket_valid[i];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    __syncthreads();
+    if (lane == 0) s_scan[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned t = 0;
+      for (int w = 0; w < kBlock / kWave; w++) t += s_scan[w];
+      counts[3] = t;
+    }
   }
 }
 
@@ -1003,8 +1019,8 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                                       double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
                                                       int* __restrict__ sorted_idx,
                                                       VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
-                                                      unsigned* __restrict__ n_valid, unsigned* __restrict__ scratch /* 5 x n words */,
-                                                      unsigned n_total) {
+                                                      unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
+                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
@@ -1015,7 +1031,10 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   __shared__ float s_one;
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  if (be == bb) return;  // empty bucket (uniform)
+  if (be == bb) {  // empty bucket (uniform)
+    if (threadIdx.x == 0) bucket_valid[k] = 0u;
+    return;
+  }
   const unsigned nb = be - bb;
   if (threadIdx.x == 0) s_one = 1.0f;
   unsigned* cnt = k1_lds;          // [C] points per cell
@@ -1250,11 +1269,20 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
   }
-  {  // one counter update per wave
+  {  // the bucket's valid voxels -> its own word; k1_count adds the words up when somebody asks (grid_counts).  One atomic
+     // per WAVE on a single counter was 8 of this kernel's 41 us at 1 M points: same-address atomics serialise at the
+     // memory side, ~15 ns each
     unsigned v = n_ok;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(n_valid, v);
+    __syncthreads();  // (s_u3 is free)
+    if ((threadIdx.x & (kWave - 1)) == 0) s_u3[threadIdx.x / kWave].pts = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int w = 0; w < kBlock / kWave; w++) t += s_u3[w].pts;
+      bucket_valid[k] = t;
+    }
   }
 }
 
@@ -1541,9 +1569,9 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   hipLaunchKernelGGL(k1_init, dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>(2048, g.lut_cells / (4 * kBlock) + 1)))), dim3(kBlock), 0,
                      stream, lut, g.lut_cells, S.tickets, 4 + K, counts);
   hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_count, S.blockbase, S.tickets, S.bucket_base, counts);
-  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_base, S.blockbase, S.bpts);
+                     S.bucket_count, S.blockbase);
+  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k + sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
+                     P.pts_per_block, S.bucket_count, S.bucket_base, S.blockbase, S.bpts, counts);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
   // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
@@ -1555,8 +1583,8 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
   if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
-                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut, counts + 3,
-                     S.order, static_cast<unsigned>(n));
+                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut,
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n));
   return hipGetLastError();
 }
 

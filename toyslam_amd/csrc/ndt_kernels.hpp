@@ -145,7 +145,7 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& plan);
 struct GridBuildScratch {
   unsigned* tickets;       // [4]: the control words (zeroed by the build), followed by
   unsigned* bucket_count;  // [n_buckets] (= tickets + 4, zeroed by the build)
-  unsigned* bucket_base;   // [n_buckets + 1]   (kept with the grid: the leaf pass needs it)
+  unsigned* bucket_base;   // [n_buckets + 1] bases + [n_buckets] valid voxels per bucket   (kept with the grid: the leaf pass needs both)
   unsigned* blockbase;     // [n_blocks x n_buckets]
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
   unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS

@@ -25,6 +25,7 @@ namespace {
 // inter-kernel gap of the two-kernel path (~5 us per evaluation at 100k points).
 // The counter is reset by the last block, so it is 0 again at the next launch.
 // ---------------------------------------------------------------------------
+constexpr int kFusedShards = 16;  // shard counters of the fused kernel's ticket: counter[32 * (1 + s)], top counter[0]
 template <int NNB, bool WANT_H, int TPB>
 __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
                                                            double* __restrict__ partials, unsigned* __restrict__ counter,
@@ -72,8 +73,27 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+      // Two-level ticket: shard s = the blocks b with b % kFusedShards == s, a counter per shard 128 B apart, and a top
+      // counter for the shards' last arrivers.  (Returning atomics on ONE word serialise at the memory side at ~15 ns each:
+      // the 512 blocks of a multi-million-point scan queued ~7 us behind a single counter, every evaluation.)  Every
+      // counter is left at zero by the block that takes its last ticket.
+      // (A scan that takes its blocks several passes -- multi-million points -- has them finish spread over tens of
+      // microseconds: there the second level only adds its own round trip, measured -1 % at 2 M points, so one counter.)
+      const bool one_pass = static_cast<long long>(gridDim.x) * ppb >= n;
+      int last = 0;
+      if (one_pass && gridDim.x > 1u) {
+        const unsigned shards = min(static_cast<unsigned>(kFusedShards), gridDim.x);
+        const unsigned shard = blockIdx.x % shards;
+        const unsigned in_shard = (gridDim.x + shards - 1u - shard) / shards;
+        unsigned* const c1 = counter + 32u * (1u + shard);
+        if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1u) {
+          __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) ? 1 : 0;
+        }
+      } else {
+        last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+      }
+      s_last = last;
     }
   }
   __syncthreads();
