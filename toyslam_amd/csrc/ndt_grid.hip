@@ -486,15 +486,21 @@ ndt_status build_grid(ndt_context* h) {
       HIP_TRY(centroids_by_slot.reserve(rec_slots));
       HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(geo.lut_cells) + 1));
     }
-    DevBuf<unsigned> ctrl, blockbase, order;
-    HIP_TRY(ctrl.reserve(4 + K));  // tickets[2], pad[2], bucket_count[K]: zeroed by the build's first kernel
+    DevBuf<unsigned> blockbase, order;
+    // the handle's bucket counters: zero between builds (k1_finalize clears what k1_hist counted); cleared here only when
+    // they are new or a build was cut short
+    if (!h->k1_bucket_count.p) {
+      HIP_TRY(h->k1_bucket_count.reserve(ndt::kK1MaxBuckets));
+      h->k1_bucket_count_clean = false;
+    }
+    if (!h->k1_bucket_count_clean) HIP_TRY(hipMemsetAsync(h->k1_bucket_count.p, 0, ndt::kK1MaxBuckets * sizeof(unsigned), st));
+    h->k1_bucket_count_clean = false;  // until every launch of this build is queued
     HIP_TRY(g->bucket_base.reserve(2 * K + 1));  // [K + 1] bucket bases, [K] valid voxels per bucket (k1_finalize -> k1_count)
     HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
     HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
     HIP_TRY(g->bpts.reserve(n));
     ndt::GridBuildScratch S{};
-    S.tickets = ctrl.p;
-    S.bucket_count = ctrl.p + 4;
+    S.bucket_count = h->k1_bucket_count.p;
     S.bucket_base = g->bucket_base.p;
     S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
@@ -509,6 +515,7 @@ ndt_status build_grid(ndt_context* h) {
                                            g->counts.p, st));
     if (compact)
       HIP_TRY(ndt::launch_compact_records(g->lut.p, geo.lut_cells, recs_by_slot.p, centroids_by_slot.p, g->recs.p, g->centroids.p, tile_sums.p, st));
+    h->k1_bucket_count_clean = true;
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
   } else {

@@ -4,7 +4,7 @@
 //    general chain:  bbox -> per-cell count -> 3-phase exclusive scan over cells (leaf ordinals, segment offsets, record
 //                    ordinals, LUT init) -> counting-sort scatter of point indices -> k_presort_large (crowded voxels) ->
 //                    k_finalize
-//    bucket form:    k1_init -> k1_hist -> k1_scatter -> k1_finalize (4 launches, LDS histograms, no per-point global
+//    bucket form:    k1_hist -> k1_scatter -> k1_finalize (3 launches, LDS histograms, no per-point global
 //                    atomics; crowded cells summed by lane teams), k1_count / k1_leaves on demand
 //    (the sort-based sparse form is ndt_sparse.hip; all three end in finish_voxel: index-ordered f64 sums -- bit-identical
 //    to the reference's sequential accumulation --, mean, covariance with the reference's quirks, 3x3 symmetric
@@ -822,24 +822,20 @@ __device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ sr
   if (tid == 0) dst[n] = total;
 }
 
-// the padded look-up table starts out empty, the control words and the four counters at zero: one launch instead of
-// three hipMemsetAsync calls (each costs the host ~7 us)
-__global__ __launch_bounds__(kBlock) void k1_init(int* __restrict__ lut, long long lut_cells, unsigned* __restrict__ ctrl, int n_ctrl,
-                                                  unsigned* __restrict__ counts) {
-  const long long tid = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x, nt = static_cast<long long>(gridDim.x) * kBlock;
-  int4* l4 = reinterpret_cast<int4*>(lut);
-  const long long n4 = lut_cells / 4;
-  for (long long i = tid; i < n4; i += nt) l4[i] = make_int4(kLutEmpty, kLutEmpty, kLutEmpty, kLutEmpty);
-  for (long long i = n4 * 4 + tid; i < lut_cells; i += nt) lut[i] = kLutEmpty;
-  for (long long i = tid; i < n_ctrl; i += nt) ctrl[i] = 0;
-  if (tid < 5) counts[tid] = 0;  // [4]: points in crowded cells
-}
-
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase) {
+                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
+                                                      int* __restrict__ lut, long long lut_cells) {
   extern __shared__ unsigned k1_lds[];
   unsigned* h = k1_lds;
   for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
+  {  // the padded look-up table starts out empty: every block clears its slice (nothing reads the table before k1_finalize)
+    const long long n4 = lut_cells / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long lo4 = static_cast<long long>(blockIdx.x) * per, hi4 = min(n4, lo4 + per);
+    int4* l4 = reinterpret_cast<int4*>(lut);
+    for (long long i = lo4 + threadIdx.x; i < hi4; i += kK1Threads) l4[i] = make_int4(kLutEmpty, kLutEmpty, kLutEmpty, kLutEmpty);
+    if (blockIdx.x == 0)
+      for (long long i = n4 * 4 + threadIdx.x; i < lut_cells; i += kK1Threads) lut[i] = kLutEmpty;
+  }
   __syncthreads();
   const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
   for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {  // eight loads in flight per thread
@@ -1020,7 +1016,8 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                                       int* __restrict__ sorted_idx,
                                                       VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                       unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
-                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total) {
+                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
+                                                      unsigned* __restrict__ bucket_count) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
@@ -1030,6 +1027,9 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
   __shared__ float s_one;
   const int k = blockIdx.x;
+  // the handle's bucket counters are zero between builds: k1_hist counted into them, k1_scatter has read them, this block
+  // clears its own -- instead of a clearing launch in front of every build
+  if (threadIdx.x == 0) bucket_count[k] = 0u;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) {  // empty bucket (uniform)
     if (threadIdx.x == 0) bucket_valid[k] = 0u;
@@ -1530,7 +1530,7 @@ static int pow2_ceil(long long v) {
 }
 
 bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
-  constexpr int kMaxBuckets = 8192, kMaxCells = 4096;
+  constexpr int kMaxBuckets = kK1MaxBuckets, kMaxCells = 4096;
   if (n_points <= 0 || n_cells <= 0 || n_cells > static_cast<long long>(kMaxBuckets) * kMaxCells) return false;
   // ~1000 points per bucket: a bucket's per-point arrays then live in LDS and there are several blocks per CU
   // ... and at least a bucket per CU; small clouds (the mapping nodes' 16 k points: latency-bound on their fullest bucket)
@@ -1566,10 +1566,8 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                                      int* lut, unsigned* counts, hipStream_t stream) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
   const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
-  hipLaunchKernelGGL(k1_init, dim3(static_cast<unsigned>(std::max<long long>(1, std::min<long long>(2048, g.lut_cells / (4 * kBlock) + 1)))), dim3(kBlock), 0,
-                     stream, lut, g.lut_cells, S.tickets, 4 + K, counts);
   hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_count, S.blockbase);
+                     S.bucket_count, S.blockbase, lut, g.lut_cells);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k + sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
                      P.pts_per_block, S.bucket_count, S.bucket_base, S.blockbase, S.bpts, counts);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
@@ -1584,7 +1582,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
                      S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut,
-                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n));
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.bucket_count);
   return hipGetLastError();
 }
 

@@ -142,9 +142,9 @@ struct GridBuildPlan {
 };
 // false: the grid is outside the bucket form's range (more than 8192 x 4096 cells): the general path builds it
 bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& plan);
+constexpr int kK1MaxBuckets = 8192;
 struct GridBuildScratch {
-  unsigned* tickets;       // [4]: the control words (zeroed by the build), followed by
-  unsigned* bucket_count;  // [n_buckets] (= tickets + 4, zeroed by the build)
+  unsigned* bucket_count;  // [n_buckets] of the HANDLE's kK1MaxBuckets counters: zero on entry, zero again when k1_finalize is through
   unsigned* bucket_base;   // [n_buckets + 1] bases + [n_buckets] valid voxels per bucket   (kept with the grid: the leaf pass needs both)
   unsigned* blockbase;     // [n_blocks x n_buckets]
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
