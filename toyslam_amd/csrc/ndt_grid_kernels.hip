@@ -1557,6 +1557,8 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   P.shift = rb | (kb << 8);  // the packed cell <-> (bucket, local) map of the kernels
   P.n_buckets = K;
   P.pts_per_block = std::max(1024, std::min(16384, pow2_ceil((n_points + 383) / 384)));  // >= one block per CU: the LDS atomics of a block run at ~0.7 G/s
+  static const int ppb_env = [] { const char* v = getenv("NDT_K1_PPB"); return v ? atoi(v) : 0; }();
+  if (ppb_env > 0) P.pts_per_block = ppb_env;
   P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
   return true;
 }
