@@ -495,6 +495,38 @@ def test_point_stride_32_and_clone(mods, pair):
     assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())   # the copy did not disturb a
 
 
+def test_output_records_of_32_bytes(mods, pair):
+    """Outputs into caller records wider than 16 bytes (PointXYZI / PointXYZRGB clouds: `out_stride_bytes` 32) -- the aligned
+    cloud, the N1 filter's centroids and the N2 map: the first 16 bytes of every record are what the 16-byte form returns,
+    the rest of the record is left alone (downloads go through the page-locked staging block and a CPU scatter)."""
+    import ctypes as C
+    ndt, _, _ = mods
+    from toyslam_amd import _lib
+    L = _lib.lib()
+    t, s = pair
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    g.setInputSource(s)
+    ref = g.align(n_out=len(s))
+    # aligned cloud
+    out = np.full((len(s), 8), 7.5, np.float32)
+    assert L.ndt_align(g._h, None, None, None, None, None, out.ctypes.data, 32) == 0
+    assert np.array_equal(out[:, :4], ref) and np.all(out[:, 4:] == 7.5)
+    # N1
+    ref_f = g.voxelGridFilter(t, 0.5)
+    out = np.full((len(t), 8), -3.0, np.float32)
+    m = C.c_size_t(0)
+    t32 = np.ascontiguousarray(t, dtype=np.float32)
+    assert L.ndt_voxel_grid_filter(g._h, t32.ctypes.data, len(t32), 12, 1, C.c_float(0.5), out.ctypes.data, 32, C.byref(m)) == 0
+    assert m.value == len(ref_f) and np.array_equal(out[:m.value, :3], ref_f) and np.all(out[:, 4:] == -3.0) and np.all(out[m.value:] == -3.0)
+    # N2
+    g.mapUpdate(t, None, 0.5)
+    ref_m = g.mapGet()
+    out = np.full((len(ref_m), 8), 11.0, np.float32)
+    assert L.ndt_map_get(g._h, out.ctypes.data, 32) == 0
+    assert np.array_equal(out[:, :3], ref_m) and np.all(out[:, 4:] == 11.0)
+
+
 def test_edge_cases(mods, pair):
     ndt, po, _ = mods
     t, s = pair
