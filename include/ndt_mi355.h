@@ -211,10 +211,10 @@ ndt_status ndt_align_batch_device(ndt_handle h, const void* d_pts, const size_t*
 
 /* How many independent lock-step groups ndt_align_batch* runs the batch as (each on a stream and a host thread of
  * its own, so one group's host-side Newton / More-Thuente steps and launches hide behind the other groups' kernels):
- * 0 = automatic (2 from 16 scans, 4 from 48), 1 = one lock-step loop.  Every scan's result is independent of the
- * members of its group; with the spatial ordering of the batch common to a group, results of different groupings
- * agree to the rounding of the f64 sums.  Batches with an exchange step (communicator / all-reduce hook) always run as
- * one loop. */
+ * 0 = automatic (2 from 16 scans, 4 from 192), 1 = one lock-step loop.  Every scan's result is independent of the
+ * members of its group and of the grouping: every scan is ordered on a lattice of its own and summed in its own blocks, so
+ * a scan gets the same bits in any batch, group or rank.  Batches with an exchange step (communicator / all-reduce hook)
+ * always run as one loop. */
 ndt_status ndt_set_batch_groups(ndt_handle h, int n_groups);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---------------------------

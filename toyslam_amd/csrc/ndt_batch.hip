@@ -410,7 +410,7 @@ static ndt_status align_batch_grouped(ndt_handle h, const void* pts, const size_
   const bool exchange = h && (h->comm != nullptr || h->allreduce != nullptr);
   size_t groups = (h && h->batch_groups_wanted > 0) ? static_cast<size_t>(h->batch_groups_wanted)
                   : forced                           ? static_cast<size_t>(forced)
-                                                     : (n_scans >= 48 ? 4 : n_scans >= 16 ? 2 : 1);  // (64 scans: 5.42k reg/s as two groups, 5.75k as four, 5.54k as six)
+                                                     : (n_scans >= 192 ? 4 : n_scans >= 16 ? 2 : 1);  // (same-box A/B, two / four groups: 64 scans 5.9k / 5.6k reg/s, 96 6.25k / 6.1k, 128 equal, 512 6.4k / 6.6k; one loop: 32 scans 3.8k against 5.4k as two)
   groups = std::min(groups, std::max<size_t>(1, n_scans / 4));
   // (event pairs around the kernels of a lock-step -- ndt_profile_enable(1) -- only mean something without overlap)
   if (!h || !offsets || exchange || groups <= 1 || !h->grid || !h->target || h->profiling)
