@@ -109,6 +109,27 @@ def test_matrix_to_pose(ndt):
         assert np.abs(ndt.host_pose_to_matrix(q) - T).max() < 5e-6
 
 
+def test_rotation_substitution_is_bounded_by_an_independent_f32_svd(ndt):
+    """rotation() of the guess matrix (Eigen: computeRotationScaling through an f32 JacobiSVD, ndt_omp_impl.hpp:103-111) is
+    restated -- by the product and the oracle alike -- as the f64 polar factor rounded to f32, so the two cannot show a
+    disagreement with a real f32 SVD.  An f32 SVD of a different family (LAPACK sgesdd through numpy) can: the polar factor
+    U V^T it gives, fed through the same Euler extraction, moves the rebuilt guess by less than 2e-6 -- two orders below the
+    1e-4 rotation tolerance -- over poses of the size the nodes produce (and the restatement is exact for Identity)."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for _ in range(400):
+        p = np.r_[rng.uniform(-50, 50, 3), rng.uniform(-1.5, 1.5, 3)]
+        T = po.pose_to_matrix(p)  # f32 products of three f32 axis rotations: orthonormal to ~1e-7
+        U, _, Vt = np.linalg.svd(T[:3, :3].astype(np.float32))
+        assert U.dtype == np.float32
+        T2 = T.copy()
+        T2[:3, :3] = (U @ Vt).astype(np.float32)
+        q, q2 = ndt.host_matrix_to_pose(T), ndt.host_matrix_to_pose(T2)
+        worst = max(worst, float(np.abs(ndt.host_pose_to_matrix(q) - ndt.host_pose_to_matrix(q2)).max()))
+    assert worst < 2e-6, worst
+    assert np.array_equal(ndt.host_matrix_to_pose(np.eye(4, dtype=np.float32)), np.zeros(6))
+
+
 def test_angle_derivatives_quirks(ndt):
     p = np.array([0, 0, 0, 0.3, -0.2, 0.5])
     j, h, jd, hd = ndt.host_angle_derivatives(p)
