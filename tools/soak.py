@@ -44,7 +44,11 @@ def main():
     n = {name: 0 for name, _ in cases}
     bad = 0
     k = 0
+    t_say = time.time() + 30.0
     while time.time() < t_end:
+        if time.time() > t_say:  # (a GPU box takes a run that stays silent for minutes to be hung)
+            print("... registrations so far:", n, "mismatches:", bad, flush=True)
+            t_say = time.time() + 30.0
         name, g = cases[k % len(cases)]
         k += 1
         reps = 200 if name.startswith("pair") else 20
