@@ -16,6 +16,11 @@ Cases
                   ndt_rosbag_mapping_node.cpp:130), epsilon 1e-3.
   pyramid       : configs[4] -- scans 0 and 5 of the 16-scan sequence of toyslam_amd.pyramid.write_sequence,
                   levels 2.0 -> 1.0 -> 0.5 m, each level's result the next level's guess (epsilon 0.01, 35 iterations).
+  cfgA          : configs[1], the headline, exactly as bench.py runs it -- set U (1M-pt uniform target, 100k-pt source,
+                  T_gt as config 2), 1.0 m voxels, DIRECT7, identity guess, max_iterations 28, epsilon 1e-9 (SURVEY 8(d):
+                  30 outer passes).  `python oracle/gen_golden_large.py --only cfgA` adds / refreshes this case alone
+                  (seconds) and leaves the others as committed.
+  cfgA_eval     : one computeDerivatives evaluation of that pair at the pose of T_gt.
 """
 import json
 import os
@@ -46,7 +51,37 @@ def res_dict(r, dt):
             "trans_probability": r["trans_probability"], "oracle_seconds": dt}
 
 
+def cfg_a(out):
+    """configs[1] with bench.py's parameters (bench.py: MAX_ITER, EPS = 28, 1e-9; set U; source seed SEED + 1)."""
+    tgt = clouds.target_uniform(1000000)
+    src = clouds.source_from_target(tgt, 100000)
+    o = po.OracleNDT(resolution=1.0, num_threads=THREADS, max_iter=28, trans_eps=1e-9)
+    o.set_target(tgt)
+    o.set_source(src)
+    t0 = time.time()
+    r = o.align()
+    out["cfgA"] = res_dict(r, time.time() - t0)
+    out["cfgA"]["inputs"] = {"target": "clouds.target_uniform(1000000)", "source": "clouds.source_from_target(target, 100000)",
+                             "resolution": 1.0, "max_iterations": 28, "transformation_epsilon": 1e-9}
+    print("cfgA", {k: v for k, v in out["cfgA"].items() if k not in ("T", "inputs")}, flush=True)
+    p = np.array([0.30, -0.20, 0.10] + list(np.deg2rad([0.5, -0.3, 1.0])))
+    sc, g, H, nn = o.eval(p, True)
+    out["cfgA_eval"] = {"p": p.tolist(), "score": sc, "gradient": g.tolist(), "hessian": H.tolist(), "mean_neighbors": nn}
+    print("cfgA_eval score %.6f h-bar %.4f" % (sc, nn), flush=True)
+
+
 def main():
+    path = os.path.join(ROOT, "tests", "golden", "large_golden.json")
+    if "--only" in sys.argv:
+        which = sys.argv[sys.argv.index("--only") + 1]
+        assert which == "cfgA", "only cfgA can be refreshed alone"
+        with open(path) as f:
+            out = json.load(f)
+        cfg_a(out)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        print("updated", path)
+        return
     out = {"generator": "oracle/gen_golden_large.py", "threads": THREADS,
            "inputs": {"target": "clouds.target_surfaces(10000000, extent=400.0, n_boxes=60)",
                       "source": "clouds.source_from_target(target, 2000000)  (T_gt = clouds.T_GT_DEFAULT)"}}
@@ -101,7 +136,7 @@ def main():
             print("pyramid scan", k, "level", res, {kk: v for kk, v in d.items() if kk != "T"}, flush=True)
         pyr[str(k)] = {"T_gt": Tg.tolist(), "levels": lv}
     out["pyramid"] = pyr
-    path = os.path.join(ROOT, "tests", "golden", "large_golden.json")
+    cfg_a(out)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)

@@ -140,7 +140,7 @@ def test_align_app_reproduces_readme_table(built_lib, pair, golden, tmp_path):
     for b in blocks:
         name = b.split(")")[0]
         fields = {ln.split(":")[0].strip(): ln.split(":", 1)[1].strip() for ln in b.splitlines() if ":" in ln}
-        assert float(fields["fitness"]) == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        assert float(fields["fitness"]) == pytest.approx(golden["readme_fitness"][name], abs=2e-6)
         assert fields["converged"].startswith("1")
         assert float(fields["single"].split("[")[0]) > 0 and float(fields["10times"].split("[")[0]) > 0
     # with the down-sample step (idempotent on an already filtered cloud up to the order of the points)

@@ -1,6 +1,7 @@
-"""GPU: BASELINE.json's configs[2], configs[3] and configs[4] at their stated sizes.
+"""GPU: BASELINE.json's configs[1] (the headline), configs[2], configs[3] and configs[4] at their stated sizes.
 
-The CPU oracle needs minutes at these sizes, so parity is pinned three ways:
+configs[1] is compared with the committed golden vectors AND with the live oracle (one registration costs it
+seconds).  For the larger configurations the CPU oracle needs minutes, so parity is pinned three ways:
   * against tests/golden/large_golden.json -- the faithful oracle's answers on the same seeded inputs, computed once
     by oracle/gen_golden_large.py (committed generator, committed numbers);
   * against the live oracle on a same-geometry reduction that finishes in seconds;
@@ -50,6 +51,66 @@ def cfg_b(mods):
 def close_sums(a, b, rel=2e-6):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-30)
+
+
+# ------------------------------------------------------------------ configs[1]: the headline, with bench.py's parameters
+def test_config1_full_size_follows_the_oracle(mods, large_golden):
+    """100k-pt source vs 1M-pt target, set U, 1.0 m voxels, DIRECT7, max_iterations 28, epsilon 1e-9 -- the registration
+    bench.py times (ndt_omp_impl.hpp:80-171, convergence rule :158-164): against the committed
+    golden vectors (oracle/gen_golden_large.py, cfgA) and against the live oracle on the same inputs."""
+    ndt, po, clouds, _ = mods
+    tgt = clouds.target_uniform(1000000)
+    src = clouds.source_from_target(tgt, 100000)
+    gold = large_golden["cfgA"]
+    g = ndt.NormalDistributionsTransform()
+    g.setResolution(1.0)
+    g.setNeighborhoodSearchMethod(ndt.DIRECT7)
+    g.setMaximumIterations(28)
+    g.setTransformationEpsilon(1e-9)
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align()
+    T1 = g.getFinalTransformation()
+    st = g.stats()
+    # golden vectors
+    Tg = np.array(gold["T"])
+    assert rot_err(T1, Tg) < ROT_TOL and trans_err(T1, Tg) < TRANS_TOL
+    assert g.getFinalNumIteration() == gold["iterations"] == 30
+    assert st["n_evals"] == gold["n_evals"] == 41
+    assert st["n_hessian_recomputes"] == gold["n_hessian_recomputes"] == 1
+    assert g.hasConverged() == gold["converged"]
+    assert g.getTransformationProbability() == pytest.approx(gold["trans_probability"], rel=2e-6)
+    # the live oracle, same inputs, same parameters
+    o = po.OracleNDT(resolution=1.0, search_method=po.DIRECT7, num_threads=16, max_iter=28, trans_eps=1e-9)
+    o.set_target(tgt)
+    o.set_source(src)
+    r = o.align()
+    assert rot_err(T1, r["T"]) < ROT_TOL and trans_err(T1, r["T"]) < TRANS_TOL
+    assert np.array_equal(np.asarray(r["T"], dtype=np.float64), Tg)  # the committed golden IS the live oracle's answer
+    assert g.getFinalNumIteration() == r["iterations"]
+    assert st["n_evals"] == r["n_evals"] and st["n_hessian_recomputes"] == r["n_hessian_recomputes"]
+    assert g.getTransformationProbability() == pytest.approx(r["trans_probability"], rel=2e-6)
+    # observed agreement is far inside the tolerance; keep a regression bound two orders below it
+    assert rot_err(T1, r["T"]) < 1e-6 and trans_err(T1, r["T"]) < 1e-5
+    # one evaluation at the pose of T_gt: score / gradient / Hessian sums and the exact neighbour count
+    ge = large_golden["cfgA_eval"]
+    sc, gr, H, nn = g.eval(np.array(ge["p"]), True)
+    assert nn == pytest.approx(ge["mean_neighbors"], abs=1e-12)
+    assert sc == pytest.approx(ge["score"], rel=2e-6)
+    assert close_sums(gr, ge["gradient"]) and close_sums(H, ge["hessian"])
+    so, go, Ho, no = o.eval(np.array(ge["p"]), True)
+    assert nn == pytest.approx(no, abs=1e-12) and sc == pytest.approx(so, rel=2e-6)
+    assert close_sums(gr, go) and close_sums(H, Ho)
+    # the f64 computeHessian path (ndt_omp_impl.hpp:540-645) at the same pose
+    H64, H64o = g.hessian_f64(np.array(ge["p"])), o.hessian_f64(np.array(ge["p"]))
+    assert np.abs(H64 - H64o).max() <= 1e-11 * np.abs(H64o).max()
+    # bit-identical re-run; the evaluation server and the launch path agree bit for bit at this size too
+    g.align()
+    assert np.array_equal(T1, g.getFinalTransformation())
+    g.setEvaluationPath(0)
+    g.align()
+    assert np.array_equal(T1, g.getFinalTransformation())
+    g.setEvaluationPath(1)
 
 
 # ------------------------------------------------------------------ configs[2]

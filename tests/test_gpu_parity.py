@@ -336,9 +336,10 @@ def test_readme_fitness_on_gpu(mods, pair, golden):
         out = g.align(n_out=len(s))
         d, _ = cKDTree(t.astype(np.float64)).query(out[:, :3].astype(np.float64))
         fit = float(np.mean((d.astype(np.float32) ** 2).astype(np.float64)))
-        assert fit == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        # the window test_readme_fitness_pins_the_transform (tests/test_oracle_golden.py) measured the pin's power for
+        assert fit == pytest.approx(golden["readme_fitness"][name], abs=2e-6)
         # ... and computed by the library itself (row N4: getFitnessScore on the GPU)
-        assert g.getFitnessScore() == pytest.approx(golden["readme_fitness"][name], abs=5e-6)
+        assert g.getFitnessScore() == pytest.approx(golden["readme_fitness"][name], abs=2e-6)
         assert g.getFitnessScore() == pytest.approx(fit, rel=1e-6)
 
 
@@ -675,9 +676,10 @@ def test_batch_stats_and_step_profile(mods, pair):
 
 # ------------------------------------------------------------------ BASELINE size
 def test_full_size_properties(mods):
-    """config[1]: 100 k-pt source vs 1 M-pt target, 1.0 m voxels, 30 Newton passes (max_iter 28, eps 0).
-    The oracle needs minutes at this size, so: recovery of the known T_gt, run-to-run bit-identity,
-    linearity of the sums in the points, and h-bar in the expected range."""
+    """config[1]'s sizes on the surface scene (set S), 30 Newton passes with eps 0: size-independent properties --
+    recovery of the known T_gt, run-to-run bit-identity, linearity of the sums in the points, h-bar in range.
+    (The headline itself -- set U, eps 1e-9 -- is compared with the oracle and its golden vectors in
+    tests/test_gpu_fullsize.py::test_config1_full_size_follows_the_oracle.)"""
     ndt, po, clouds = mods
     tgt = clouds.target_surfaces(1000000)
     src = clouds.source_from_target(tgt, 100000)

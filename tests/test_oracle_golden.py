@@ -77,6 +77,31 @@ def test_readme_fitness_pins_the_transform(pair, golden, name):
                 assert moved_t > 12 * window and moved_r > 12 * window, (name, axis, sign, moved_t, moved_r)
 
 
+def test_headline_golden_is_the_oracles_answer():
+    """tests/golden/large_golden.json: cfgA (configs[1] with bench.py's parameters) is what the oracle computes today --
+    the committed numbers the -m gpu headline test compares against cannot drift from the restatement unnoticed."""
+    import json
+    import os
+    from toyslam_amd import clouds
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_golden.json")) as f:
+        gold = json.load(f)
+    tgt = clouds.target_uniform(1000000)
+    src = clouds.source_from_target(tgt, 100000)
+    o = po.OracleNDT(resolution=1.0, search_method=po.DIRECT7, num_threads=3, max_iter=28, trans_eps=1e-9)
+    o.set_target(tgt)
+    o.set_source(src)
+    r = o.align()
+    g = gold["cfgA"]
+    assert (r["iterations"], r["n_evals"], r["n_hessian_recomputes"]) == (g["iterations"], g["n_evals"], g["n_hessian_recomputes"]) == (30, 41, 1)
+    # the sums are added in index order whatever the thread count (ndt_omp_impl.hpp:277-282), so: the same bits
+    assert np.array_equal(np.asarray(r["T"], dtype=np.float64), np.array(g["T"]))
+    assert r["trans_probability"] == g["trans_probability"]
+    ge = gold["cfgA_eval"]
+    sc, gr, H, nn = o.eval(np.array(ge["p"]), True)
+    assert sc == ge["score"] and nn == ge["mean_neighbors"]
+    assert np.array_equal(gr, np.array(ge["gradient"])) and np.array_equal(H, np.array(ge["hessian"]))
+
+
 def test_grid_matches_golden(oracle, golden, golden_grid):
     g = oracle.grid()
     assert len(g["idx"]) == golden["grid_1p0"]["n_leaves"] == 1098
