@@ -73,6 +73,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="scans per GPU for --workload batch")
     ap.add_argument("--extent", type=float, default=400.0, help="scene size of --workload large / pyramid (SURVEY 8(d): 400 m)")
     ap.add_argument("--seq-scans", type=int, default=16, help="scans of the streamed sequence of --workload pyramid")
+    ap.add_argument("--near-guess", action="store_true",
+                    help="--workload large: register from a guess 4 cm / 0.03 deg off T_gt with epsilon 1e-3, 35 iterations -- the "
+                         "align(output, guess) path of ndt_rosbag_mapping_node.cpp:130 (tests/golden/large_golden.json: cfgB_near)")
+    ap.add_argument("--lockstep-steps", type=int, default=3, help="N > 1 mapbuild: timed steps of the RCCL lock-step leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bind", action="store_true", help="leave the CPU affinity of the rank alone (default: the cores of the GPU's NUMA node)")
     ap.add_argument("--no-mapbuild-leg", action="store_true", help="N = 1 single: skip the 512-scan map-build leg")
@@ -115,19 +119,55 @@ def self_launch(args, argv):
         print(json.dumps({"launcher": "self", "n_ranks": args.gpus, "ranks": plan,
                           "command": [sys.executable, os.path.abspath(__file__)] + argv}))
         return 0
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a pipe nobody drains while we poll could fill up)
     for r, e in enumerate(envs):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+    rcs = supervise(procs, float(os.environ.get("NDT_BENCH_LAUNCH_BUDGET_S", "1500")))
+    out0.seek(0)
+    lines = [ln for ln in out0.read().decode("utf-8", "replace").splitlines() if ln.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
     rc = max(abs(c) for c in rcs)
     if rc or not lines:
         sys.stderr.write("bench.py self-launch: rank exit codes %s\n" % rcs)
     return rc if rc else (0 if lines else 1)
+
+
+def supervise(procs, budget_s, grace_s=20.0, poll_s=0.2):
+    """Wait for every child.  If one exits non-zero (a rank that dies before the rendezvous leaves the others waiting in
+    init_process_group or in a collective for ever) or the wall-clock budget runs out, the remaining ranks get SIGTERM,
+    then SIGKILL after grace_s.  Returns the exit codes (a killed child reports its negative signal number; a child
+    stopped because of ANOTHER child's failure counts as failed too).  Never execs, never kills by pattern: only the
+    PIDs started here."""
+    t0 = time.monotonic()
+    failed = False
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(c is not None for c in rcs):
+            break
+        if any(c not in (None, 0) for c in rcs) or time.monotonic() - t0 > budget_s:
+            failed = True
+            break
+        time.sleep(poll_s)
+    if failed:
+        why = "budget of %.0f s exhausted" % budget_s if all(c in (None, 0) for c in rcs) else "a rank failed"
+        sys.stderr.write("bench.py self-launch: %s (exit codes so far %s); stopping the remaining ranks\n" % (why, rcs))
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < grace_s:
+            time.sleep(poll_s)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        rcs = [p.returncode if p.returncode else 1 for p in procs]
+    return rcs
 
 
 # =====================================================================================================
@@ -163,7 +203,19 @@ def host_info():
         quota = None if q == "max" else float(q) / float(per)
     except (OSError, ValueError):
         pass
-    return {"cpu_model": model, "logical_cpus": len(cpus), "physical_cores": len(cores), "cgroup_cpu_quota": quota}
+    granted = len(cores) if quota is None else max(1, min(len(cores), int(quota)))  # threads the kernel will really run
+    return {"cpu_model": model, "logical_cpus": len(cpus), "physical_cores": len(cores), "cgroup_cpu_quota": quota,
+            "granted_cpus": granted}
+
+
+def cgroup_throttle_counters():
+    """(nr_throttled, throttled_usec) of this process's cgroup (v2 cpu.stat), or None: how often the kernel parked the
+    cgroup's threads for having used up its CPU bandwidth -- the failure mode of too many spinning host threads."""
+    try:
+        d = dict(ln.split() for ln in open("/sys/fs/cgroup/cpu.stat").read().splitlines() if ln.strip())
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return None
 
 
 def bind_near_gpu(local_rank):
@@ -363,8 +415,15 @@ def main():
     reg = ndt.NormalDistributionsTransform(device=local_rank)
     reg.setResolution(RESOLUTION)
     reg.setNeighborhoodSearchMethod(ndt.DIRECT7)
-    reg.setMaximumIterations(MAX_ITER)
-    reg.setTransformationEpsilon(EPS)
+    near = workload == "large" and args.near_guess
+    guess = None
+    if near:  # oracle/gen_golden_large.py: NEAR_GUESS, cfgB_near
+        guess = clouds.make_T([0.30 + 0.04, -0.20 - 0.03, 0.10 + 0.02], np.deg2rad([0.5 + 0.03, -0.3 - 0.02, 1.0 + 0.04]))
+        reg.setMaximumIterations(35)
+        reg.setTransformationEpsilon(1e-3)
+    else:
+        reg.setMaximumIterations(MAX_ITER)
+        reg.setTransformationEpsilon(EPS)
     t0 = time.perf_counter()
     reg.setInputTarget(tgt)
     t_build_first = time.perf_counter() - t0
@@ -380,7 +439,7 @@ def main():
         t_source = median_time(lambda: reg.setInputSource(src))           # H2D + spatial ordering of the scan
 
         def step():
-            reg.align()
+            reg.align(guess)
         regs_per_step_global = world  # replicas: every rank registers its own scan
         scaling = "weak"
     else:
@@ -409,11 +468,13 @@ def main():
         step()
     barrier()
     thr0 = thread_cpu_times() if os.environ.get("NDT_BENCH_THREADS") else None
+    cg0 = cgroup_throttle_counters()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier()
     dt_local = time.perf_counter() - t0
+    cg1 = cgroup_throttle_counters()
     if thr0 is not None:  # diagnostics: which host threads burned CPU during the timed region (cgroup quota hunting)
         thr1 = thread_cpu_times()
         used = sorted(((thr1[t][1] - thr0.get(t, (None, 0))[1], thr1[t][0], t) for t in thr1), reverse=True)
@@ -441,7 +502,8 @@ def main():
         value = steps * regs_per_step_global / dt
         names = {
             "single": "single 100k-pt source vs 1M-pt target, 1.0 m voxels, DIRECT7, 30 Newton passes (max_iterations 28, epsilon 1e-9), set " + args.set,
-            "large": "single 2M-pt source vs 10M-pt target (surface scene, %g m), 0.5 m voxels, DIRECT7, 30 Newton passes" % args.extent,
+            "large": ("single 2M-pt source vs 10M-pt target (surface scene, %g m), 0.5 m voxels, DIRECT7, " % args.extent) +
+                     ("from a guess 4 cm / 0.03 deg off T_gt, epsilon 1e-3, max_iterations 35 (ndt_rosbag_mapping_node.cpp:130)" if near else "30 Newton passes"),
             "mapbuild": "map-build: %d x 100k-pt sources vs one shared 1M-pt target, scans split over %d GPU(s), lock-step batch per GPU, set %s" % (args.scans, world, args.set),
             "batch": "map-build batch: %d x 100k-pt sources per GPU vs one 1M-pt target, lock-step, set %s" % (args.batch, args.set),
         }
@@ -450,11 +512,12 @@ def main():
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": names[workload], "target_points": M_TARGET, "source_points": N_SOURCE, "resolution_m": RESOLUTION,
-                       "search": "DIRECT7", "outer_passes": MAX_ITER + 2,
+                       "search": "DIRECT7", "outer_passes": (None if near else MAX_ITER + 2),
                        "sharding": ("scans split over the ranks (dist.shard_range), target grid replicated, no collective in the data path"
                                     if workload in ("mapbuild", "batch") else "one scan stream per GPU, target grid replicated")},
             "world_size": world, "collective_backend": (dist.get_backend() if dist is not None else None),
             "per_rank_registrations_per_s": per_rank_regs,
+            "cgroup_nr_throttled_in_timed_region_rank0": (cg1[0] - cg0[0]) if (cg0 and cg1) else None,
             "host_binding": binding, "target_build_ms": t_build * 1e3,
             "target_build_roofline": None, "target_build_device_resident_ms": t_build_dev * 1e3,
             "target_build_first_call_ms": t_build_first * 1e3,
@@ -475,7 +538,7 @@ def main():
 
     if workload in ("single", "large"):
         if rank == 0:
-            single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value)
+            single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value, guess)
     else:
         batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps, dt, N_SOURCE, dev if n_local else None, offsets, lo, hi,
                    T_gts, torch)
@@ -489,9 +552,11 @@ def main():
 # =====================================================================================================
 # legs of the single-scan workloads (rank 0, outside the timed region)
 # =====================================================================================================
-def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value):
+def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value, guess=None):
     import numpy as np
     st = reg.stats()
+    out["outer_iterations"] = reg.getFinalNumIteration()
+    out["converged"] = bool(reg.hasConverged())
     T_timed = reg.getFinalTransformation()
     it_timed = reg.getFinalNumIteration()
     out["set_source_ms"] = t_source * 1e3
@@ -508,14 +573,14 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
     reg.profile(2)
     reg.profile_read(3)
     for _ in range(n_rep):
-        reg.align()
+        reg.align(guess)
     n_launch, ms = reg.profile_read(3)
     st2 = reg.stats()
     # ... and, for reference, the same device code as one launch per evaluation (profile mode 1)
     reg.profile(1)
     reg.profile_read(0)
     for _ in range(n_rep):
-        reg.align()
+        reg.align(guess)
     n_eval_launch, ms_eval = reg.profile_read(0)
     reg.profile(0)
     hbar = st2["mean_neighbors"]
@@ -571,6 +636,17 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
                            "achieved_GBs": bytes_per_eval / (ms_eval * 1e-3 / max(n_eval_launch, 1)) / 1e9}}
     out["roofline"].update(committed)
     out["us_per_evaluation_in_timed_region"] = dt / steps / max(st["n_evals"] + st["n_hessian_recomputes"], 1) * 1e6
+    # where an evaluation's time goes through the persistent server: a round with no per-point body (command -> every block
+    # -> row stores -> shard tickets -> part sums -> host) against a full with-Hessian round (ndt_diag_server_roundtrip)
+    if server_used and workload == "single":
+        try:
+            rt = reg.diag_server_roundtrip(ndt.host_matrix_to_pose(T_timed), 300)
+            out["protocol_us_per_evaluation"] = rt["nop_us"]
+            out["body_us_per_evaluation"] = rt["with_hessian_us"] - rt["nop_us"]
+            out["server_round_us"] = {"no_body": rt["nop_us"], "without_hessian": rt["no_hessian_us"], "with_hessian": rt["with_hessian_us"],
+                                      "how": "ndt_diag_server_roundtrip: 300 rounds of each kind through the evaluation server at the final pose"}
+        except Exception as e:
+            out["server_round_us"] = {"error": repr(e)}
     out["registration_algorithmic_GBs"] = (st["n_evals"] + st["n_hessian_recomputes"]) * bytes_per_eval / (dt / steps) / 1e9
 
     # ---- configs[3] on this one GPU: the denominator of the 8-GPU map-build comparison ----
@@ -605,31 +681,31 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
         hi_ = host_info()
         out["host"] = hi_
         phys = max(1, hi_["physical_cores"])
-        # faithful port at all physical cores and at 16 threads (one GPU's share of an 8-GPU host)
-        med, n_t, tb, r = timed_oracle(po, tgt, src, RESOLUTION, phys, False, 12.0)
-        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": phys, "kind": "port",
+        granted = hi_["granted_cpus"]
+        # THE baseline: the faithful port with as many threads as the box really runs -- min(physical cores, floor(cgroup CPU
+        # quota)).  Threads beyond the quota are throttled by the kernel, not run, and make the port SLOWER.
+        med, n_t, tb, r = timed_oracle(po, tgt, src, RESOLUTION, granted, False, 12.0)
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "registrations/s", "cores": granted, "kind": "port",
                                "sample": "%d full registrations of the same workload (median), after 1 warm-up; align only, target grid resident" % n_t,
                                "ms_per_registration": med * 1e3, "target_build_ms": tb * 1e3, "evaluations": r["n_evals"],
-                               "cpu_model": hi_["cpu_model"], "threads": phys, "host_logical_cpus": hi_["logical_cpus"],
-                               "cgroup_cpu_quota": hi_["cgroup_cpu_quota"],
-                               "note": "threads beyond the cgroup's CPU quota are throttled by the kernel, not run: see cpu_baseline_16_threads "
-                                       "and cpu_baseline_optimised.by_threads for the same port at the box's granted share"}
+                               "cpu_model": hi_["cpu_model"], "threads": granted, "host_logical_cpus": hi_["logical_cpus"],
+                               "host_physical_cores": phys, "cgroup_cpu_quota": hi_["cgroup_cpu_quota"],
+                               "note": "threads = min(physical cores, floor(cgroup CPU quota)): what this box grants the process"}
         out["parity_vs_oracle"] = {"rot_max_abs": float(np.abs(T_timed[:3, :3] - r["T"][:3, :3]).max()),
                                    "trans_max_abs_m": float(np.abs(T_timed[:3, 3] - r["T"][:3, 3]).max()),
                                    "iterations_gpu": it_timed, "iterations_oracle": r["iterations"],
                                    "evals_gpu": st["n_evals"], "evals_oracle": r["n_evals"]}
         best_cpu = 1.0 / med
-        if phys != 16:
-            t16 = min(16, hi_["logical_cpus"])
-            med16, n16, _, _ = timed_oracle(po, tgt, src, RESOLUTION, t16, False, 10.0)
-            out["cpu_baseline_16_threads"] = {"value": 1.0 / med16, "unit": "registrations/s", "cores": t16, "threads": t16, "kind": "port",
-                                              "sample": "%d full registrations (median)" % n16, "ms_per_registration": med16 * 1e3}
-            best_cpu = max(best_cpu, 1.0 / med16)
+        if phys > granted:  # for the record: every physical core of the host, most of them throttled
+            medp, np_, _, _ = timed_oracle(po, tgt, src, RESOLUTION, phys, False, 6.0)
+            out["cpu_baseline_all_cores_throttled"] = {"value": 1.0 / medp, "unit": "registrations/s", "cores": phys, "threads": phys, "kind": "port",
+                                                       "sample": "%d full registrations (median)" % np_, "ms_per_registration": medp * 1e3,
+                                                       "note": "%d threads inside a cgroup that grants %s CPUs" % (phys, hi_["cgroup_cpu_quota"])}
         # also an OPTIMISED CPU variant, so that the ratio is not inflated by the reference's own
         # inefficiencies (rb-tree voxel lookup, N x 344 B scratch allocated, zeroed and summed per evaluation,
         # serial f64 Hessian).  Same arithmetic per neighbour.
         opt = {}
-        for thr in sorted({phys, min(16, hi_["logical_cpus"])}):
+        for thr in sorted({granted, min(16, hi_["logical_cpus"])}):
             med_o, n_o, _, ro = timed_oracle(po, tgt, src, RESOLUTION, thr, True, 6.0)
             opt[thr] = {"value": 1.0 / med_o, "ms_per_registration": med_o * 1e3, "threads": thr, "runs": n_o, "evaluations": ro["n_evals"]}
             best_cpu = max(best_cpu, 1.0 / med_o)
@@ -691,11 +767,11 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
         done = threading.Event()
 
         def watchdog():  # a collective that never completes must not take the measured line down with it
-            if not done.wait(180.0):
+            if not done.wait(float(os.environ.get("NDT_BENCH_LOCKSTEP_BUDGET_S", "240"))):
                 if rank == 0:
-                    out["lockstep_allreduce"] = {"error": "timed out after 180 s"}
+                    out["lockstep_allreduce"] = {"error": "timed out: a collective of the lock-step leg never returned"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)  # the measured line is out; the run still FAILED (rc != 0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             on_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -709,12 +785,16 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
                       first_scan=lo, total_scans=args.scans)
             res = reg.alignBatchSharded(**kw)  # warm-up (communicator set-up, first collective)
             torch.cuda.synchronize()
+            n_ls = max(1, args.lockstep_steps)
+            thr0 = cgroup_throttle_counters()
             dist.barrier()
             ta = time.perf_counter()
-            res = reg.alignBatchSharded(**kw)
+            for _ in range(n_ls):
+                res = reg.alignBatchSharded(**kw)
             torch.cuda.synchronize()
             dist.barrier()
-            tl = time.perf_counter() - ta
+            tl = (time.perf_counter() - ta) / n_ls
+            thr1 = cgroup_throttle_counters()
             t = torch.tensor([tl], dtype=torch.float64, device=on_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ok = 0
@@ -723,11 +803,39 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
             okt = torch.tensor([float(ok)], dtype=torch.float64, device=on_dev)
             dist.all_reduce(okt)
             cs = reg.commStats()
+            # one more pass with HIP events on the library stream: per lock-step, the derivative kernels / k_reduce +
+            # ncclAllReduce / k_publish_rows, and the host's wall time for the whole step (ndt_profile_enable(1), kinds 0, 4, 5, 6)
+            reg.profile(1)
+            for k in (0, 4, 5, 6):
+                reg.profile_read(k)
+            reg.alignBatchSharded(**kw)
+            torch.cuda.synchronize()
+            split = {k: reg.profile_read(k) for k in (0, 4, 5, 6)}
+            reg.profile(0)
+            n_st = max(split[6][0], 1)
+            mine = torch.zeros((world, 5), dtype=torch.float64, device=on_dev)
+            mine[rank, 0] = split[0][1] / n_st * 1e3
+            mine[rank, 1] = split[4][1] / max(split[4][0], 1) * 1e3
+            mine[rank, 2] = split[5][1] / max(split[5][0], 1) * 1e3
+            mine[rank, 3] = split[6][1] / n_st * 1e3
+            mine[rank, 4] = float((thr1[0] - thr0[0]) if (thr0 and thr1) else -1)
+            dist.all_reduce(mine)
+            per_rank = mine.cpu().numpy()
             result = {"value": args.scans / float(t.item()), "unit": "registrations/s", "ms_per_step": float(t.item()) * 1e3,
-                      "registrations_ending_at_T_gt": int(okt.item()), "lock_steps": cs["collectives"],
+                      "steps": n_ls, "registrations_ending_at_T_gt": int(okt.item()), "lock_steps": cs["lock_steps"],
                       "allreduce_doubles_per_lock_step": args.scans * 32, "rccl_world_size": cs["world"],
+                      "per_lock_step_us": {"lock_steps_profiled": int(n_st),
+                                           "derivative_kernels": [float(x) for x in per_rank[:, 0]],
+                                           "reduce_plus_ncclAllReduce": [float(x) for x in per_rank[:, 1]],
+                                           "publish_rows": [float(x) for x in per_rank[:, 2]],
+                                           "host_wall": [float(x) for x in per_rank[:, 3]],
+                                           "how": "per rank; HIP events on the library stream in one extra profiled pass (ndt_profile_enable(1): "
+                                                  "kinds 0 / 4 / 5) and the host's wall clock per lock-step (kind 6)"},
+                      "cgroup_nr_throttled_delta_per_rank": [int(x) for x in per_rank[:, 4]],
+                      "host_thread_plan": dict(zip(("affinity_cpus", "cgroup_quota_cpus", "local_world_size"), ndt.host_thread_budget())),
                       "what": "every rank steps all %d solvers; rows of the scans a rank does not own are zero; one in-place "
                               "ncclAllReduce(sum) of the [%d][32] f64 buffer per lock-step on the library stream (C++, ndt_comm_*)" % (args.scans, args.scans)}
+            result["host_thread_plan"]["pool_threads"], result["host_thread_plan"]["max_batch_groups"] = ndt.host_thread_plan(*ndt.host_thread_budget())
             reg.commDestroy()
         except Exception as e:
             result = {"error": repr(e)}

@@ -228,6 +228,11 @@ ndt_status ndt_set_batch_groups(ndt_handle h, int n_groups);
  *    guesses and the per-scan outputs have total_scans entries and come out identical on every rank.
  *  - ndt_align with a communicator set: the source cloud each rank holds is a SHARD of one big scan (target replicated);
  *    the 32-f64 row of every evaluation is all-reduced, so all ranks walk the same registration.
+ * PRECONDITION of both: every rank holds the SAME target (same points, same parameters) -- the grid is replicated, not
+ * exchanged.  A rank whose target has no voxel at all still joins the exchange of a sharded batch with zero rows; in the
+ * point-sharded ndt_align such a rank returns without a collective, which is consistent only when every rank's target
+ * is that empty one.  If a peer never joins a collective the waiting rank gives up after NDT_BATCH_TIMEOUT_S (60)
+ * seconds, aborts its communicator (ncclCommAbort, so that its stream drains) and returns NDT_ERR_COMM.
  * The collective is issued from C++ on the handle's own stream (no host synchronisation around it); librccl is loaded
  * on first use.  ndt_comm_get_unique_id (rank 0) wraps ncclGetUniqueId; the caller carries the NDT_COMM_ID_BYTES to
  * the other ranks (MPI, a file, torch.distributed ...), then every rank calls ndt_comm_init_rank on its own device. */
@@ -282,6 +287,9 @@ ndt_status ndt_grid_dump(ndt_handle h, int64_t* idx, int* nr_points, double* mea
  * on = 1: ndt_align runs one launch per evaluation and brackets each with an event pair; kind 0 =
  *         derivatives with Hessian, 1 = without, 2 = f64 Hessian.  ndt_align_batch brackets the
  *         derivative kernels of every lock-step with one pair: kind 0, n_launches = lock-steps.
+ *         With a communicator set (ndt_align_batch_sharded) every lock-step is split three ways: kind 0 the
+ *         derivative kernels, kind 4 k_reduce + ncclAllReduce, kind 5 k_publish_rows (all on the library stream),
+ *         and kind 6 the host's wall time for the whole lock-step (descriptors, launches, wait, solver steps), in ms.
  * on = 2: ndt_align keeps its persistent kernel (one launch per registration, the kernel of the
  *         timed region) and brackets that launch with one event pair; kind 3.
  * Off (0) by default: the event records cost host time. */
@@ -327,6 +335,14 @@ void ndt_host_matrix_to_pose(const float* T /*16 col-major*/, double* p /*6*/); 
 void ndt_host_angle_derivatives(const double* p /*6*/, float* j_ang /*8*3*/, float* h_ang /*15*3*/,
                                 double* j_ang_d /*8*3*/, double* h_ang_d /*15*3*/);              /* :288-395 */
 void ndt_host_gauss(float resolution, double outlier_ratio, double* d /*3: d1,d2,d3*/);          /* :86-93 */
+/* Host threads a lock-step batch may use.  ndt_host_thread_budget probes this process: CPUs in its affinity mask, the
+ * cgroup's CPU bandwidth in CPUs (cpu.max / cfs_quota; 0 = unlimited) and LOCAL_WORLD_SIZE (ranks sharing the node, 1
+ * when unset).  ndt_host_thread_plan is the pure rule applied to such a budget: share = min(affinity, floor(quota)) /
+ * local_world_size (at least 1); *pool_threads = clamp(share / 2, 1, 16) workers for the per-step solver work (they
+ * block when idle), *max_batch_groups = clamp(share, 1, 8) independent lock-step groups (a host thread each).
+ * NDT_HOST_THREADS / NDT_BATCH_GROUPS / ndt_set_batch_groups override. */
+void ndt_host_thread_budget(int* affinity_cpus, double* quota_cpus, int* local_world_size);
+void ndt_host_thread_plan(int affinity_cpus, double quota_cpus, int local_world_size, int* pool_threads, int* max_batch_groups);
 /* Runs the Newton + More-Thuente driver against a caller-supplied evaluator
  * (test hook: lets the CPU suite drive the PRODUCT driver with oracle
  * evaluations).  kind: 0 = derivatives with Hessian, 1 = without, 2 = f64

@@ -56,3 +56,39 @@ def rot_err(Ta, Tb):
 
 def trans_err(Ta, Tb):
     return float(np.abs(np.asarray(Ta)[:3, 3] - np.asarray(Tb)[:3, 3]).max())
+
+
+def run_ranks(cmds_envs, timeout=300):
+    """Start one process per (argv, env), wait for all of them and return [(returncode, stdout, stderr)].  Whatever
+    happens -- a rank failing before the rendezvous, the timeout, an exception here -- no child is left behind: the
+    survivors are killed by PID (never by pattern) in the finally block."""
+    import subprocess
+    import tempfile
+    import time
+    procs, files = [], []
+    try:
+        for argv, env in cmds_envs:
+            fo, fe = tempfile.TemporaryFile(), tempfile.TemporaryFile()  # files, not pipes: nobody has to drain them while we poll
+            files.append((fo, fe))
+            procs.append(subprocess.Popen(argv, env=env, stdout=fo, stderr=fe))
+        t0 = time.monotonic()
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break  # a failed rank leaves its peers waiting in a collective for ever
+            if time.monotonic() - t0 > timeout:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    out = []
+    for p, (fo, fe) in zip(procs, files):
+        fo.seek(0)
+        fe.seek(0)
+        out.append((p.returncode, fo.read().decode("utf-8", "replace"), fe.read().decode("utf-8", "replace")))
+        fo.close()
+        fe.close()
+    return out

@@ -70,3 +70,35 @@ def test_same_entry_point_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["world_size"] == 2
+
+
+def test_self_launch_stops_the_other_ranks_when_one_dies(tmp_path):
+    """A rank that dies before the rendezvous (a HIP init failure on one GPU) must not leave the launcher waiting for ever
+    with the other ranks alive: bench.supervise terminates the survivors and reports failure."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    sleeper = [sys.executable, "-c", "import time; time.sleep(600)"]
+    procs = [subprocess.Popen(sleeper), subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(3)"]), subprocess.Popen(sleeper)]
+    t0 = time.monotonic()
+    try:
+        rcs = bench.supervise(procs, budget_s=120.0, grace_s=5.0, poll_s=0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert time.monotonic() - t0 < 30
+    assert all(p.poll() is not None for p in procs)
+    assert rcs[1] == 3 and all(c != 0 for c in rcs)
+    # ... and the wall-clock budget: healthy but endless ranks are stopped too
+    procs = [subprocess.Popen(sleeper), subprocess.Popen(sleeper)]
+    try:
+        rcs = bench.supervise(procs, budget_s=1.0, grace_s=5.0, poll_s=0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.poll() is not None for p in procs) and all(c != 0 for c in rcs)
+    # ... and the good case is left alone
+    procs = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.supervise(procs, budget_s=60.0) == [0, 0, 0]

@@ -39,6 +39,38 @@ def test_no_device_means_error_not_fallback(built_lib, ndt):
     assert e.value.status == _lib.NDT_ERR_NO_DEVICE
 
 
+def test_host_thread_plan_respects_quota_affinity_and_ranks(ndt):
+    """Host threads of a lock-step batch (ndt_batch.hip: StepPool, batch groups) are sized from min(cgroup quota, affinity)
+    / LOCAL_WORLD_SIZE: eight ranks on a box that grants 16 CPUs must not start 16 spinning workers each."""
+    plan = ndt.host_thread_plan
+    assert plan(256, 0.0, 1) == (16, 8)       # a whole host, one rank: the caps
+    assert plan(256, 0.0, 8) == (16, 8)       # 32 CPUs per rank
+    assert plan(128, 16.0, 1) == (8, 8)       # the one-GPU boxes of this pool: 16 CPUs granted of 128 visible
+    assert plan(128, 16.0, 8) == (1, 2)       # the same quota shared by eight ranks: 2 CPUs each
+    assert plan(128, 16.7, 8) == (1, 2)       # floor(quota)
+    assert plan(8, 0.0, 1) == (4, 8)
+    assert plan(8, 0.0, 8) == (1, 1)          # floor 1
+    assert plan(4, 2.5, 1) == (1, 2)
+    assert plan(1, 0.0, 1) == (1, 1) and plan(0, 0.0, 0) == (1, 1) and plan(64, 0.4, 4) == (1, 1)
+    for aff in (1, 3, 16, 100, 512):
+        for q in (0.0, 0.5, 1.0, 7.9, 64.0):
+            for lw in (1, 2, 8, 64):
+                p, g = plan(aff, q, lw)
+                cpus = aff if q <= 0 else min(aff, max(1, int(q)))
+                share = max(1, cpus // lw)
+                assert 1 <= p <= max(1, share // 2) <= 16 or p == 1 or p == 16
+                assert 1 <= g <= min(8, share)
+    # the probe: what this very process has
+    import os
+    a, q, w = ndt.host_thread_budget()
+    assert a == len(os.sched_getaffinity(0)) and w == int(os.environ.get("LOCAL_WORLD_SIZE", "1")) and q >= 0.0
+    try:
+        qs, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        assert q == (0.0 if qs == "max" else float(qs) / float(per))
+    except OSError:
+        pass
+
+
 def test_gauss_constants(ndt):
     for res, ratio in ((1.0, 0.55), (0.5, 0.55), (2.0, 0.35)):
         o = po.OracleNDT(resolution=res, outlier_ratio=ratio)

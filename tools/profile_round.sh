@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats + PMC (FETCH_SIZE / WRITE_SIZE in separate passes) of the
 # default bench command.  Usage (on the GPU box): tools/profile_round.sh r01
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/rNN_* is made from, in one GPU-box call:  gpurun --timeout 1200 -- bash tools/record_round.sh r02
+# Everything profiles/rNN_* is made from, in one GPU-box call:  gpurun --timeout 1200 -- bash tools/record_round.sh r03
 # (kernel stats + PMC passes of the default command, VALU counters, the batch profile, one bench line per workload)
-# afterwards, here: python tools/summarize_batch_profile.py r02; cp gpurun_out/r02/{summary.json,kernel_stats.csv} and gpurun_out/r02_*.json to profiles/
-tag=${1:-r02}
+# afterwards, here: python tools/summarize_batch_profile.py r03; cp gpurun_out/r03/{summary.json,kernel_stats.csv} and gpurun_out/r03_*.json to profiles/
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd $R
 bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile_round.log 2>&1
@@ -11,6 +11,7 @@ bash tools/profile_batch.sh > gpurun_out/${tag}_profile_batch.log 2>&1
 cd $R
 python3 bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 python3 bench.py --workload large > gpurun_out/${tag}_bench_large.json 2>/dev/null
+python3 bench.py --workload large --near-guess > gpurun_out/${tag}_bench_large_near.json 2>/dev/null
 python3 bench.py --workload large --extent 200 > gpurun_out/${tag}_bench_large200.json 2>/dev/null
 python3 bench.py --workload batch --batch 64 > gpurun_out/${tag}_bench_batch64.json 2>/dev/null
 python3 bench.py --workload batch --batch 256 > gpurun_out/${tag}_bench_batch256.json 2>/dev/null

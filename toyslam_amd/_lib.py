@@ -112,6 +112,8 @@ SIGNATURES = {
     "ndt_host_matrix_to_pose": (None, [fp, dp]),
     "ndt_host_angle_derivatives": (None, [dp, fp, fp, dp, dp]),
     "ndt_host_gauss": (None, [C.c_float, C.c_double, dp]),
+    "ndt_host_thread_budget": (None, [ip, dp, ip]),
+    "ndt_host_thread_plan": (None, [C.c_int, C.c_double, C.c_int, ip, ip]),
     "ndt_host_run_driver": (C.c_int, [EVAL_CB, vp, C.c_size_t, fp, C.c_float, C.c_double, C.c_double, C.c_double,
                                       C.c_int, fp, ip, ip, dp, ip, ip]),
     "ndt_pcd_sequence_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),

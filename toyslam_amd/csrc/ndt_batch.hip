@@ -2,14 +2,19 @@
 // (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
 #include "ndt_internal.hpp"
 
+#include <condition_variable>
 #include <dlfcn.h>
+#include <sched.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is dlopen'ed (no link-time dependency)
 
 namespace ndtc {
 
-// Small spinning worker pool for the per-step host work of a lock-step batch (one Newton /
-// More-Thuente state machine per scan: 6x6 SVD solves, pose -> matrix, angle tables).  Threads
-// live for one ndt_align_batch call.
+// Small worker pool for the per-step host work of a lock-step batch (one Newton / More-Thuente
+// state machine per scan: 6x6 SVD solves, pose -> matrix, angle tables).  Threads live for one
+// ndt_align_batch call.  An idle worker spins for about 50 us (the gap between the two jobs of one lock-step is
+// shorter than that when the step is host-bound) and then BLOCKS on a condition variable: a lock-step whose kernels
+// run for hundreds of microseconds must not burn a core per worker meanwhile -- on a box whose cgroup grants a few
+// CPUs to eight ranks the spinning is what exhausts the CFS quota and parks the polling thread.
 class StepPool {
  public:
   explicit StepPool(int n_threads) : n_(std::max(1, n_threads)) {
@@ -17,7 +22,7 @@ class StepPool {
   }
   ~StepPool() {
     stop_.store(true, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_acq_rel);
+    post();
     for (auto& w : workers_) w.join();
   }
   // runs fn(i) for i in [0, count), statically partitioned; returns when all are done
@@ -32,19 +37,32 @@ class StepPool {
       for (size_t i = lo; i < hi; i++) fn(i);
     };
     pending_.store(n_ - 1, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_acq_rel);
+    post();
     job_(0);
     while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
   }
 
  private:
+  void post() {
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    if (sleepers_.load(std::memory_order_acquire) > 0) {
+      std::lock_guard<std::mutex> g(mu_);  // a sleeper re-checks gen_ under this lock before it waits: no lost wake-up
+      cv_.notify_all();
+    }
+  }
   void loop(int t) {
     unsigned long long seen = 0;
     for (;;) {
+      const auto idle_since = std::chrono::steady_clock::now();
       unsigned spins = 0;
       while (gen_.load(std::memory_order_acquire) == seen) {
         __builtin_ia32_pause();
-        if (++spins > 20000) { std::this_thread::yield(); spins = 0; }
+        if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(50)) {
+          std::unique_lock<std::mutex> lk(mu_);
+          sleepers_.fetch_add(1, std::memory_order_acq_rel);
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+        }
       }
       seen = gen_.load(std::memory_order_acquire);
       if (stop_.load(std::memory_order_acquire)) return;
@@ -57,8 +75,60 @@ class StepPool {
   std::function<void(int)> job_;
   std::atomic<unsigned long long> gen_{0};
   std::atomic<int> pending_{0};
+  std::atomic<int> sleepers_{0};
   std::atomic<bool> stop_{false};
+  std::mutex mu_;
+  std::condition_variable cv_;
 };
+
+// ---- how many host threads a rank may use -----------------------------------------------------------
+// CPUs this process can really run on: its affinity mask, cut down to the cgroup's CPU bandwidth (cgroup v2
+// cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us: threads beyond the quota are throttled by the kernel, not run),
+// shared between the ranks of this node (LOCAL_WORLD_SIZE: one process per GPU).
+static double read_cgroup_quota() {
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    double per = 0;
+    const int n = std::fscanf(f, "%63s %lf", q, &per);
+    std::fclose(f);
+    if (n == 2 && std::strcmp(q, "max") != 0 && per > 0) return std::atof(q) / per;
+    if (n >= 1) return 0.0;  // "max": no limit
+  }
+  double quota = -1, per = 0;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    if (std::fscanf(f, "%lf", &quota) != 1) quota = -1;
+    std::fclose(f);
+  }
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+    if (std::fscanf(f, "%lf", &per) != 1) per = 0;
+    std::fclose(f);
+  }
+  return (quota > 0 && per > 0) ? quota / per : 0.0;
+}
+
+void host_thread_budget(int* affinity_cpus, double* quota_cpus, int* local_world) {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int aff = 0;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) aff = CPU_COUNT(&set);
+  if (aff <= 0) aff = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+  int lw = 1;
+  if (const char* v = getenv("LOCAL_WORLD_SIZE")) lw = std::max(1, atoi(v));
+  if (affinity_cpus) *affinity_cpus = aff;
+  if (quota_cpus) *quota_cpus = read_cgroup_quota();
+  if (local_world) *local_world = lw;
+}
+
+// pure: the plan for a given budget.  share = min(affinity, floor(quota)) / local_world, at least 1.  One of the
+// share is the thread that drives the batch (launches, polls); the pool gets the rest up to 16 threads (the per-step
+// host work of 512 solvers stops scaling there), the batch groups at most one host thread per CPU of the share.
+void host_thread_plan(int affinity_cpus, double quota_cpus, int local_world, int* pool_threads, int* max_groups) {
+  int cpus = std::max(1, affinity_cpus);
+  if (quota_cpus > 0) cpus = std::min(cpus, std::max(1, static_cast<int>(std::floor(quota_cpus))));
+  const int share = std::max(1, cpus / std::max(1, local_world));
+  if (pool_threads) *pool_threads = std::max(1, std::min(16, share / 2));
+  if (max_groups) *max_groups = std::max(1, std::min(8, share));
+}
 
 }  // namespace ndtc
 
@@ -72,6 +142,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // optional
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string error;
@@ -94,6 +165,7 @@ static Rccl* rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) r.error = "librccl lacks an expected symbol";
   });
@@ -123,6 +195,11 @@ ndt_status comm_allreduce(ndt_context* h, double* d_buf, size_t n) {
   return NDT_OK;
 }
 
+static int poll_timeout_s() {
+  static const int v = [] { const char* e = getenv("NDT_BATCH_TIMEOUT_S"); return e ? std::max(1, atoi(e)) : 60; }();
+  return v;
+}
+
 // waits until slot 31 of every listed row of the pinned result block carries `seq`
 template <class LiveFn>
 static ndt_status poll_rows(ndt_context* h, size_t n_rows, unsigned long long seq, const LiveFn& live) {
@@ -139,8 +216,20 @@ static ndt_status poll_rows(ndt_context* h, size_t n_rows, unsigned long long se
           if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
           return fail(NDT_ERR_HIP, "batch step finished without publishing its results");
         }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(poll_timeout_s())) {
+          // a peer never joined the collective: the enqueued ncclAllReduce and everything behind it would sit on the
+          // stream for ever (and ndt_destroy / ndt_comm_destroy synchronise that stream) -- abort the communicator so
+          // that the stream drains; the handle is left without one
+          if (h->comm) {
+            Rccl* r = rccl();
+            if (r && r->CommAbort) (void)r->CommAbort(static_cast<ncclComm_t>(h->comm));
+            h->comm = nullptr;
+            h->comm_rank = 0;
+            h->comm_world = 1;
+            return fail(NDT_ERR_COMM, "timed out waiting for the exchange step (a rank never joined the all-reduce); communicator aborted");
+          }
           return fail(NDT_ERR_HIP, "timed out waiting for the batch step");
+        }
       }
     }
   }
@@ -195,8 +284,10 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
     if (h->comm) {
       ndt_status sc = comm_allreduce(h, h->batch_out.p, total * ndt::kEvalStride);
       if (sc) return sc;
+      if (h->profiling) HIP_TRY(hipEventRecord(h->ev_c, h->stream));
       const unsigned long long seq = ++h->eval_seq;
       HIP_TRY(ndt::launch_publish_rows(h->batch_out.p, static_cast<int>(total), h->host_result, seq, h->stream));
+      if (h->profiling) HIP_TRY(hipEventRecord(h->ev_d, h->stream));
       return poll_rows(h, total, seq, live);
     }
     // caller-supplied collective (host tests over gloo; torch.distributed on the device buffer): not stream-ordered
@@ -261,7 +352,11 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
   static const int n_host_threads = [] {
     const char* v = getenv("NDT_HOST_THREADS");
     if (v) return std::max(1, atoi(v));
-    return static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
+    int aff = 1, lw = 1, pool = 1;
+    double quota = 0;
+    host_thread_budget(&aff, &quota, &lw);
+    host_thread_plan(aff, quota, lw, &pool, nullptr);
+    return pool;
   }();
   StepPool pool((total >= 32 && !h->is_batch_worker) ? n_host_threads : 1);  // grouped batches: the groups are the host parallelism
   static const bool batch_timing = [] { const char* v = getenv("NDT_TIMING"); return v && atoi(v) != 0; }();
@@ -306,8 +401,14 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       else fill_eval_params(rq, gs, kd_radius2(h->resolution), descs[g].P);
     });
     const auto tb1 = now();
-    if (degenerate) {
+    if (degenerate && !exchange) {
       std::memset(h->host_result, 0, total * ndt::kEvalStride * sizeof(double));
+    } else if (degenerate) {
+      // this rank's target has no voxel: its rows are zero, but it still joins the exchange -- the other ranks' grids
+      // need not be empty (every rank is SUPPOSED to hold the same target; a rank that does not must not hang the rest)
+      HIP_TRY(hipMemsetAsync(h->batch_out.p, 0, total * ndt::kEvalStride * sizeof(double), h->stream));
+      s = exchange_rows([&](size_t g) { return live_kind[g] != ndt::EVAL_NONE; });
+      if (s) return s;
     } else {
       // one H2D copy: descriptors and the three active lists are contiguous in the pinned block
       // (by a kernel reading the page-locked block: a few KB are in HBM before a DMA engine would have started)
@@ -348,6 +449,17 @@ static ndt_status align_batch_impl(ndt_handle h, const void* pts, const size_t* 
       HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
       h->prof_n[0]++;
       h->prof_ms[0] += ms;
+      if (h->comm) {  // ... the exchange: k_reduce + ncclAllReduce (slot 4), k_publish_rows (slot 5)
+        HIP_TRY(hipEventSynchronize(h->ev_d));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_b, h->ev_c));
+        h->prof_n[4]++;
+        h->prof_ms[4] += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_c, h->ev_d));
+        h->prof_n[5]++;
+        h->prof_ms[5] += ms;
+      }
+      h->prof_n[6]++;  // slot 6: host wall time of the lock-step (descriptor fill + launches + wait + solver steps), ms
+      h->prof_ms[6] += secs(tb0, now()) * 1e3;
     }
     static const int trace_scan = [] { const char* v = getenv("NDT_BATCH_TRACE"); return v ? atoi(v) : -1; }();
     if (trace_scan >= 0 && static_cast<size_t>(trace_scan) < total && live_kind[trace_scan] != ndt::EVAL_NONE) {
@@ -412,6 +524,14 @@ static ndt_status align_batch_grouped(ndt_handle h, const void* pts, const size_
                   : forced                           ? static_cast<size_t>(forced)
                                                      : (n_scans >= 192 ? 4 : n_scans >= 16 ? 2 : 1);  // (same-box A/B, two / four groups: 64 scans 5.9k / 5.6k reg/s, 96 6.25k / 6.1k, 128 equal, 512 6.4k / 6.6k; one loop: 32 scans 3.8k against 5.4k as two)
   groups = std::min(groups, std::max<size_t>(1, n_scans / 4));
+  static const int max_groups = [] {
+    int aff = 1, lw = 1, mg = 1;
+    double quota = 0;
+    host_thread_budget(&aff, &quota, &lw);
+    host_thread_plan(aff, quota, lw, nullptr, &mg);
+    return mg;
+  }();
+  if (!(h && h->batch_groups_wanted > 0) && !forced) groups = std::min(groups, static_cast<size_t>(max_groups));  // a host thread per group
   // (event pairs around the kernels of a lock-step -- ndt_profile_enable(1) -- only mean something without overlap)
   if (!h || !offsets || exchange || groups <= 1 || !h->grid || !h->target || h->profiling)
     return align_batch_impl(h, pts, offsets, n_scans, stride, on_device, guesses, final_T, conv, iters, tprob);
@@ -450,6 +570,14 @@ static ndt_status align_batch_grouped(ndt_handle h, const void* pts, const size_
     });
   }
   for (auto& t : threads) t.join();
+  // the workers' rows have been polled, so their streams are idle: drop their references to the target and its grid (a
+  // caller that now sets a new target must not find hundreds of MB of the old one pinned until the next batch)
+  for (size_t g = 0; g < groups; g++) {
+    ndt_context* w = h->batch_workers[g];
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    w->target.reset();
+    w->grid.reset();
+  }
   long long ne = 0, nh = 0;
   double nn_w = 0, pts_w = 0;
   int steps = 0;
@@ -491,6 +619,13 @@ ndt_status ndt_align_batch_sharded_device(ndt_handle h, const void* d_pts, const
                                           int* iters, double* tprob) {
   if (total_scans == 0) return fail(NDT_ERR_INVALID, "total_scans must be > 0");
   return align_batch_impl(h, d_pts, offsets, n_local, stride, true, guesses, final_T, conv, iters, tprob, first_scan, total_scans);
+}
+
+void ndt_host_thread_budget(int* affinity_cpus, double* quota_cpus, int* local_world_size) {
+  host_thread_budget(affinity_cpus, quota_cpus, local_world_size);
+}
+void ndt_host_thread_plan(int affinity_cpus, double quota_cpus, int local_world_size, int* pool_threads, int* max_batch_groups) {
+  host_thread_plan(affinity_cpus, quota_cpus, local_world_size, pool_threads, max_batch_groups);
 }
 
 ndt_status ndt_set_batch_groups(ndt_handle h, int n_groups) {

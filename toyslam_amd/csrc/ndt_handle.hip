@@ -191,6 +191,8 @@ ndt_status ndt_profile_enable(ndt_handle h, int on) {
     if (s) return s;
     if (!h->ev_a) HIP_TRY(hipEventCreate(&h->ev_a));
     if (!h->ev_b) HIP_TRY(hipEventCreate(&h->ev_b));
+    if (!h->ev_c) HIP_TRY(hipEventCreate(&h->ev_c));
+    if (!h->ev_d) HIP_TRY(hipEventCreate(&h->ev_d));
   }
   h->profiling = on == 1;
   h->profile_server = on == 2;
@@ -198,7 +200,7 @@ ndt_status ndt_profile_enable(ndt_handle h, int on) {
 }
 
 ndt_status ndt_profile_read(ndt_handle h, int kind, long long* n_launches, double* total_ms, int reset) {
-  if (!h || kind < 0 || kind > 3) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h || kind < 0 || kind >= ndt_context::kProfSlots) return fail(NDT_ERR_INVALID, "bad arguments");
   if (n_launches) *n_launches = h->prof_n[kind];
   if (total_ms) *total_ms = h->prof_ms[kind];
   if (reset) {

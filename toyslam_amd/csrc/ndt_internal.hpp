@@ -105,12 +105,14 @@ class DevPool {
     if (!p) return;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    bool over = false;
     {
       std::lock_guard<std::mutex> g(m_);
       free_.insert(std::make_pair(Key(dev, tls_pool_stream, cls), p));
       cached_ += cls;
+      over = cached_ > kPoolTrimBytes;
     }
-    if (cached_ > kPoolTrimBytes) trim(kPoolTrimBytes / 2);
+    if (over) trim(kPoolTrimBytes / 2);
   }
   // blocks cached for a stream that is about to be destroyed: give them back
   void forget_stream(hipStream_t st) {
@@ -309,9 +311,10 @@ struct ndt_context {
   bool profiling = false;       // mode 1: one launch per evaluation, an event pair around each
   bool profile_server = false;  // mode 2: the persistent kernel of each registration between one event pair
   bool server_timed = false;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  long long prof_n[4] = {0, 0, 0, 0};
-  double prof_ms[4] = {0, 0, 0, 0};
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  static constexpr int kProfSlots = 7;  // 0-2 evaluation kinds / lock-step kernels, 3 server launch, 4-6 exchange step (ndt_mi355.h)
+  long long prof_n[kProfSlots] = {0, 0, 0, 0, 0, 0, 0};
+  double prof_ms[kProfSlots] = {0, 0, 0, 0, 0, 0, 0};
   // collective hook
   ndt_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -348,6 +351,8 @@ struct ndt_context {
     if (batch_pinned) (void)hipHostFree(batch_pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    if (ev_c) (void)hipEventDestroy(ev_c);
+    if (ev_d) (void)hipEventDestroy(ev_d);
     if (stream) {
       DevPool::instance().forget_stream(stream);
       (void)hipStreamDestroy(stream);

@@ -481,6 +481,20 @@ def host_angle_derivatives(p):
     return j, h, jd, hd
 
 
+def host_thread_budget():
+    """(CPUs in the affinity mask, cgroup CPU bandwidth in CPUs or 0.0 for unlimited, LOCAL_WORLD_SIZE) as the library probes them."""
+    a, w, q = C.c_int(0), C.c_int(0), C.c_double(0)
+    _lib.lib().ndt_host_thread_budget(C.byref(a), C.byref(q), C.byref(w))
+    return a.value, q.value, w.value
+
+
+def host_thread_plan(affinity_cpus, quota_cpus, local_world_size):
+    """(pool threads, max batch groups) the library would use for that budget (pure)."""
+    p, g = C.c_int(0), C.c_int(0)
+    _lib.lib().ndt_host_thread_plan(int(affinity_cpus), float(quota_cpus), int(local_world_size), C.byref(p), C.byref(g))
+    return p.value, g.value
+
+
 def host_gauss(resolution, outlier_ratio):
     d = np.zeros(3)
     _lib.lib().ndt_host_gauss(float(resolution), float(outlier_ratio), _d(d))
