@@ -9,8 +9,8 @@
 // getFitnessScore through the base class -- so the class derives from pcl::IterativeClosestPoint
 // (hence pcl::Registration) and overrides the virtual setInput* and computeTransformation.
 //
-// Not carried over: setSourceCovariances / setTargetCovariances (:147-166, caller-supplied covariance
-// vectors; no caller in the reference), the protected per-point helpers (computeCovariances,
+// setSourceCovariances / setTargetCovariances (:165-168,186-189) are carried over (gicp_set_*_covariances).
+// Not carried over: the protected per-point helpers (computeCovariances,
 // mahalanobis(), computeRDerivative, estimateRigidTransformationBFGS, the BFGS functor), which live
 // behind the C-ABI.  Needs PCL at compile time like the original; compile- and run-checked here against
 // the stand-ins of tests/pcl_stub/ (test-only).
@@ -77,18 +77,26 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
     }
     pcl::IterativeClosestPoint<PointSource, PointTarget>::setInputSource(cloud);
     input_covariances_.reset();
+    source_cov_dirty_ = false;  // setting the cloud resets the handle's matrices too
     check(gicp_set_input_source(handle_, cloud->points.data(), cloud->points.size(), sizeof(PointSource)), "gicp_set_input_source");
   }
   /** :165-168 -- used by the next align instead of the k-NN covariances, until setInputSource */
-  inline void setSourceCovariances(const MatricesVectorPtr& covariances) { input_covariances_ = covariances; }
+  inline void setSourceCovariances(const MatricesVectorPtr& covariances) {
+    input_covariances_ = covariances;
+    source_cov_dirty_ = true;
+  }
   /** :156-160 */
   inline void setInputTarget(const PointCloudTargetConstPtr& target) override {
     pcl::IterativeClosestPoint<PointSource, PointTarget>::setInputTarget(target);
     target_covariances_.reset();
+    target_cov_dirty_ = false;
     check(gicp_set_input_target(handle_, target->points.data(), target->points.size(), sizeof(PointTarget)), "gicp_set_input_target");
   }
   /** :186-189 */
-  inline void setTargetCovariances(const MatricesVectorPtr& covariances) { target_covariances_ = covariances; }
+  inline void setTargetCovariances(const MatricesVectorPtr& covariances) {
+    target_covariances_ = covariances;
+    target_cov_dirty_ = true;
+  }
 
   inline void setRotationEpsilon(double epsilon) { rotation_epsilon_ = epsilon; }  // :213
   inline double getRotationEpsilon() { return rotation_epsilon_; }                 // :219
@@ -129,9 +137,12 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
     gicp_set_transformation_epsilon(handle_, transformation_epsilon_);
     gicp_set_maximum_iterations(handle_, max_iterations_);
     gicp_set_max_correspondence_distance(handle_, corr_dist_threshold_);
-    // caller-supplied covariances (:386,392: the class computes its own only while these are missing or empty)
-    push_covariances(target_covariances_, false);
-    push_covariances(input_covariances_, true);
+    // caller-supplied covariances (gicp_omp_impl.hpp:386-397: the class computes its own k-NN covariances whenever the
+    // pointer is missing or the vector empty -- so a null / empty setter call CLEARS what an earlier call supplied).
+    // Pushed only when a setter ran since the last align: the matrices are flattened and uploaded once, not per align.
+    if (target_cov_dirty_) push_covariances(target_covariances_, false);
+    if (source_cov_dirty_) push_covariances(input_covariances_, true);
+    target_cov_dirty_ = source_cov_dirty_ = false;
     int conv = 0, iters = 0;
     float final_T[16];
     std::vector<float> moved(input_->points.size() * 4);
@@ -151,6 +162,7 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
   double rotation_epsilon_;
   int max_inner_iterations_;
   MatricesVectorPtr input_covariances_, target_covariances_;
+  bool source_cov_dirty_ = false, target_cov_dirty_ = false;  // a setter ran since the handle last saw the matrices
 
  private:
   static int default_device() {
@@ -158,7 +170,11 @@ class GeneralizedIterativeClosestPoint : public pcl::IterativeClosestPoint<Point
     return v ? std::atoi(v) : 0;
   }
   void push_covariances(const MatricesVectorPtr& c, bool source) {
-    if (!c || c->empty()) return;
+    if (!c || c->empty()) {  // back to the class's own k-NN covariances
+      check(source ? gicp_set_source_covariances(handle_, nullptr, 0) : gicp_set_target_covariances(handle_, nullptr, 0),
+            source ? "gicp_set_source_covariances" : "gicp_set_target_covariances");
+      return;
+    }
     std::vector<double> flat(c->size() * 9);
     for (size_t i = 0; i < c->size(); i++)
       for (int r = 0; r < 3; r++)

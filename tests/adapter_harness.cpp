@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
     reg2->setInputSource(source);  // resets the source's covariances: k-NN ones again, the target keeps the supplied ones
     reg2->align(*aligned4);
     print("gicp_mixed_cov", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
+    // gicp_omp_impl.hpp:386-397: an empty pointer means "compute them": a null setter call after an earlier supplied set
+    // must bring the k-NN covariances back (the first GICP registration above), not keep the stale matrices
+    gicp_omp->setTargetCovariances(GICP::MatricesVectorPtr());
+    reg2->align(*aligned4);
+    print("gicp_cleared_cov", reg2->getFinalTransformation(), reg2->hasConverged(), 0);
   }
   return 0;
 }

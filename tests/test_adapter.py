@@ -115,6 +115,10 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     conv, _, Tm = parse("gicp_mixed_cov")
     assert conv == int(rm["converged"])
     assert rot_err(Tm, rm["T"]) < 1e-4 and trans_err(Tm, rm["T"]) < 1e-3
+    # setTargetCovariances(null) after a supplied set: both clouds on their own k-NN covariances again = the first registration
+    conv, _, Tc = parse("gicp_cleared_cov")
+    assert conv == 1 and rot_err(Tc, rg["T"]) < 1e-4 and trans_err(Tc, rg["T"]) < 1e-3
+    assert np.array_equal(Tc, Tg)
 
 
 @pytest.mark.gpu
