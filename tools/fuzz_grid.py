@@ -82,6 +82,30 @@ def main():
                         scale = np.abs(y[fin]).max()
                         if np.abs(x[fin] - y[fin]).max() > 1e-8 * scale:
                             why = "%s differs (rel %.3g)" % (k, np.abs(x[fin] - y[fin]).max() / scale)
+        # the RECORDS the evaluations read (the dump above is recomputed by a pass of its own): the other index form builds
+        # them with another kernel chain (bucket form: stable radix sorts; sparse form: one thread per voxel sorting its
+        # indices) -- the same voxels summed in the same order give bit-identical evaluation sums
+        if not why and not gpu_overflow and n >= 8:
+            src = c[rng.choice(n, min(n, 2000), replace=False)]
+            src = src[np.isfinite(src).all(axis=1)]
+            p6 = np.concatenate([rng.uniform(-0.3, 0.3, 3) * res, rng.uniform(-0.03, 0.03, 3)])
+            if len(src):
+                ev = []
+                for form in (1, 2):
+                    g2 = ndt.NormalDistributionsTransform()
+                    g2.setResolution(res)
+                    g2.setVoxelIndex(form)
+                    g2.setMinPointPerVoxel(min_pts)
+                    g2.setCovEigValueInflationRatio(eig)
+                    try:
+                        g2.setInputTarget(wide, is_dense=dense)
+                    except ndt.NdtError:
+                        ev = None
+                        break
+                    g2.setInputSource(src)
+                    ev.append(g2.eval(p6, True))
+                if ev and not (ev[0][0] == ev[1][0] and np.array_equal(ev[0][1], ev[1][1]) and np.array_equal(ev[0][2], ev[1][2]) and ev[0][3] == ev[1][3]):
+                    why = "records differ between the dense and the sparse index form (evaluation sums not bit-identical)"
         if why:
             bad += 1
             print("MISMATCH K1 case", case, "index form", index_form, "n", n, "extent", extent, "res", res, "min_pts", min_pts, "eig", eig, "dense", dense, ":", why)

@@ -1,5 +1,13 @@
-mkdir -p gpurun_out
-set -e
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "grid or batch or compaction or dump" > gpurun_out/k1_check_tests.log 2>&1
-timeout -k 10 200 python tools/time_k1_1m.py > gpurun_out/k1_check_time.log 2>&1
-timeout -k 10 200 python tools/fuzz_grid.py 40 > gpurun_out/k1_check_fuzz.log 2>&1
+#!/bin/bash
+# K1 after a change (GPU box): the grid tests, the randomised grid check, build times per cloud shape, kernel stats at 1 M points
+#   gpurun --timeout 900 -- bash tools/k1_check.sh
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=gpurun_out/k1
+mkdir -p $O
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "grid or voxel or sparse or map or fitness or small_host or config or full_size" > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log; tail -3 $O/tests.log
+grep -q "rc=0" $O/tests.log || exit 1
+timeout -k 10 300 python tools/fuzz_grid.py 11 80 > $O/fuzz.log 2>&1; tail -2 $O/fuzz.log
+timeout -k 10 300 python tools/time_k1_forms.py > $O/forms.log 2>&1; cat $O/forms.log
+bash tools/prof_k1.sh 1e6 0 1.0 > $O/prof_u.log 2>&1; cat $O/prof_u.log
+bash tools/prof_k1.sh 1e6 100 1.0 > $O/prof_s.log 2>&1; cat $O/prof_s.log
+bash tools/prof_k1.sh 1e7 400 0.5 > $O/prof_10m.log 2>&1; cat $O/prof_10m.log

@@ -486,25 +486,29 @@ ndt_status build_grid(ndt_context* h) {
       HIP_TRY(centroids_by_slot.reserve(rec_slots));
       HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(geo.lut_cells) + 1));
     }
-    DevBuf<unsigned> blockbase, order;
-    // the handle's bucket counters: zero between builds (k1_finalize clears what k1_hist counted); cleared here only when
-    // they are new or a build was cut short
-    if (!h->k1_bucket_count.p) {
-      HIP_TRY(h->k1_bucket_count.reserve(ndt::kK1MaxBuckets));
-      h->k1_bucket_count_clean = false;
-    }
-    if (!h->k1_bucket_count_clean) HIP_TRY(hipMemsetAsync(h->k1_bucket_count.p, 0, ndt::kK1MaxBuckets * sizeof(unsigned), st));
-    h->k1_bucket_count_clean = false;  // until every launch of this build is queued
-    HIP_TRY(g->bucket_base.reserve(2 * K + 1));  // [K + 1] bucket bases, [K] valid voxels per bucket (k1_finalize -> k1_count)
-    HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
-    HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
-    HIP_TRY(g->bpts.reserve(n));
+    DevBuf<unsigned> cntmat, order;
+    DevBuf<float4> bpts;
+    HIP_TRY(g->bucket_base.reserve(K + 1));
+    HIP_TRY(g->bucket_stat.reserve(4 * K));
+    HIP_TRY(g->leaf_slots.reserve(n));
+    HIP_TRY(cntmat.reserve((static_cast<size_t>(plan.n_blocks) + 1) * K));
+    HIP_TRY(order.reserve(4 * static_cast<size_t>(n)));
+    HIP_TRY(bpts.reserve(n));
     ndt::GridBuildScratch S{};
-    S.bucket_count = h->k1_bucket_count.p;
+    S.cntmat = cntmat.p;
     S.bucket_base = g->bucket_base.p;
-    S.blockbase = blockbase.p;
-    S.bpts = g->bpts.p;
+    S.bucket_stat = g->bucket_stat.p;
+    S.leaf_slots = g->leaf_slots.p;
+    S.bpts = bpts.p;
     S.order = order.p;
+    static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
+    DevBuf<unsigned long long> stamps;
+    const size_t n_stamp = (static_cast<size_t>(plan.n_blocks) + K) * ndt::kK1StampWords;
+    if (want_stamps) {
+      HIP_TRY(stamps.reserve(n_stamp));
+      HIP_TRY(hipMemsetAsync(stamps.p, 0, n_stamp * sizeof(unsigned long long), st));
+      S.stamps = stamps.p;
+    }
     // Records dense and in ascending cell order (launch_compact_records: two small launches, ~13 us) pay for themselves as
     // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
     // The mapping nodes' clouds (16 k points, one registration of ~6 evaluations per target, records that fit L2 many
@@ -515,7 +519,27 @@ ndt_status build_grid(ndt_context* h) {
                                            g->counts.p, st));
     if (compact)
       HIP_TRY(ndt::launch_compact_records(g->lut.p, geo.lut_cells, recs_by_slot.p, centroids_by_slot.p, g->recs.p, g->centroids.p, tile_sums.p, st));
-    h->k1_bucket_count_clean = true;
+    if (want_stamps) {  // per phase: median and maximum over the blocks, in shader cycles since the block's first stamp
+      std::vector<unsigned long long> hst(n_stamp);
+      HIP_TRY(hipMemcpyAsync(hst.data(), stamps.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      auto report = [&](const char* name, size_t first, size_t nblk) {
+        std::fprintf(stderr, "[k1 stamps] %s (%zu blocks): ", name, nblk);
+        for (int ph = 1; ph < ndt::kK1StampWords; ph++) {
+          std::vector<long long> d;
+          for (size_t b = 0; b < nblk; b++) {
+            const unsigned long long t0 = hst[(first + b) * ndt::kK1StampWords], t = hst[(first + b) * ndt::kK1StampWords + ph];
+            if (t0 && t) d.push_back(static_cast<long long>(t - t0));
+          }
+          if (d.empty()) continue;
+          std::sort(d.begin(), d.end());
+          std::fprintf(stderr, "p%d %lld/%lld  ", ph, d[d.size() / 2], d.back());
+        }
+        std::fprintf(stderr, "\n");
+      };
+      report("k1_scatter", 0, static_cast<size_t>(plan.n_blocks));
+      report("k1_finalize", static_cast<size_t>(plan.n_blocks), K);
+    }
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
   } else {
@@ -569,14 +593,15 @@ ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
   if (g->counts_known) return NDT_OK;
   if (g->leaves_pending) {  // bucket-form build: number the leaves now that somebody wants them
     const size_t K = static_cast<size_t>(g->plan.n_buckets);
-    DevBuf<unsigned> scratch;
-    HIP_TRY(scratch.reserve(4 * K + 4));
-    HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->bpts.p, g->bucket_base.p, scratch.p, g->leaf_cell.p, g->leaf_start.p,
-                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
+    DevBuf<unsigned> occ_base;
+    HIP_TRY(occ_base.reserve(K + 1));
+    HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->leaf_slots.p, g->bucket_base.p, g->bucket_stat.p, occ_base.p, g->leaf_cell.p,
+                                    g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     g->leaves_pending = false;
-    g->bpts.release();
+    g->leaf_slots.release();
     g->bucket_base.release();
+    g->bucket_stat.release();
   }
   unsigned c[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(c, g->counts.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));

@@ -212,11 +212,11 @@ struct DeviceGrid {
   DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
   DevBuf<int> row_any;      // per x-row of cells: occupied or not
   bool have_cell2leaf = false;
-  // bucket-form build (ndt_kernels.hip): kept until the leaf arrays have been written (grid_counts)
+  // bucket-form build (ndt_grid_kernels.hip): kept until the leaf arrays have been written (grid_counts)
   bool leaves_pending = false;
   ndt::GridBuildPlan plan{};
-  DevBuf<float4> bpts;
-  DevBuf<unsigned> bucket_base;
+  DevBuf<uint4> leaf_slots;          // every bucket's runs (cell, start, count) at [bucket base + ordinal]
+  DevBuf<unsigned> bucket_base, bucket_stat;
   ndt::GridView view() const {
     ndt::GridView v;
     v.lut = lut.p;
@@ -300,8 +300,6 @@ struct ndt_context {
   void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
   int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
-  DevBuf<unsigned> k1_bucket_count;  // kK1MaxBuckets counters of the bucket-form grid build, zero between builds (build_grid)
-  bool k1_bucket_count_clean = false;
   DevBuf<unsigned> server_counter;  // two sets of kServerCounterWords, used alternately (server_start)
   int server_counter_set = 0;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
