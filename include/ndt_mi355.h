@@ -84,6 +84,13 @@ ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t 
 /* Same, for clouds already resident in HBM (device pointers on the handle's device). */
 ndt_status ndt_set_input_target_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes, int is_dense);
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+/* Same, BY REFERENCE: the cloud -- dense 16-byte records (x, y, z, anything) on a 16-byte boundary in HBM, pcl::PointXYZ's
+ * layout -- is used where it lies instead of being copied: the caller keeps the memory alive and unchanged for as long as
+ * it is this handle's input (or the input of a handle cloned from it / sharing it), exactly what pcl::Registration's
+ * setInputTarget(ConstPtr) / setInputSource(ConstPtr) promise (ndt_omp.h:122-127: the base class keeps the shared pointer,
+ * it never copies the cloud).  Saves the 16 MB -> 16 MB copy of a 1 M-point target; only the bounding boxes are computed. */
+ndt_status ndt_set_input_target_device_ref(ndt_handle h, const void* d_pts, size_t n, int is_dense);
+ndt_status ndt_set_input_source_device_ref(ndt_handle h, const void* d_pts, size_t n);
 /* The voxel index behind the target grid and the prefilter (the reference's std::map<size_t, Leaf> keyed by the linear
  * voxel index, voxel_grid_covariance_omp.h:201): 0 = chosen by occupancy (default), 1 = dense table over the bounding
  * box, 2 = sparse (sort-based build, hash look-up; what a fine leaf over a wide box needs: the 0.1 m prefilter of

@@ -164,6 +164,48 @@ def test_small_host_clouds_route_equals_device_route(mods, n, floats, dense):
         assert sh == sd and nh == nd_ and np.array_equal(gh_, gd_) and np.array_equal(Hh, Hd)
 
 
+@pytest.mark.parametrize("n,dense", [(1, 1), (3000, 0), (70000, 1), (300000, 0)])
+def test_clouds_by_reference_equal_copied_clouds(mods, n, dense):
+    """ndt_set_input_target_device_ref / ndt_set_input_source_device_ref: 16-byte records in HBM used where they lie (what
+    pcl::Registration's ConstPtr inputs are, ndt_omp.h:122-127) -- the same boxes, grid, evaluation and registration as the
+    copying entry points, whatever sits in the fourth float; anything but aligned 16-byte device records is refused."""
+    ndt, _, clouds = mods
+    rng = np.random.default_rng(4242 + n)
+    rec = np.zeros((n, 4), np.float32)
+    rec[:, :3] = (rng.uniform(-40, 40, (n, 3)) * [1, 1, 0.1]).astype(np.float32)
+    rec[:, 3] = rng.uniform(-1e6, 1e6, n).astype(np.float32)  # (not 1: nothing may read it)
+    if n > 100 and not dense:
+        rec[5, 0] = np.nan
+        rec[17, 2] = np.inf
+    src = np.zeros((max(1, n // 3), 4), np.float32)
+    src[:, :3] = clouds.apply_T(clouds.make_T([0.2, -0.1, 0.05], [0.01, -0.005, 0.02]), np.nan_to_num(rec[: len(src), :3], posinf=0.0))
+    src[:, 3] = 7.0
+    gc, gr = ndt.NormalDistributionsTransform(), ndt.NormalDistributionsTransform()
+    with _DeviceCopies() as dc:
+        d_t, d_s = dc.put(rec), dc.put(src)
+        gc.setInputTargetDevice(d_t, n, 16, is_dense=bool(dense))
+        gr.setInputTargetDeviceRef(d_t, n, is_dense=bool(dense))
+        a, b = gc.grid(), gr.grid()
+        for k in ("min_b", "max_b", "div_b", "idx", "n", "mean", "cov", "icov"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        gc.setInputSourceDevice(d_s, len(src), 16)
+        gr.setInputSourceDeviceRef(d_s, len(src))
+        p = np.array([0.1, -0.05, 0.02, 0.01, -0.02, 0.03])
+        (sa, ga, Ha, na), (sb, gb, Hb, nb) = gc.eval(p), gr.eval(p)
+        assert sa == sb and na == nb and np.array_equal(ga, gb) and np.array_equal(Ha, Hb)
+        if n >= 3000:
+            out_c, out_r = gc.align(n_out=len(src)), gr.align(n_out=len(src))
+            assert np.array_equal(gc.getFinalTransformation(), gr.getFinalTransformation())
+            assert np.array_equal(out_c, out_r) and np.all(out_r[:, 3] == 1.0)  # the aligned cloud's data[3] = 1 (PCL align pre-amble)
+            assert gc.getFitnessScore() == gr.getFitnessScore()
+        # a clone shares the borrowed cloud
+        g2 = gr.copy()
+        assert np.array_equal(g2.grid()["mean"], a["mean"])
+        # refused: misaligned records
+        with pytest.raises(ndt.NdtError):
+            gr.setInputTargetDeviceRef(d_t + 4, max(1, n - 1), is_dense=bool(dense))
+
+
 @pytest.mark.parametrize("res", [0.5, 2.0])
 def test_grid_other_resolutions(mods, pair, res):
     t, s = pair

@@ -12,7 +12,7 @@ n, ext, res = int(float(sys.argv[1])), float(sys.argv[2]), float(sys.argv[3])
 tgt = clouds.target_uniform(n) if ext == 0 else clouds.target_surfaces(n, extent=ext, n_boxes=40)
 dev = torch.from_numpy(np.c_[tgt, np.ones(n, np.float32)]).cuda()
 g = ndt.NormalDistributionsTransform(); g.setResolution(res)
-for i in range(6): g.setInputTargetDevice(dev.data_ptr(), n, 16)
+for i in range(6): g.setInputTargetDeviceRef(dev.data_ptr(), n)
 torch.cuda.synchronize()
 PY
 cd /tmp && export TMPDIR=/tmp

@@ -63,6 +63,8 @@ SIGNATURES = {
     "ndt_set_input_source": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
     "ndt_set_input_target_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int]),
     "ndt_set_input_source_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "ndt_set_input_target_device_ref": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
+    "ndt_set_input_source_device_ref": (C.c_int, [vp, vp, C.c_size_t]),
     "ndt_share_input_source": (C.c_int, [vp, vp]),
     "ndt_set_voxel_index": (C.c_int, [vp, C.c_int]),
     "ndt_align": (C.c_int, [vp, fp, fp, ip, ip, dp, vp, C.c_size_t]),

@@ -70,14 +70,19 @@ ndt_status download_records(ndt_context* h, const float4* d_src, size_t n, void*
 
 // upload + repack to dense float4
 ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
-                        std::shared_ptr<DeviceCloud>& out) {
+                        std::shared_ptr<DeviceCloud>& out, bool by_reference) {
   if (n > 0 && !pts) return fail(NDT_ERR_INVALID, "null point buffer");
   if (stride < 12 || stride % 4) return fail(NDT_ERR_INVALID, "stride_bytes must be a multiple of 4 and >= 12");
   if (n > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "too many points");
   ndt_status s = ensure_device(h);
   if (s) return s;
   auto c = std::make_shared<DeviceCloud>();
-  HIP_TRY(c->pts.reserve(n));
+  // by reference: dense 16-byte records already in HBM are used where they lie -- the caller keeps them alive and unchanged
+  // while they are an input of this handle (what pcl::Registration's ConstPtr inputs promise); only the boxes are computed
+  const bool borrowed = by_reference && on_device && n > 0 && stride == sizeof(float4) && (reinterpret_cast<uintptr_t>(pts) & 15) == 0;
+  if (by_reference && !borrowed && n > 0) return fail(NDT_ERR_INVALID, "a cloud by reference must be device memory of 16-byte records on a 16-byte boundary");
+  if (borrowed) c->pts.borrow(const_cast<float4*>(static_cast<const float4*>(pts)), n);
+  else HIP_TRY(c->pts.reserve(n));
   c->n = n;
   // clouds of at most this many points take the host route (NDT_HOST_STAGE_MAX, 0 = never): the repack + bounding box pass
   // costs the host ~1 ns per point, the device route a blocking pageable copy, a kernel and a wait (~35 us whatever the size)
@@ -106,10 +111,13 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
     }
     // repack and bounding boxes in one pass; the per-block rows come back behind the synchronisation
     // the upload needs anyway (the caller's buffer must be free to go when this returns)
-    const int nb = static_cast<int>(std::min<size_t>(1024, (n + 255) / 256));
+    // (16-byte records: a block per CU and eight 16-byte loads in flight per thread; the rows travel over PCIe one by one,
+    // so fewer, fatter blocks also mean fewer of those writes at the end of the kernel)
+    const bool rec16 = stride == sizeof(float4) && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0;
+    const int nb = static_cast<int>(std::min<size_t>(rec16 ? 256 : 1024, (n + 255) / 256));
     if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
     // the kernel stores its per-block rows straight into pinned host memory (no D2H copy to queue)
-    HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, c->pts.p, h->bbox_rows, nb, h->stream));
+    HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, borrowed ? nullptr : c->pts.p, h->bbox_rows, nb, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const float* mm = h->bbox_rows;
     for (int b = 0; b < nb; b++)
@@ -486,29 +494,25 @@ ndt_status build_grid(ndt_context* h) {
       HIP_TRY(centroids_by_slot.reserve(rec_slots));
       HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(geo.lut_cells) + 1));
     }
-    DevBuf<unsigned> cntmat, order;
-    DevBuf<float4> bpts;
-    HIP_TRY(g->bucket_base.reserve(K + 1));
-    HIP_TRY(g->bucket_stat.reserve(4 * K));
-    HIP_TRY(g->leaf_slots.reserve(n));
-    HIP_TRY(cntmat.reserve((static_cast<size_t>(plan.n_blocks) + 1) * K));
-    HIP_TRY(order.reserve(4 * static_cast<size_t>(n)));
-    HIP_TRY(bpts.reserve(n));
-    ndt::GridBuildScratch S{};
-    S.cntmat = cntmat.p;
-    S.bucket_base = g->bucket_base.p;
-    S.bucket_stat = g->bucket_stat.p;
-    S.leaf_slots = g->leaf_slots.p;
-    S.bpts = bpts.p;
-    S.order = order.p;
-    static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
-    DevBuf<unsigned long long> stamps;
-    const size_t n_stamp = (static_cast<size_t>(plan.n_blocks) + K) * ndt::kK1StampWords;
-    if (want_stamps) {
-      HIP_TRY(stamps.reserve(n_stamp));
-      HIP_TRY(hipMemsetAsync(stamps.p, 0, n_stamp * sizeof(unsigned long long), st));
-      S.stamps = stamps.p;
+    DevBuf<unsigned> blockbase, order;
+    // the handle's bucket counters: zero between builds (k1_finalize clears what k1_hist counted); cleared here only when
+    // they are new or a build was cut short
+    if (!h->k1_bucket_count.p) {
+      HIP_TRY(h->k1_bucket_count.reserve(ndt::kK1MaxBuckets));
+      h->k1_bucket_count_clean = false;
     }
+    if (!h->k1_bucket_count_clean) HIP_TRY(hipMemsetAsync(h->k1_bucket_count.p, 0, ndt::kK1MaxBuckets * sizeof(unsigned), st));
+    h->k1_bucket_count_clean = false;  // until every launch of this build is queued
+    HIP_TRY(g->bucket_base.reserve(2 * K + 1));  // [K + 1] bucket bases, [K] valid voxels per bucket (k1_finalize -> k1_count)
+    HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
+    HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
+    HIP_TRY(g->bpts.reserve(n));
+    ndt::GridBuildScratch S{};
+    S.bucket_count = h->k1_bucket_count.p;
+    S.bucket_base = g->bucket_base.p;
+    S.blockbase = blockbase.p;
+    S.bpts = g->bpts.p;
+    S.order = order.p;
     // Records dense and in ascending cell order (launch_compact_records: two small launches, ~13 us) pay for themselves as
     // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
     // The mapping nodes' clouds (16 k points, one registration of ~6 evaluations per target, records that fit L2 many
@@ -519,27 +523,7 @@ ndt_status build_grid(ndt_context* h) {
                                            g->counts.p, st));
     if (compact)
       HIP_TRY(ndt::launch_compact_records(g->lut.p, geo.lut_cells, recs_by_slot.p, centroids_by_slot.p, g->recs.p, g->centroids.p, tile_sums.p, st));
-    if (want_stamps) {  // per phase: median and maximum over the blocks, in shader cycles since the block's first stamp
-      std::vector<unsigned long long> hst(n_stamp);
-      HIP_TRY(hipMemcpyAsync(hst.data(), stamps.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      auto report = [&](const char* name, size_t first, size_t nblk) {
-        std::fprintf(stderr, "[k1 stamps] %s (%zu blocks): ", name, nblk);
-        for (int ph = 1; ph < ndt::kK1StampWords; ph++) {
-          std::vector<long long> d;
-          for (size_t b = 0; b < nblk; b++) {
-            const unsigned long long t0 = hst[(first + b) * ndt::kK1StampWords], t = hst[(first + b) * ndt::kK1StampWords + ph];
-            if (t0 && t) d.push_back(static_cast<long long>(t - t0));
-          }
-          if (d.empty()) continue;
-          std::sort(d.begin(), d.end());
-          std::fprintf(stderr, "p%d %lld/%lld  ", ph, d[d.size() / 2], d.back());
-        }
-        std::fprintf(stderr, "\n");
-      };
-      report("k1_scatter", 0, static_cast<size_t>(plan.n_blocks));
-      report("k1_finalize", static_cast<size_t>(plan.n_blocks), K);
-    }
+    h->k1_bucket_count_clean = true;
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
   } else {
@@ -593,15 +577,14 @@ ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
   if (g->counts_known) return NDT_OK;
   if (g->leaves_pending) {  // bucket-form build: number the leaves now that somebody wants them
     const size_t K = static_cast<size_t>(g->plan.n_buckets);
-    DevBuf<unsigned> occ_base;
-    HIP_TRY(occ_base.reserve(K + 1));
-    HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->leaf_slots.p, g->bucket_base.p, g->bucket_stat.p, occ_base.p, g->leaf_cell.p,
-                                    g->leaf_start.p, g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
+    DevBuf<unsigned> scratch;
+    HIP_TRY(scratch.reserve(4 * K + 4));
+    HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->bpts.p, g->bucket_base.p, scratch.p, g->leaf_cell.p, g->leaf_start.p,
+                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     g->leaves_pending = false;
-    g->leaf_slots.release();
+    g->bpts.release();
     g->bucket_base.release();
-    g->bucket_stat.release();
   }
   unsigned c[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(c, g->counts.p, sizeof(c), hipMemcpyDeviceToHost, h->stream));
@@ -780,10 +763,10 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
 
 extern "C" {
 
-static ndt_status set_target_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, bool on_device) {
+static ndt_status set_target_impl(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, bool on_device, bool by_ref = false) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   std::shared_ptr<DeviceCloud> c;
-  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c, by_ref);
   if (s) return s;
   h->target = c;
   h->target_dense = is_dense ? 1 : 0;
@@ -795,10 +778,13 @@ ndt_status ndt_set_input_target(ndt_handle h, const void* pts, size_t n, size_t 
 ndt_status ndt_set_input_target_device(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense) {
   return set_target_impl(h, pts, n, stride, is_dense, true);
 }
-static ndt_status set_source_impl(ndt_handle h, const void* pts, size_t n, size_t stride, bool on_device) {
+ndt_status ndt_set_input_target_device_ref(ndt_handle h, const void* d_pts, size_t n, int is_dense) {
+  return set_target_impl(h, d_pts, n, sizeof(float4), is_dense, true, true);
+}
+static ndt_status set_source_impl(ndt_handle h, const void* pts, size_t n, size_t stride, bool on_device, bool by_ref = false) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   std::shared_ptr<DeviceCloud> c;
-  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c);
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device, c, by_ref);
   if (s) return s;
   s = order_cloud(h, c.get(), nullptr, 0);
   if (s) return s;
@@ -810,6 +796,9 @@ ndt_status ndt_set_input_source(ndt_handle h, const void* pts, size_t n, size_t 
 }
 ndt_status ndt_set_input_source_device(ndt_handle h, const void* pts, size_t n, size_t stride) {
   return set_source_impl(h, pts, n, stride, true);
+}
+ndt_status ndt_set_input_source_device_ref(ndt_handle h, const void* d_pts, size_t n) {
+  return set_source_impl(h, d_pts, n, sizeof(float4), true, true);
 }
 
 ndt_status ndt_set_voxel_index(ndt_handle h, int mode) {

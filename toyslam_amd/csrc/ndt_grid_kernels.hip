@@ -97,6 +97,50 @@ __global__ __launch_bounds__(kBlock) void k_repack_bbox(const unsigned char* __r
   }
 }
 
+// The same for clouds that already are dense 16-byte records (pcl::PointXYZ in HBM): 16-byte loads, and -- COPY false --
+// no copy at all: a cloud handed over by reference only needs its bounding boxes (ndt_set_input_*_device_ref).
+template <bool COPY>
+__global__ __launch_bounds__(kBlock) void k_bbox16(const float4* __restrict__ src, size_t n, float4* __restrict__ dst,
+                                                  float* __restrict__ block_minmax) {
+  float mn[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+  float mx[6] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
+  for (size_t i0 = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i0 < n; i0 += 8 * stride) {  // eight loads in flight
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) p[u] = (i0 + u * stride < n) ? src[i0 + u * stride] : make_float4(NAN, NAN, NAN, 1.0f);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (i0 + u * stride >= n) continue;
+      const float x = p[u].x, y = p[u].y, z = p[u].z;
+      if (COPY) dst[i0 + u * stride] = make_float4(x, y, z, 1.0f);
+      mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);  // fminf / fmaxf drop NaN operands
+      mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+      mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+      if (finite3(x, y, z)) {
+        mn[3] = fminf(mn[3], x); mx[3] = fmaxf(mx[3], x);
+        mn[4] = fminf(mn[4], y); mx[4] = fmaxf(mx[4], y);
+        mn[5] = fminf(mn[5], z); mx[5] = fmaxf(mx[5], z);
+      }
+    }
+  }
+  __shared__ float s[kBlock / kWave][12];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+    const int base = (k < 3) ? 0 : 6, c = k % 3;
+    if (lane == 0) { s[wave][base + c] = a; s[wave][base + 3 + c] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const bool is_min = (threadIdx.x % 6) < 3;
+    float v = s[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v = is_min ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+    block_minmax[blockIdx.x * 12 + threadIdx.x] = v;
+  }
+}
+
 // linear voxel index of a target point while BUILDING the grid:
 // floor(x * inv_leaf) - float(min_b), _impl.hpp:218-223 (f32, trap 2)
 __device__ __forceinline__ int build_cell(const GridGeom& g, float x, float y, float z) {
@@ -753,21 +797,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
 // execute at the memory side on gfx950, ~23 G/s (tools/probes/atomic_probe.cpp) -- and the per-voxel pass then gathers
 // its points at random from the whole cloud (64-B sectors for 16-B points).  Here the voxel index space is dealt out to
 // K buckets of C cells each (short runs of consecutive cells, round-robin: k1_bucket below) and everything per-voxel is
-// staged through LDS.  Round 3: the whole chain is ORDER-PRESERVING -- a bucket holds its points in ascending point index,
-// and so does every cell after k1_finalize's LDS sort -- because the reference adds a voxel's points in index order
-// (_impl.hpp:233-244) and a sort by index per cell was a third of the old k1_finalize:
-//   k1_hist     per block of points: LDS histogram over the buckets -> the block's row of the count matrix [blocks][K]
-//               (plain stores; round 2 claimed a run per (block, bucket) with a returning global atomic: 250 k of them at
-//               1 M points = 11 us of memory-side atomics); also clears the look-up table
-//   k1_scatter  the same blocks: column sums of the count matrix (rows before mine = my base inside every bucket, all rows
-//               = the bucket sizes), then a STABLE split of the block's points over the buckets: ranks inside a 64-point
-//               chunk from ballots (wave_rank), per-wave running counts in LDS -- bucket k then holds the points of block 0,
-//               block 1, ... each in index order
-//   k1_finalize one block per bucket: the same stable ranking by CELL into LDS (no atomics, no sort), then one thread per
-//               cell: sums in ascending point order (bit-identical to the reference's sequential pass), second pass of
-//               applyFilter -> record, centroid, look-up table slot, sorted_idx
-//   k1_count / k1_leaves  on demand: occupied / candidate counts, leaf arrays
-// Points are read three times (k1_hist, k1_scatter: the second read comes from the Infinity Cache) and written once.
+// staged through LDS:
+//   k1_hist     per block of points: LDS histogram over the buckets, ONE returning global atomic per (block, bucket)
+//               claims the block's run inside the bucket; the last block to finish scans the bucket totals
+//   k1_scatter  the same blocks move their points (x, y, z, point index) to their runs: bucket-contiguous copy
+//   k1_count    one block per bucket: LDS per-cell counters -> occupied / candidate cells of the bucket; the last
+//               block scans those totals (leaf ordinals: bucket by bucket, ascending local cell inside a bucket)
+//   k1_finalize one block per bucket: LDS counting sort of the bucket's points by cell, rank sort by point index inside
+//               every cell (one thread per point; any cell size), then one thread per cell: sums in ascending point
+//               order (bit-identical to the reference's sequential pass), second pass of applyFilter -> record,
+//               centroid, look-up table slot, leaf arrays, sorted_idx
+// Points are read three times and written once, contiguously; no per-point global atomic.
 // ---------------------------------------------------------------------------
 // Cell <-> (bucket, local cell).  Buckets are NOT ranges of the linear cell index: a clustered scene (a ground plane) would
 // fill a few of those with many times the mean and leave the rest empty.  Runs of 2^rb consecutive cells (neighbours in x,
@@ -784,9 +824,7 @@ __device__ __forceinline__ int k1_cell(int bucket, int local, int map) {
   return ((((local >> rb) << kb) | bucket) << rb) | (local & ((1 << rb) - 1));
 }
 
-constexpr int kK1Threads = 512;              // k1_hist / k1_scatter / k1_finalize
-constexpr int kK1Waves = kK1Threads / kWave;  // 8
-constexpr int kK1Round = 8 * kK1Threads;     // points one block ranks per round in k1_scatter (eight 64-point chunks per wave)
+constexpr int kK1Threads = 512;   // k1_hist / k1_scatter
 
 __device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int dense) {
   int c = -1;
@@ -828,41 +866,13 @@ __device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ sr
   if (tid == 0) dst[n] = total;
 }
 
-// Stable rank of a lane's key among the lanes of its wave that hold the same key, plus the wave's running count of that
-// key: the lanes with equal keys are found with one ballot per key bit; the lowest of them (the leader) bumps the wave's
-// counter row in LDS by their number and hands the old value to the others.  Returns old count + number of equal-key
-// lanes below this one -- the position of the lane's element among ALL elements of that key the wave has ranked so far,
-// in the order the wave met them.  `row` is this wave's private row of counters (u16, one per key).  Invalid lanes (key
-// ignored) take part in the ballots only.
-__device__ __forceinline__ unsigned wave_rank(int key, bool valid, unsigned short* row, int bits) {
-  unsigned long long peers = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < 13; b++) {
-    if (b < bits) {
-      const bool bit = ((key >> b) & 1) != 0;
-      const unsigned long long m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-  }
-  const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(peers), 0u));
-  unsigned old = 0;
-  if (valid && below == 0) {
-    old = row[key];
-    row[key] = static_cast<unsigned short>(old + static_cast<unsigned>(__popcll(peers)));
-  }
-  const int leader = valid ? (__ffsll(static_cast<long long>(peers)) - 1) : 0;
-  old = __shfl(old, leader, kWave);
-  return old + below;
-}
-
-// rows = blocks of points, columns = buckets: the block's row of bucket counts (plain stores); the look-up table is cleared
-// on the side (nothing reads it before k1_finalize)
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                      int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells) {
+                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
+                                                      int* __restrict__ lut, long long lut_cells) {
   extern __shared__ unsigned k1_lds[];
   unsigned* h = k1_lds;
   for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
-  {  // the padded look-up table starts out empty: every block clears its slice
+  {  // the padded look-up table starts out empty: every block clears its slice (nothing reads the table before k1_finalize)
     const long long n4 = lut_cells / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
     const long long lo4 = static_cast<long long>(blockIdx.x) * per, hi4 = min(n4, lo4 + per);
     int4* l4 = reinterpret_cast<int4*>(lut);
@@ -886,131 +896,47 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cntmat[static_cast<size_t>(blockIdx.x) * K + k] = h[k];
-}
-
-// The count matrix, column by column: cntmat[b][k] <- points of bucket k in the blocks BEFORE b (exclusive prefix down the
-// rows, in place), total[k] <- the bucket's size.  One pass over the matrix instead of every block of k1_scatter summing
-// all the rows above its own (at 10 M points: 489 x 4096 entries, read 489 times).  A block takes 16 columns; its 512
-// threads are 32 row groups x 16 columns, a thread keeps its rows (at most kColRows) in registers between the two sweeps.
-constexpr int kColCols = 16, kColGroups = kK1Threads / kColCols, kColRows = 16;  // B <= kColGroups * kColRows = 512 rows
-__global__ __launch_bounds__(kK1Threads) void k1_colscan(unsigned* __restrict__ cntmat, int B, int K, unsigned* __restrict__ total) {
-  __shared__ unsigned s_part[kColGroups][kColCols + 1];
-  const int c = threadIdx.x % kColCols, rg = threadIdx.x / kColCols;
-  const int col = blockIdx.x * kColCols + c;
-  const int R = (B + kColGroups - 1) / kColGroups;  // rows per group, <= kColRows
-  const int r0 = rg * R;
-  unsigned v[kColRows];
-  unsigned sum = 0;
-#pragma unroll
-  for (int i = 0; i < kColRows; i++) {
-    const int r = r0 + i;
-    v[i] = (i < R && r < B && col < K) ? cntmat[static_cast<size_t>(r) * K + col] : 0u;
-  }
-#pragma unroll
-  for (int i = 0; i < kColRows; i++) sum += v[i];
-  s_part[rg][c] = sum;
-  __syncthreads();
-  unsigned base = 0, all = 0;
-  for (int g = 0; g < kColGroups; g++) {
-    const unsigned t = s_part[g][c];
-    if (g < rg) base += t;
-    all += t;
-  }
-#pragma unroll
-  for (int i = 0; i < kColRows; i++) {
-    const int r = r0 + i;
-    if (i < R && r < B && col < K) cntmat[static_cast<size_t>(r) * K + col] = base;
-    base += v[i];
-  }
-  if (rg == 0 && col < K) total[col] = all;
-}
-
-// phase stamps (development aid, NDT_K1_STAMPS=1): thread 0 of every block leaves the shader clock at each phase boundary
-__device__ __forceinline__ void k1_stamp(unsigned long long* st, int n_phases, int phase) {
-  if (st && threadIdx.x == 0) st[static_cast<size_t>(blockIdx.x) * n_phases + phase] = stamp();
-}
-constexpr int kK1StampPhases = 12;
-
-// LDS of k1_scatter: cursor[K + 1] u32, part_lt[K] u32, part_all[K] u32, tab[kK1Waves][K] u16
-__global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                         int ppb, const unsigned* __restrict__ cntmat, const unsigned* __restrict__ total,
-                                                         unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
-                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st) {
-  extern __shared__ unsigned k1_lds[];
-  __shared__ unsigned s_scan[kK1Waves];
-  unsigned* cursor = k1_lds;            // [K + 1]
-  unsigned* part_lt = cursor + K + 1;   // [K]: points of this bucket in the blocks before this one
-  unsigned* part_all = part_lt + K;     // [K]: bucket sizes; later the current round's counts
-  unsigned short* tab = reinterpret_cast<unsigned short*>(part_all + K);  // [kK1Waves][K]
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int b = blockIdx.x;
-  const int kbits = map >> 8;
-  k1_stamp(st, kK1StampPhases, 0);
   for (int k = threadIdx.x; k < K; k += kK1Threads) {
-    part_lt[k] = cntmat[static_cast<size_t>(b) * K + k];
-    part_all[k] = total[k];
+    const unsigned v = h[k];
+    // the block's run inside bucket k starts where the bucket's counter stood (arrival order of the blocks: any)
+    blockbase[static_cast<size_t>(blockIdx.x) * K + k] = v ? __hip_atomic_fetch_add(bucket_count + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
+  // (no ticket, no last-block scan of the bucket counters: every block of k1_scatter scans the K counters itself --
+  // 245 returning atomics on one ticket word queued ~4 us behind each other at the end of this kernel)
+}
+
+__global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
+                                                         int ppb, const unsigned* __restrict__ bucket_count, unsigned* __restrict__ bucket_base,
+                                                         const unsigned* __restrict__ blockbase, float4* __restrict__ bpts,
+                                                         unsigned* __restrict__ counts) {
+  extern __shared__ unsigned k1_lds[];  // K + 1 words
+  __shared__ unsigned s_scan[kK1Threads / kWave];
+  unsigned* cursor = k1_lds;
+  // bucket bases = exclusive scan of the K bucket counters, by every block for itself (1 us); block 0 keeps them for
+  // k1_finalize and the leaf pass
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] = bucket_count[k];
   __syncthreads();
-  k1_stamp(st, kK1StampPhases, 1);
-  // bucket bases = exclusive scan of the bucket sizes, by every block for itself; block 0 keeps them for k1_finalize
-  block_scan_array(part_all, cursor, K, kK1Threads, s_scan, false);
+  block_scan_array(cursor, cursor, K, kK1Threads, s_scan, false);
   __syncthreads();
-  if (b == 0) {
+  if (blockIdx.x == 0) {
     for (int k = threadIdx.x; k <= K; k += kK1Threads) bucket_base[k] = cursor[k];
     if (threadIdx.x == 0) counts[0] = cursor[K];  // points binned
   }
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += part_lt[k];
-  for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += blockbase[static_cast<size_t>(blockIdx.x) * K + k];
   __syncthreads();
-  k1_stamp(st, kK1StampPhases, 2);
-  // ---- stable split: rounds of 4096 points; wave w ranks the eight 64-point chunks [w * 512, (w + 1) * 512) of the round
-  const int lo = b * ppb, hi = min(n, lo + ppb);
-  unsigned short* row = tab + wave * K;
-  for (int r0 = lo; r0 < hi; r0 += kK1Round) {
+  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
+  for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {
     float4 p[8];
-    int key[8];
-    unsigned rk[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
+      const int i = base + u * kK1Threads;
       p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
+      const int i = base + u * kK1Threads;
       const int c = (i < hi) ? key_of(g, p[u], dense) : -1;
-      key[u] = (c >= 0) ? k1_bucket(c, map) : -1;
-      rk[u] = wave_rank(key[u], key[u] >= 0, row, kbits);
-    }
-    __syncthreads();
-    if (r0 == lo) k1_stamp(st, kK1StampPhases, 3);
-    // per bucket: the waves' counts -> exclusive prefix over the waves (in place), the round's total -> cursor afterwards
-    for (int k = threadIdx.x; k < K; k += kK1Threads) {
-      unsigned s = 0;
-#pragma unroll
-      for (int w = 0; w < kK1Waves; w++) {
-        const unsigned t = tab[w * K + k];
-        tab[w * K + k] = static_cast<unsigned short>(s);
-        s += t;
-      }
-      part_all[k] = s;
-    }
-    __syncthreads();
-    if (r0 == lo) k1_stamp(st, kK1StampPhases, 4);
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (key[u] >= 0) {
-        const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
-        bpts[cursor[key[u]] + row[key[u]] + rk[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
-      }
-    }
-    __syncthreads();
-    if (r0 == lo) k1_stamp(st, kK1StampPhases, 5);
-    if (r0 + kK1Round < hi) {  // (uniform) another round: advance the cursors, clear the counters
-      for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += part_all[k];
-      for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-      __syncthreads();
+      if (c >= 0) bpts[atomicAdd(&cursor[k1_bucket(c, map)], 1u)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
     }
   }
 }
@@ -1018,636 +944,389 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
 // per-bucket cell histogram in LDS (cnt[C], zeroed here)
 __device__ __forceinline__ void k1_cell_histogram(const float4* __restrict__ bpts, unsigned bb, unsigned be, const GridGeom& g,
                                                   int map, int C, unsigned* cnt) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) cnt[c] = 0;
+  for (int c = threadIdx.x; c < C; c += kBlock) cnt[c] = 0;
   __syncthreads();
-  for (unsigned j = bb + threadIdx.x; j < be; j += blockDim.x) {
+  for (unsigned j = bb + threadIdx.x; j < be; j += kBlock) {
     const float4 p = bpts[j];
     atomicAdd(&cnt[k1_local(build_cell(g, p.x, p.y, p.z), map)], 1u);
   }
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------
-// k1_finalize: one block per bucket.  The bucket holds its points in ascending point index (k1_scatter is order-preserving);
-// a STABLE sort by local cell -- LSD radix sort, digits of dbits <= 11 bits, ranks from ballots (wave_rank) -- therefore
-// leaves every cell's points in ascending point index, the order the reference adds them in, with no comparison sort at all.
-// Cells are the runs of equal keys of the sorted sequence: nothing here is sized by the number of cells a bucket may hold.
-//   fast path  the bucket fits the block's LDS (PT x 512 points): points stay in registers while they are ranked, one or two
-//              digits, one scatter of x / y / z / key into LDS;
-//   slow path  (a clustered cloud: more points than that) the same radix sort streamed in rounds through global scratch
-//              (key, position-in-bucket pairs; sweep 1 counts a digit, sweep 2 places), the sums gather through the sorted
-//              positions.  Runs longer than a round are summed by a lane team straight from global memory.
-// Per run: sums in ascending point order (a team of 16 lanes, a lane per accumulator, for runs of more than 32 points),
-// finish_voxel -> record, side sector, look-up table slot; the run itself (cell, start, count) goes to leaf_slots[bb + run
-// ordinal] for the leaf pass (k1_leaves, on demand).
-// ---------------------------------------------------------------------------
-constexpr int kTeamCell = 32, kTeamLanes = 16;
-constexpr size_t kK1MaxDynamicLds = 148 * 1024;  // of the CU's 160 KB; k1_finalize also holds ~10 KB of static team sums
-constexpr int kMaxTeams = 96;   // long runs one round can hold in its team list (the rest are summed by their own thread)
-
-struct K1Team {
-  double s64[9];
-  float s32[3];
-  unsigned beg, cnt;
-};
-
-// sums of the points at sorted positions [beg, beg + cnt) by the 16-lane team `tl` belongs to: lane 0-2 the mean sums, 3-8
-// the products xx xy xz yy yz zz (seeded Identity, voxel_grid_covariance_omp.h:107), 9-11 the f32 centroid sums
-template <class Pts>
-__device__ __forceinline__ void team_sum(const Pts& P, unsigned beg, unsigned cnt, int tl, K1Team* out) {
-#pragma clang fp contract(off)
-  const int ia = (tl < 3) ? tl : (tl < 6) ? 0 : (tl < 8) ? 1 : (tl == 8) ? 2 : (tl < 12) ? tl - 9 : 0;
-  const int ib = (tl == 3) ? 0 : (tl == 4 || tl == 6) ? 1 : (tl == 5 || tl == 7 || tl == 8) ? 2 : -1;
-  double acc = (tl == 3 || tl == 6 || tl == 8) ? 1.0 : 0.0;
-  float acc32 = 0.f;
-  unsigned i = 0;
-  for (; i + 4 <= cnt; i += 4) {
-    float a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      a[u] = P.coord(beg + i + u, ia);
-      b[u] = (ib < 0) ? 1.0f : P.coord(beg + i + u, ib);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const double prod = static_cast<double>(a[u]) * static_cast<double>(b[u]);  // (x * 1.0 is exact)
-      acc += prod;
-      acc32 += a[u];
-    }
-  }
-  for (; i < cnt; i++) {
-    const float a = P.coord(beg + i, ia), b = (ib < 0) ? 1.0f : P.coord(beg + i, ib);
-    const double prod = static_cast<double>(a) * static_cast<double>(b);
-    acc += prod;
-    acc32 += a;
-  }
-  if (tl < 9) out->s64[tl] = acc;
-  else if (tl < 12) out->s32[tl - 9] = acc32;
-}
-
-// sorted points in LDS (fast path) ...
-struct K1LdsPts {
-  const float* x;
-  const float* y;
-  const float* z;
-  __device__ __forceinline__ float coord(unsigned pos, int a) const { return (a == 0 ? x : a == 1 ? y : z)[pos]; }
-  __device__ __forceinline__ void get(unsigned pos, float& px, float& py, float& pz) const { px = x[pos]; py = y[pos]; pz = z[pos]; }
-};
-// ... or reached through the sorted positions in global memory (slow path): pos -> position in the bucket -> point
-struct K1GlobalPts {
-  const float4* b;      // the bucket's points
-  const unsigned* jpos;  // sorted position -> position in the bucket (offset by `off`)
-  unsigned off;
-  __device__ __forceinline__ float coord(unsigned pos, int a) const {
-    const float4 p = b[jpos[off + pos]];
-    return a == 0 ? p.x : a == 1 ? p.y : p.z;
-  }
-  __device__ __forceinline__ void get(unsigned pos, float& px, float& py, float& pz) const {
-    const float4 p = b[jpos[off + pos]];
-    px = p.x; py = p.y; pz = p.z;
-  }
-};
-
-// The runs [runstart[r], runstart[r + 1]) of one round, r < n_runs: long ones by lane teams, then a thread per run.
-// key(r) = local cell of run r; slot0 = position of the round's first point in the bucket order (for the record slot and
-// the leaf entry); run0 = ordinal of the round's first run inside the bucket.  Returns this thread's count of valid voxels.
-template <class Pts, class KeyFn>
-__device__ __forceinline__ unsigned k1_process_runs(const Pts& P, const KeyFn& key, const unsigned short* runstart, int n_runs, unsigned bb,
-                                                    unsigned slot0, unsigned run0, int bucket, int map, int min_pts, double eig_ratio,
-                                                    const GridGeom& g, VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids,
-                                                    int* __restrict__ lut, uint4* __restrict__ leaf_slots, K1Team* s_team,
-                                                    unsigned short* s_team_of /* [runs]: team slot + 1, or 0 */, int* s_nteam,
-                                                    unsigned long long* st = nullptr) {
-  if (threadIdx.x == 0) *s_nteam = 0;
-  __syncthreads();
-  for (int r = threadIdx.x; r < n_runs; r += kK1Threads) {
-    const int n_c = static_cast<int>(runstart[r + 1]) - static_cast<int>(runstart[r]);
-    unsigned short t = 0;
-    if (n_c > kTeamCell && n_c >= min_pts) {
-      const int slot = atomicAdd(s_nteam, 1);
-      if (slot < kMaxTeams) {
-        s_team[slot].beg = runstart[r];
-        s_team[slot].cnt = static_cast<unsigned>(n_c);
-        t = static_cast<unsigned short>(slot + 1);
-      }
-    }
-    s_team_of[r] = t;
-  }
-  __syncthreads();
-  {
-    const int n_team = min(*s_nteam, kMaxTeams);
-    const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
-    for (int s = team; s < n_team; s += kK1Threads / kTeamLanes) team_sum(P, s_team[s].beg, s_team[s].cnt, tl, &s_team[s]);
-  }
-  __syncthreads();
-  k1_stamp(st, kK1StampPhases, 6);
-  const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
-  unsigned n_ok = 0;
-  for (int r = threadIdx.x; r < n_runs; r += kK1Threads) {
-    const unsigned beg = runstart[r];
-    const int n_c = static_cast<int>(runstart[r + 1]) - static_cast<int>(beg);
-    const int local = key(r, beg);
-    const int cell = k1_cell(bucket, local, map);
-    leaf_slots[bb + run0 + r] = make_uint4(static_cast<unsigned>(cell), bb + slot0 + beg, static_cast<unsigned>(n_c), 0u);
-    if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
-    // record slot: candidates' segments start at least min_pts apart, so start / min_pts is unique per candidate --
-    // no scan over the buckets is needed to number the records
-    const int rec = static_cast<int>((bb + slot0 + beg) / static_cast<unsigned>(min_pts));
-    VoxelSums S;
-    const unsigned short t = s_team_of[r];
-    if (t) {
-      const K1Team& T = s_team[t - 1];
-      S.sx = T.s64[0]; S.sy = T.s64[1]; S.sz = T.s64[2];
-      S.cxx = T.s64[3]; S.cxy = T.s64[4]; S.cxz = T.s64[5];
-      S.cyy = T.s64[6]; S.cyz = T.s64[7]; S.czz = T.s64[8];
-      S.fx = T.s32[0]; S.fy = T.s32[1]; S.fz = T.s32[2];
-    } else {
-      int i = 0;
-      for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
-        float x[4], y[4], z[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) P.get(beg + i + u, x[u], y[u], z[u]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) S.add(x[u], y[u], z[u]);
-      }
-      for (; i < n_c; i++) {
-        float x, y, z;
-        P.get(beg + i, x, y, z);
-        S.add(x, y, z);
-      }
-    }
-    n_ok += finish_voxel(S, n_c, 0, rec, cell, min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
-  }
-  return n_ok;
-}
-
-// exclusive scan of the D digit counts that the eight wave rows of `tab` hold: tab[w][d] <- count of digit d in the waves
-// before w, dstart[d] <- positions before digit d (dstart[D] = total).  `s_scan`: kK1Waves words.
-__device__ __forceinline__ void k1_digit_offsets(unsigned short* tab, unsigned* dstart, int D, unsigned* s_scan) {
-  const int per = (D + kK1Threads - 1) / kK1Threads;  // D <= 2048: at most four digits per thread, consecutive
-  const int lo = threadIdx.x * per, hi = min(D, lo + per);
-  unsigned cnt[4] = {0, 0, 0, 0};
-  unsigned sum = 0;
-  for (int d = lo; d < hi; d++) {
-    unsigned s = 0;
-#pragma unroll
-    for (int w = 0; w < kK1Waves; w++) {
-      const unsigned t = tab[w * D + d];
-      tab[w * D + d] = static_cast<unsigned short>(s);
-      s += t;
-    }
-    cnt[d - lo] = s;
-    sum += s;
-  }
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  unsigned inc = sum;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned a = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += a;
-  }
-  if (lane == kWave - 1) s_scan[wave] = inc;
-  __syncthreads();
-  unsigned base = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < kK1Waves; w++) {
-    if (w < wave) base += s_scan[w];
-    total += s_scan[w];
-  }
-  unsigned run = base + inc - sum;
-  for (int d = lo; d < hi; d++) {
-    dstart[d] = run;
-    run += cnt[d - lo];
-  }
-  if (threadIdx.x == 0) dstart[D] = total;
-  __syncthreads();
-}
-
-// heads of the runs of equal keys among the `n` sorted positions of one round -> runstart[0 .. n_runs], returns n_runs
-// (uniform).  keyat(pos) reads the key at a sorted position.  PTR = positions per thread.
-template <int PTR, class KeyAt>
-__device__ __forceinline__ int k1_find_runs(const KeyAt& keyat, unsigned n, unsigned short* runstart, unsigned* s_scan, int* s_total) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  // wave w looks at the PTR consecutive chunks [w * PTR, (w + 1) * PTR) of 64 positions
-  unsigned long long heads[PTR];
-  unsigned mine = 0;
-#pragma unroll
-  for (int u = 0; u < PTR; u++) {
-    const unsigned pos = static_cast<unsigned>((wave * PTR + u) * kWave + lane);
-    const bool h = pos < n && (pos == 0 || keyat(pos) != keyat(pos - 1));
-    heads[u] = __ballot(h);
-    mine += static_cast<unsigned>(__popcll(heads[u]));  // (uniform per wave)
-  }
-  if (lane == 0) s_scan[wave] = mine;
-  __syncthreads();
-  unsigned base = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < kK1Waves; w++) {
-    if (w < wave) base += s_scan[w];
-    total += s_scan[w];
-  }
-#pragma unroll
-  for (int u = 0; u < PTR; u++) {
-    const unsigned pos = static_cast<unsigned>((wave * PTR + u) * kWave + lane);
-    if ((heads[u] >> lane) & 1ull) {
-      const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(heads[u] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(heads[u]), 0u));
-      runstart[base + below] = static_cast<unsigned short>(pos);
-    }
-    base += static_cast<unsigned>(__popcll(heads[u]));
-  }
-  if (threadIdx.x == 0) {
-    runstart[total] = static_cast<unsigned short>(n);
-    *s_total = static_cast<int>(total);
-  }
-  __syncthreads();
-  return *s_total;
-}
-
-// PT: points per thread the fast path holds (capacity PT x 512); TWO: the local cell index needs two digits.
-// LDS (dynamic): tab u16 [8][D] | dstart u32 [D + 2] | ox oy oz f32 [cap] (at least 2 D words: the slow path's histograms)
-//                | skey u32 [cap] | runstart u16 [cap + 2] | team_of u16 [cap], or (TWO) item u32 [cap] (team_of on top) + posmap u16 [cap]
-template <int PT, bool TWO>
-__global__ __launch_bounds__(kK1Threads) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int cbits, int dbits,
-                                                          int min_pts, double eig_ratio, const unsigned* __restrict__ bucket_base,
-                                                          int* __restrict__ sorted_idx, VoxelRec* __restrict__ recs,
-                                                          VoxelSide* __restrict__ centroids, int* __restrict__ lut,
-                                                          unsigned* __restrict__ bucket_stat /* [K][4]: valid, occupied, candidate voxels, 0 */,
-                                                          uint4* __restrict__ leaf_slots, unsigned* __restrict__ scratch /* 4 words per point */,
-                                                          unsigned n_total, unsigned long long* __restrict__ st) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char k1_smem[];
-  __shared__ unsigned s_scan[kK1Waves];
-  __shared__ int s_total, s_nteam;
-  __shared__ unsigned s_u[4];
-  __shared__ K1Team s_team[kMaxTeams];
-  constexpr int cap = PT * kK1Threads;
-  const int D = 1 << dbits;
-  unsigned short* tab = reinterpret_cast<unsigned short*>(k1_smem);
-  unsigned* dstart = reinterpret_cast<unsigned*>(tab + kK1Waves * D);
-  float* ox = reinterpret_cast<float*>(dstart + D + 2);
-  float* oy = ox + cap;
-  float* oz = oy + cap;
-  unsigned* skey = reinterpret_cast<unsigned*>(ox + max(3 * cap, 2 * D));
-  unsigned short* runstart = reinterpret_cast<unsigned short*>(skey + cap);
-  unsigned* item = reinterpret_cast<unsigned*>(runstart + cap + 2);        // TWO only: (high key bits, position) pairs ...
-  unsigned short* posmap = reinterpret_cast<unsigned short*>(item + cap);  // ... and where each position ended up
-  unsigned short* team_of = reinterpret_cast<unsigned short*>(item);       // (the pairs are dead by then)
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+__global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, unsigned min_pts,
+                                                   const unsigned* __restrict__ bucket_base, unsigned* __restrict__ tot,
+                                                   unsigned* __restrict__ ticket, unsigned* __restrict__ occ_base,
+                                                   unsigned* __restrict__ cand_base, unsigned* __restrict__ counts) {
+  extern __shared__ unsigned k1_lds[];
+  __shared__ U3 s_u3[kBlock / kWave];
+  __shared__ unsigned s_scan[kBlock / kWave];
+  __shared__ int s_last;
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  const unsigned nb = be - bb;
-  if (nb == 0) {  // empty bucket (uniform)
-    if (threadIdx.x < 4) bucket_stat[4 * k + threadIdx.x] = 0u;
-    return;
-  }
-  const float4* bp = bpts + bb;
-  unsigned n_ok = 0, n_occ = 0, n_cand = 0;
-  k1_stamp(st, kK1StampPhases, 0);
-  const unsigned dmask = static_cast<unsigned>(D - 1);
-
-  if (nb <= static_cast<unsigned>(cap)) {
-    // =============================== fast path: everything in LDS ===============================
-    for (int i = threadIdx.x; i < kK1Waves * D / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-    // wave w owns the consecutive chunks [w * per_wave, (w + 1) * per_wave) of 64 points: contiguous, ascending ranges
-    const int per_wave = static_cast<int>(((nb + kWave - 1) / kWave + kK1Waves - 1) / kK1Waves);  // <= PT
-    float4 p[PT];
-    unsigned key[PT], rk[PT];
-#pragma unroll
-    for (int u = 0; u < PT; u++) {
-      const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-      p[u] = (u < per_wave && j < nb) ? bp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    k1_stamp(st, kK1StampPhases, 1);
-    unsigned short* row = tab + wave * D;
-#pragma unroll
-    for (int u = 0; u < PT; u++) {
-      const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-      const bool valid = u < per_wave && j < nb;
-      key[u] = valid ? static_cast<unsigned>(k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map)) : 0u;
-      if (u < per_wave) rk[u] = wave_rank(static_cast<int>(key[u] & dmask), valid, row, dbits);  // (uniform condition)
-    }
-    __syncthreads();
-    k1_stamp(st, kK1StampPhases, 2);
-    k1_digit_offsets(tab, dstart, D, s_scan);
-    k1_stamp(st, kK1StampPhases, 3);
-    if (!TWO) {
-#pragma unroll
-      for (int u = 0; u < PT; u++) {
-        const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-        if (u < per_wave && j < nb) {
-          const unsigned d = key[u] & dmask;
-          const unsigned pos = dstart[d] + row[d] + rk[u];
-          ox[pos] = p[u].x;
-          oy[pos] = p[u].y;
-          oz[pos] = p[u].z;
-          skey[pos] = key[u];
-          sorted_idx[bb + pos] = __float_as_int(p[u].w);
-        }
-      }
-      __syncthreads();
-    } else {
-      // second digit: the (high key bits, position in bucket) pairs in first-digit order, ranked again in that order
-#pragma unroll
-      for (int u = 0; u < PT; u++) {
-        const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-        if (u < per_wave && j < nb) {
-          const unsigned d = key[u] & dmask;
-          item[dstart[d] + row[d] + rk[u]] = ((key[u] >> dbits) << 13) | j;
-        }
-      }
-      __syncthreads();
-      for (int i = threadIdx.x; i < kK1Waves * D / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-      __syncthreads();
-      unsigned it[PT], rk2[PT];
-#pragma unroll
-      for (int u = 0; u < PT; u++) {
-        const unsigned s = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-        const bool valid = u < per_wave && s < nb;
-        it[u] = valid ? item[s] : 0u;
-        if (u < per_wave) rk2[u] = wave_rank(static_cast<int>((it[u] >> 13) & dmask), valid, row, dbits);
-      }
-      __syncthreads();
-      k1_digit_offsets(tab, dstart, D, s_scan);
-#pragma unroll
-      for (int u = 0; u < PT; u++) {
-        const unsigned s = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-        if (u < per_wave && s < nb) {
-          const unsigned d = (it[u] >> 13) & dmask;
-          posmap[it[u] & 8191u] = static_cast<unsigned short>(dstart[d] + row[d] + rk2[u]);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PT; u++) {
-        const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-        if (u < per_wave && j < nb) {
-          const unsigned pos = posmap[j];
-          ox[pos] = p[u].x;
-          oy[pos] = p[u].y;
-          oz[pos] = p[u].z;
-          skey[pos] = key[u];
-          sorted_idx[bb + pos] = __float_as_int(p[u].w);
-        }
-      }
-      __syncthreads();
-    }
-    k1_stamp(st, kK1StampPhases, 4);
-    const int n_runs = k1_find_runs<PT>([&](unsigned pos) { return skey[pos]; }, nb, runstart, s_scan, &s_total);
-    k1_stamp(st, kK1StampPhases, 5);
-    const K1LdsPts P{ox, oy, oz};
-    n_ok = k1_process_runs(P, [&](int, unsigned beg) { return static_cast<int>(skey[beg]); }, runstart, n_runs, bb, 0u, 0u, k, map, min_pts,
-                           eig_ratio, g, recs, centroids, lut, leaf_slots, s_team, team_of, &s_nteam, st);
-    k1_stamp(st, kK1StampPhases, 7);
-    for (int r = threadIdx.x; r < n_runs; r += kK1Threads) n_cand += (static_cast<int>(runstart[r + 1]) - static_cast<int>(runstart[r]) >= min_pts) ? 1u : 0u;
-    if (threadIdx.x == 0) n_occ = static_cast<unsigned>(n_runs);
-    __syncthreads();
-    k1_stamp(st, kK1StampPhases, 8);
-  } else {
-    // =============================== slow path: the radix sort streamed through global scratch ===============================
-    // scratch: (key, jpos) pairs, two copies (ping-pong), each n_total words: keyA | posA | keyB | posB
-    unsigned* keyA = scratch + bb;
-    unsigned* posA = scratch + n_total + bb;
-    unsigned* keyB = scratch + 2 * static_cast<size_t>(n_total) + bb;
-    unsigned* posB = scratch + 3 * static_cast<size_t>(n_total) + bb;
-    unsigned* dcur = dstart;  // [D + 1]
-    unsigned* hist = reinterpret_cast<unsigned*>(ox);  // [D] (the point arrays are free during the sort)
-    unsigned* tot = hist + D;                           // [D]
-    constexpr int R = 8;  // chunks per wave per round
-    constexpr unsigned round_n = R * kK1Threads;
-    const int n_dig = (cbits + dbits - 1) / dbits;
-    for (int dig = 0; dig < n_dig; dig++) {
-      const unsigned* ksrc = (dig == 0) ? nullptr : ((dig & 1) ? keyA : keyB);
-      const unsigned* psrc = (dig & 1) ? posA : posB;
-      unsigned* kdst = (dig & 1) ? keyB : keyA;
-      unsigned* pdst = (dig & 1) ? posB : posA;
-      const int shift = dig * dbits;
-      // sweep 1: histogram of this digit over the whole bucket
-      for (int d = threadIdx.x; d < D; d += kK1Threads) hist[d] = 0u;
-      __syncthreads();
-      for (unsigned j = threadIdx.x; j < nb; j += kK1Threads) {
-        unsigned key;
-        if (dig == 0) {
-          const float4 q = bp[j];
-          key = static_cast<unsigned>(k1_local(build_cell(g, q.x, q.y, q.z), map));
-        } else {
-          key = ksrc[j];
-        }
-        atomicAdd(&hist[(key >> shift) & dmask], 1u);
-      }
-      __syncthreads();
-      block_scan_array(hist, dcur, D, kK1Threads, s_scan, false);
-      __syncthreads();
-      // sweep 2: rounds of 4096 elements in order, ranked stably, placed behind what the earlier rounds placed
-      for (unsigned r0 = 0; r0 < nb; r0 += round_n) {
-        for (int i = threadIdx.x; i < kK1Waves * D / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-        __syncthreads();
-        unsigned key[R], pj[R], rk[R];
-        unsigned short* row = tab + wave * D;
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-          const unsigned j = r0 + static_cast<unsigned>((wave * R + u) * kWave + lane);
-          const bool valid = j < nb;
-          if (dig == 0) {
-            const float4 q = valid ? bp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            key[u] = valid ? static_cast<unsigned>(k1_local(build_cell(g, q.x, q.y, q.z), map)) : 0u;
-            pj[u] = j;
-          } else {
-            key[u] = valid ? ksrc[j] : 0u;
-            pj[u] = valid ? psrc[j] : 0u;
-          }
-          rk[u] = wave_rank(static_cast<int>((key[u] >> shift) & dmask), valid, row, dbits);
-        }
-        __syncthreads();
-        for (int d = threadIdx.x; d < D; d += kK1Threads) {
-          unsigned s = 0;
-#pragma unroll
-          for (int w = 0; w < kK1Waves; w++) {
-            const unsigned t = tab[w * D + d];
-            tab[w * D + d] = static_cast<unsigned short>(s);
-            s += t;
-          }
-          tot[d] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-          const unsigned j = r0 + static_cast<unsigned>((wave * R + u) * kWave + lane);
-          if (j < nb) {
-            const unsigned d = (key[u] >> shift) & dmask;
-            const unsigned pos = dcur[d] + row[d] + rk[u];
-            kdst[pos] = key[u];
-            pdst[pos] = pj[u];
-            if (dig == n_dig - 1) sorted_idx[bb + pos] = __float_as_int(bp[pj[u]].w);
-          }
-        }
-        __syncthreads();
-        for (int d = threadIdx.x; d < D; d += kK1Threads) dcur[d] += tot[d];
-        __syncthreads();
-      }
-      __threadfence_block();
-      __syncthreads();
-    }
-    const unsigned* skeyg = (n_dig & 1) ? keyA : keyB;  // where the last digit's pass left the sorted pairs
-    const unsigned* sposg = (n_dig & 1) ? posA : posB;
-    // ---- the runs, a window of at most `cap` sorted positions at a time, windows ending on a run boundary
-    unsigned s0 = 0, run0 = 0;
-    while (s0 < nb) {
-      const unsigned wn = min(static_cast<unsigned>(cap), nb - s0);
-      int n_runs = k1_find_runs<PT>([&](unsigned pos) { return skeyg[s0 + pos]; }, wn, runstart, s_scan, &s_total);
-      // (position 0 of a window is always a head: windows start on run boundaries)
-      unsigned used = wn;
-      if (s0 + wn < nb) {  // the window's last run may continue behind it: leave it to the next window ...
-        if (n_runs > 1) {
-          used = runstart[n_runs - 1];
-          n_runs -= 1;
-        } else {
-          // ... unless it IS the window: one run longer than a window -- a lane team sums it straight from global memory
-          if (threadIdx.x == 0) s_u[0] = nb;
-          __syncthreads();
-          const unsigned kk = skeyg[s0];
-          for (unsigned q = s0 + wn + threadIdx.x; q < nb; q += kK1Threads) {  // first position behind the run
-            if (skeyg[q] != kk) {
-              atomicMin(&s_u[0], q);
-              break;
-            }
-          }
-          __syncthreads();
-          const unsigned e = s_u[0];
-          const unsigned cnt = e - s0;
-          const K1GlobalPts PG{bp, sposg, s0};
-          if (threadIdx.x < kTeamLanes) team_sum(PG, 0u, cnt, static_cast<int>(threadIdx.x), &s_team[0]);
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            const int cell = k1_cell(k, static_cast<int>(kk), map);
-            leaf_slots[bb + run0] = make_uint4(static_cast<unsigned>(cell), bb + s0, cnt, 0u);
-            n_occ += 1;
-            if (static_cast<int>(cnt) >= min_pts) {
-              n_cand += 1;
-              const K1Team& T = s_team[0];
-              VoxelSums S;
-              S.sx = T.s64[0]; S.sy = T.s64[1]; S.sz = T.s64[2];
-              S.cxx = T.s64[3]; S.cxy = T.s64[4]; S.cxz = T.s64[5];
-              S.cyy = T.s64[6]; S.cyz = T.s64[7]; S.czz = T.s64[8];
-              S.fx = T.s32[0]; S.fy = T.s32[1]; S.fz = T.s32[2];
-              const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
-              n_ok += finish_voxel(S, static_cast<int>(cnt), 0, static_cast<int>((bb + s0) / static_cast<unsigned>(min_pts)), cell, min_pts,
-                                   eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
-            }
-          }
-          __syncthreads();
-          s0 = e;
-          run0 += 1;
-          continue;
-        }
-      }
-      if (threadIdx.x == 0) runstart[n_runs] = static_cast<unsigned short>(used);
-      __syncthreads();
-      const K1GlobalPts PG{bp, sposg, s0};
-      n_ok += k1_process_runs(PG, [&](int, unsigned beg) { return static_cast<int>(skeyg[s0 + beg]); }, runstart, n_runs, bb, s0, run0, k, map,
-                              min_pts, eig_ratio, g, recs, centroids, lut, leaf_slots, s_team, team_of, &s_nteam);
-      for (int r = threadIdx.x; r < n_runs; r += kK1Threads) n_cand += (static_cast<int>(runstart[r + 1]) - static_cast<int>(runstart[r]) >= min_pts) ? 1u : 0u;
-      if (threadIdx.x == 0) n_occ += static_cast<unsigned>(n_runs);
-      __syncthreads();
-      s0 += used;
-      run0 += static_cast<unsigned>(n_runs);
+  U3 t = {0, 0, 0};
+  if (be > bb) {  // uniform
+    k1_cell_histogram(bpts, bb, be, g, map, C, k1_lds);
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+      const unsigned v = k1_lds[c];
+      t.occ += (v > 0);
+      t.cand += (v >= min_pts);
     }
   }
-  {  // the bucket's voxel counts -> its own words (k1_leaves adds them up when somebody asks: same-address atomics from
-     // every block were a sixth of this kernel once)
-    unsigned v[3] = {n_ok, n_occ, n_cand};
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      unsigned x = v[q];
-#pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-      if (lane == 0) s_scan[wave] = x;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        unsigned t = 0;
-        for (int w = 0; w < kK1Waves; w++) t += s_scan[w];
-        bucket_stat[4 * k + q] = t;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) bucket_stat[4 * k + 3] = 0u;
-  }
-}
-
-// Leaf arrays of a bucket-form build (leaf_cell / leaf_start / leaf_count / leaf_rec: bucket by bucket, ascending local cell
-// inside a bucket) and the voxel counts, written only when somebody asks for them (ndt_grid_dump, getFitnessScore's index,
-// ndt_grid_size): k1_finalize left every bucket's runs in leaf_slots[bucket base + ordinal] and its counts in bucket_stat.
-//   k1_leaf_scan  one block: exclusive scan of the buckets' occupied-cell counts -> occ_base[K + 1]; totals -> counts[1..3]
-//   k1_leaves     one block per bucket: its runs -> the leaf arrays at occ_base[bucket]
-__global__ __launch_bounds__(kBlock) void k1_leaf_scan(const unsigned* __restrict__ bucket_stat, int K, unsigned* __restrict__ occ_base,
-                                                       unsigned* __restrict__ counts) {
-  __shared__ unsigned s_scan[kBlock / kWave];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int per = (K + kBlock - 1) / kBlock, lo = tid * per, hi = min(K, lo + per);
-  unsigned sum[3] = {0, 0, 0};
-  for (int i = lo; i < hi; i++)
-    for (int q = 0; q < 3; q++) sum[q] += bucket_stat[4 * i + q];
-  // occupied cells: exclusive scan
-  unsigned inc = sum[1];
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned a = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += a;
-  }
-  if (lane == kWave - 1) s_scan[wave] = inc;
-  __syncthreads();
-  unsigned base = 0, all = 0;
-  for (int w = 0; w < kBlock / kWave; w++) {
-    if (w < wave) base += s_scan[w];
-    all += s_scan[w];
-  }
-  unsigned run = base + inc - sum[1];
-  for (int i = lo; i < hi; i++) {
-    occ_base[i] = run;
-    run += bucket_stat[4 * i + 1];
-  }
-  if (tid == 0) {
-    occ_base[K] = all;
-    counts[1] = all;  // occupied voxels
+  U3 total;
+  block_exclusive_scan(t, total, s_u3);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(tot + 2 * k, total.occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tot + 2 * k + 1, total.cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  for (int q = 0; q < 3; q += 2) {  // [3] valid voxels (stat 0), [2] candidates (stat 2)
-    unsigned x = sum[q];
+  if (!s_last) return;
+  // exclusive scans of the per-bucket (occupied, candidate) counts, interleaved in tot[]
+  {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int per = (K + kBlock - 1) / kBlock, lo = tid * per, hi = min(K, lo + per);
+    for (int which = 0; which < 2; which++) {
+      unsigned* dst = which ? cand_base : occ_base;
+      unsigned sum = 0;
+      for (int i = lo; i < hi; i++) sum += __hip_atomic_load(tot + 2 * i + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned inc = sum;
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-    if (lane == 0) s_scan[wave] = x;
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned a = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += a;
+      }
+      __syncthreads();
+      if (lane == kWave - 1) s_scan[wave] = inc;
+      __syncthreads();
+      unsigned base = 0, all = 0;
+      for (int w = 0; w < kBlock / kWave; w++) {
+        if (w < wave) base += s_scan[w];
+        all += s_scan[w];
+      }
+      unsigned run = base + inc - sum;
+      for (int i = lo; i < hi; i++) {
+        dst[i] = run;
+        run += __hip_atomic_load(tot + 2 * i + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) {
+        dst[K] = all;
+        counts[1 + which] = all;  // [1] occupied voxels, [2] candidates (>= min_pts)
+      }
+    }
+    // [3] valid voxels: the words k1_finalize left behind the bucket bases
+    const unsigned* bucket_valid = bucket_base + K + 1;
+    unsigned v = 0;
+    for (int i = lo; i < hi; i++) v += bucket_valid[i];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    __syncthreads();
+    if (lane == 0) s_scan[wave] = v;
     __syncthreads();
     if (tid == 0) {
       unsigned t = 0;
       for (int w = 0; w < kBlock / kWave; w++) t += s_scan[w];
-      counts[q == 0 ? 3 : 2] = t;
+      counts[3] = t;
     }
-    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k1_leaves(const uint4* __restrict__ leaf_slots, GridGeom g, int min_pts,
-                                                    const unsigned* __restrict__ bucket_base, const unsigned* __restrict__ bucket_stat,
-                                                    const unsigned* __restrict__ occ_base, int* __restrict__ leaf_cell,
-                                                    unsigned* __restrict__ leaf_start, int* __restrict__ leaf_count, int* __restrict__ leaf_rec,
-                                                    const int* __restrict__ lut) {
+// exclusive scan of cnt[0..C) into cend[0..C) by the block (C a power of two >= 32)
+__device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cend, int C, U3* s_u3) {
+  const int per = C / kBlock > 0 ? C / kBlock : 1;
+  const int lo = threadIdx.x * per;
+  U3 t = {0, 0, 0};
+  for (int c = lo; c < lo + per && c < C; c++) t.pts += cnt[c];
+  U3 total;
+  U3 run = block_exclusive_scan(t, total, s_u3);
+  for (int c = lo; c < lo + per && c < C; c++) {
+    cend[c] = run.pts;
+    run.pts += cnt[c];
+  }
+  __syncthreads();
+}
+
+constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
+constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
+// Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
+// three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
+// _impl.hpp:233-244) -- one thread walking a 400-point voxel of a real scan issues 15 f64 instructions per point by
+// itself (~20 us per voxel), a lane per chain issues two.
+constexpr int kTeamCell = 32, kTeamLanes = 16;
+constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
+
+__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
+                                                      double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
+                                                      int* __restrict__ sorted_idx,
+                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                      unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
+                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
+                                                      unsigned* __restrict__ bucket_count) {
+  extern __shared__ unsigned k1_lds[];
+  __shared__ U3 s_u3[kBlock / kWave];
+  __shared__ int s_hi;
+  __shared__ int s_nteam;                     // team cells of the current pass ...
+  __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells ...
+  __shared__ double s_team64[kMaxTeamCells][9];  // ... and their sums (sx sy sz cxx cxy cxz cyy cyz czz)
+  __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
+  __shared__ float s_one;
   const int k = blockIdx.x;
-  const unsigned bb = bucket_base[k], n_runs = bucket_stat[4 * k + 1], ob = occ_base[k];
-  for (unsigned r = threadIdx.x; r < n_runs; r += kBlock) {
-    const uint4 e = leaf_slots[bb + r];
-    const unsigned o = ob + r;
-    const int cell = static_cast<int>(e.x);
-    leaf_cell[o] = cell;
-    leaf_start[o] = e.y;
-    leaf_count[o] = static_cast<int>(e.z);
-    int rec = -1;
-    if (e.z >= static_cast<unsigned>(min_pts)) {  // the voxel's record: wherever the compaction put it (read back from the table)
-      const int cz = cell / g.mul[2], cy = (cell - cz * g.mul[2]) / g.mul[1], cx = cell - cz * g.mul[2] - cy * g.mul[1];
-      const int t = lut[static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * g.pmul[1] +
-                        static_cast<long long>(cz + kLutBorder) * g.pmul[2]];
-      rec = (t >= 0) ? t : (t <= -2 ? -(t + 2) : -1);
+  // the handle's bucket counters are zero between builds: k1_hist counted into them, k1_scatter has read them, this block
+  // clears its own -- instead of a clearing launch in front of every build
+  if (threadIdx.x == 0) bucket_count[k] = 0u;
+  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
+  if (be == bb) {  // empty bucket (uniform)
+    if (threadIdx.x == 0) bucket_valid[k] = 0u;
+    return;
+  }
+  const unsigned nb = be - bb;
+  if (threadIdx.x == 0) s_one = 1.0f;
+  unsigned* cnt = k1_lds;          // [C] points per cell
+  unsigned* cstart = k1_lds + C;   // [C] start of the cell's segment inside the bucket (exclusive prefix of cnt)
+  unsigned* cur = k1_lds + 2 * C;  // [C] scatter cursors of the current pass
+  // per point of the current pass, in cell order (slot q) and then, in place, in (cell, point index) order:
+  unsigned* oidx = k1_lds + 3 * C;  // point index
+  unsigned* ocell = oidx + lds_cap;
+  float* ox = reinterpret_cast<float*>(ocell + lds_cap);
+  float* oy = ox + lds_cap;
+  float* oz = oy + lds_cap;
+  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
+  k1_scan_cells(cnt, cstart, C, s_u3);
+  const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned n_ok = 0;
+  // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
+  // bucket of a uniform cloud, several for a crowded one (clustered data: a ground plane fills "its" buckets with many
+  // times the mean).  A pass selects its points from the bucket, sorts them by (cell, point index) in LDS and finishes
+  // its cells.
+  for (int c_lo = 0; c_lo < C;) {
+    if (threadIdx.x == 0) {
+      int c = c_lo;
+      if (nb <= static_cast<unsigned>(lds_cap)) {
+        c = C;
+      } else {
+        // the last cell whose END stays within lds_cap points of c_lo's start: binary search in the prefix sums
+        // (cstart[c] = points before cell c; a linear walk by one thread cost 30 us per pass at C = 4096)
+        const unsigned limit = cstart[c_lo] + static_cast<unsigned>(lds_cap);
+        int lo = c_lo, hi = C;  // invariant: cells [c_lo, lo) fit; answer in [lo, hi]
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;  // candidate: cells [c_lo, mid) -- they end at cstart[mid] (mid < C) or nb
+          const unsigned end = (mid < C) ? cstart[mid] : nb;
+          if (end <= limit) lo = mid; else hi = mid - 1;
+        }
+        c = lo;
+        if (c == c_lo) c = c_lo + 1;  // a single cell with more points than a pass holds: the crowded-cell path below
+      }
+      s_hi = c;
     }
-    leaf_rec[o] = rec;
+    __syncthreads();
+    const int c_hi = s_hi;
+    const unsigned base = cstart[c_lo];
+    const unsigned n_pass = ((c_hi < C) ? cstart[c_hi] : nb) - base;
+    if (n_pass == 0) {  // (uniform)
+      c_lo = c_hi;
+      __syncthreads();
+      continue;
+    }
+    const bool giant = n_pass > static_cast<unsigned>(lds_cap);  // then c_hi == c_lo + 1
+    // arrays of this pass: LDS, or (one cell too crowded for LDS) the bucket's slices of the global scratch
+    unsigned* pidx = giant ? scratch + bb + base : oidx;
+    float* px = giant ? reinterpret_cast<float*>(scratch + n_total + bb + base) : ox;
+    float* py = giant ? reinterpret_cast<float*>(scratch + 2 * static_cast<size_t>(n_total) + bb + base) : oy;
+    float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
+    unsigned* pcell = giant ? nullptr : ocell;
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
+    __syncthreads();
+    for (unsigned j0 = 0; j0 < nb; j0 += kK1PerThread * kBlock) {  // select this pass's points, eight loads in flight
+      float4 p[kK1PerThread];
+#pragma unroll
+      for (int u = 0; u < kK1PerThread; u++) {
+        const unsigned j = j0 + threadIdx.x + u * kBlock;
+        p[u] = (j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kK1PerThread; u++) {
+        const unsigned j = j0 + threadIdx.x + u * kBlock;
+        if (j >= nb) continue;
+        const int c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map);
+        if (c < c_lo || c >= c_hi) continue;
+        const unsigned q = atomicAdd(&cur[c], 1u);
+        pidx[q] = static_cast<unsigned>(__float_as_int(p[u].w));
+        if (pcell) pcell[q] = static_cast<unsigned>(c);
+        px[q] = p[u].x;
+        py[q] = p[u].y;
+        pz[q] = p[u].z;
+      }
+    }
+    if (giant) __threadfence_block();
+    __syncthreads();
+    if (!giant) {
+      // rank sort inside every cell's segment, one thread per point: a point's rank is the number of points of its
+      // cell with a smaller point index (indices are unique).  The sorted copy goes back IN PLACE: every thread
+      // reads its points' data first, the block synchronises, then everybody writes.
+      unsigned dst[kK1PerThread], di[kK1PerThread];
+      float rx[kK1PerThread], ry[kK1PerThread], rz[kK1PerThread];
+#pragma unroll
+      for (int u = 0; u < kK1PerThread; u++) {
+        const unsigned q = threadIdx.x + u * kBlock;
+        dst[u] = ~0u;
+        if (q < n_pass) {
+          const unsigned c = ocell[q], beg = cstart[c] - base, end = beg + cnt[c], mine = oidx[q];
+          unsigned r = 0, t = beg;
+          for (; t + 4 <= end; t += 4) {  // four independent LDS reads per step (a dependent read per step costs its full latency)
+            const unsigned a0 = oidx[t], a1 = oidx[t + 1], a2 = oidx[t + 2], a3 = oidx[t + 3];
+            r += (a0 < mine ? 1u : 0u) + (a1 < mine ? 1u : 0u) + (a2 < mine ? 1u : 0u) + (a3 < mine ? 1u : 0u);
+          }
+          for (; t < end; t++) r += (oidx[t] < mine) ? 1u : 0u;
+          dst[u] = beg + r;
+          di[u] = mine;
+          rx[u] = ox[q];
+          ry[u] = oy[q];
+          rz[u] = oz[q];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kK1PerThread; u++) {
+        if (dst[u] != ~0u) {
+          ox[dst[u]] = rx[u];
+          oy[dst[u]] = ry[u];
+          oz[dst[u]] = rz[u];
+          sorted_idx[bb + base + dst[u]] = static_cast<int>(di[u]);
+        }
+      }
+      __syncthreads();
+    } else {
+      // one cell with more points than LDS holds (thousands per voxel): rank sort through global scratch into a second
+      // set of slices.  O(n^2) reads by the block: slow, and rare.
+      unsigned* sidx = scratch + 4 * static_cast<size_t>(n_total) + bb + base;  // ranks
+      for (unsigned q = threadIdx.x; q < n_pass; q += kBlock) {
+        const unsigned mine = pidx[q];
+        unsigned r = 0, t = 0;
+        for (; t + 8 <= n_pass; t += 8) {
+          unsigned a[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) a[u] = pidx[t + u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) r += (a[u] < mine) ? 1u : 0u;
+        }
+        for (; t < n_pass; t++) r += (pidx[t] < mine) ? 1u : 0u;
+        sidx[r] = q;
+        sorted_idx[bb + base + r] = static_cast<int>(mine);
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (threadIdx.x == 0 && static_cast<int>(n_pass) >= min_pts) {
+        VoxelSums S;
+        unsigned i = 0;
+        for (; i + 8 <= n_pass; i += 8) {
+          float x[8], y[8], z[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const unsigned q = sidx[i + u]; x[u] = px[q]; y[u] = py[q]; z[u] = pz[q]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) S.add(x[u], y[u], z[u]);
+        }
+        for (; i < n_pass; i++) { const unsigned q = sidx[i]; S.add(px[q], py[q], pz[q]); }
+        const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
+        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+      }
+      c_lo = c_hi;
+      __syncthreads();
+      continue;
+    }
+    // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
+    if (threadIdx.x == 0) s_nteam = 0;
+    __syncthreads();
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
+      const int n_c = static_cast<int>(cnt[c]);
+      if (n_c > kTeamCell && n_c >= min_pts) {
+        const int slot = atomicAdd(&s_nteam, 1);
+        s_team_cell[slot] = c;
+        cur[c] = static_cast<unsigned>(slot);  // (the scatter cursors are free again)
+      }
+    }
+    __syncthreads();
+    if (s_nteam > 0) {
+#pragma clang fp contract(off)
+      const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
+      // lane -> (a, b): 0-2 mean sums a * 1; 3-8 the products xx xy xz yy yz zz; 9-11 the f32 centroid sums
+      const int ia = (tl < 3) ? tl : (tl < 6) ? 0 : (tl < 8) ? 1 : (tl == 8) ? 2 : (tl < 12) ? tl - 9 : 0;
+      const int ib = (tl == 3) ? 0 : (tl == 4 || tl == 6) ? 1 : (tl == 5 || tl == 7 || tl == 8) ? 2 : -1;
+      const float* pa = (ia == 0) ? ox : (ia == 1) ? oy : oz;
+      const float* pb = (ib == 0) ? ox : (ib == 1) ? oy : (ib == 2) ? oz : &s_one;
+      const unsigned sb = (ib < 0) ? 0u : 1u;  // mean / centroid lanes multiply by the constant 1.0f (exact)
+      const int n_team = s_nteam;
+      for (int s = team; s < n_team; s += kBlock / kTeamLanes) {
+        const int c = s_team_cell[s];
+        const unsigned beg = cstart[c] - base, n_c = cnt[c];
+        double acc = (tl == 3 || tl == 6 || tl == 8) ? 1.0 : 0.0;  // cov_ starts as Identity (voxel_grid_covariance_omp.h:107)
+        float acc32 = 0.f;
+        unsigned i = 0;
+        for (; i + 4 <= n_c; i += 4) {
+          float a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { a[u] = pa[beg + i + u]; b[u] = pb[(beg + i + u) * sb]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double prod = static_cast<double>(a[u]) * static_cast<double>(b[u]);
+            acc += prod;
+            acc32 += a[u];
+          }
+        }
+        for (; i < n_c; i++) {
+          const float a = pa[beg + i], b = pb[(beg + i) * sb];
+          const double prod = static_cast<double>(a) * static_cast<double>(b);
+          acc += prod;
+          acc32 += a;
+        }
+        if (tl < 9) s_team64[s][tl] = acc;
+        else if (tl < 12) s_team32[s][tl - 9] = acc32;
+      }
+    }
+    __syncthreads();
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
+      const int n_c = static_cast<int>(cnt[c]);
+      if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
+      const unsigned beg = cstart[c] - base;
+      // record slot: candidates' segments start at least min_pts apart, so start / min_pts is unique per candidate --
+      // no scan over the buckets is needed to number the records (k1_leaves numbers the LEAVES when somebody asks)
+      const int r = static_cast<int>((bb + cstart[c]) / static_cast<unsigned>(min_pts));
+      VoxelSums S;
+      if (n_c > kTeamCell) {
+        const unsigned slot = cur[c];
+        S.sx = s_team64[slot][0]; S.sy = s_team64[slot][1]; S.sz = s_team64[slot][2];
+        S.cxx = s_team64[slot][3]; S.cxy = s_team64[slot][4]; S.cxz = s_team64[slot][5];
+        S.cyy = s_team64[slot][6]; S.cyz = s_team64[slot][7]; S.czz = s_team64[slot][8];
+        S.fx = s_team32[slot][0]; S.fy = s_team32[slot][1]; S.fz = s_team32[slot][2];
+      } else {
+        int i = 0;
+        for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
+          float x[4], y[4], z[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { x[u] = ox[beg + i + u]; y[u] = oy[beg + i + u]; z[u] = oz[beg + i + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) S.add(x[u], y[u], z[u]);
+        }
+        for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
+      }
+      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+    }
+    c_lo = c_hi;
+    __syncthreads();  // the LDS arrays are reused by the next pass
+  }
+  {  // the bucket's valid voxels -> its own word; k1_count adds the words up when somebody asks (grid_counts).  One atomic
+     // per WAVE on a single counter was 8 of this kernel's 41 us at 1 M points: same-address atomics serialise at the
+     // memory side, ~15 ns each
+    unsigned v = n_ok;
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    __syncthreads();  // (s_u3 is free)
+    if ((threadIdx.x & (kWave - 1)) == 0) s_u3[threadIdx.x / kWave].pts = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int w = 0; w < kBlock / kWave; w++) t += s_u3[w].pts;
+      bucket_valid[k] = t;
+    }
   }
 }
 
@@ -1756,6 +1435,53 @@ __global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long
   }
 }
 
+// Leaf arrays of a bucket-form build (ascending cell order: leaf_cell / leaf_start / leaf_count / leaf_rec), written only
+// when somebody asks for them (ndt_grid_dump, getFitnessScore's index, ndt_grid_size): after k1_count has numbered
+// the buckets' occupied cells.
+__global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ bpts, GridGeom g, int map, int C, int min_pts,
+                                                    const unsigned* __restrict__ bucket_base, const unsigned* __restrict__ occ_base,
+                                                    int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
+                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec, const int* __restrict__ lut) {
+  extern __shared__ unsigned k1_lds[];
+  __shared__ U3 s_u3[kBlock / kWave];
+  const int k = blockIdx.x;
+  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
+  if (be == bb) return;
+  unsigned* cnt = k1_lds;
+  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
+  const int per = C / kBlock > 0 ? C / kBlock : 1;
+  const int lo = threadIdx.x * per;
+  U3 t = {0, 0, 0};
+  for (int c = lo; c < lo + per && c < C; c++) {
+    t.pts += cnt[c];
+    t.occ += (cnt[c] > 0);
+  }
+  U3 total;
+  U3 run = block_exclusive_scan(t, total, s_u3);
+  const unsigned ob = occ_base[k];
+  for (int c = lo; c < lo + per && c < C; c++) {
+    const unsigned v = cnt[c];
+    if (v > 0) {
+      const unsigned o = ob + run.occ;
+      leaf_cell[o] = k1_cell(k, c, map);
+      leaf_start[o] = bb + run.pts;
+      leaf_count[o] = static_cast<int>(v);
+      int rec = -1;
+      if (v >= static_cast<unsigned>(min_pts)) {  // the voxel's record: wherever the compaction put it (read back from the table)
+        const int cell = k1_cell(k, c, map);
+        const int cz = cell / g.mul[2], cy = (cell - cz * g.mul[2]) / g.mul[1], cx = cell - cz * g.mul[2] - cy * g.mul[1];
+        const int e = lut[static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * g.pmul[1] +
+                          static_cast<long long>(cz + kLutBorder) * g.pmul[2]];
+        rec = (e >= 0) ? e : (e <= -2 ? -(e + 2) : -1);
+      }
+      leaf_rec[o] = rec;
+    }
+    run.pts += v;
+    run.occ += (v > 0);
+  }
+}
+
+
 // k_presort_large: leaves per wave-step and grid (one leaf per wave while that stays within 8192 waves)
 inline int presort_chunk(int n_leaves) { return max(1, min(64, (n_leaves + 8191) / 8192)); }
 inline int presort_grid(int n_leaves) { return max(1, min(8192, (n_leaves + presort_chunk(n_leaves) - 1) / presort_chunk(n_leaves))); }
@@ -1783,8 +1509,14 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
                               int n_blocks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
-                     stride_bytes, d_dst, d_block_minmax);
+  const bool rec16 = stride_bytes == 16 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0;
+  if (rec16 && !d_dst)
+    hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax);
+  else if (rec16)
+    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax);
+  else
+    hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
+                       stride_bytes, d_dst, d_block_minmax);
   return hipGetLastError();
 }
 
@@ -1847,107 +1579,62 @@ static int pow2_ceil(long long v) {
   return p;
 }
 
-static size_t k1_finalize_lds(int pt, bool two, int dbits) {
-  const size_t D = static_cast<size_t>(1) << dbits, cap = static_cast<size_t>(pt) * kK1Threads;
-  size_t b = kK1Waves * D * 2 + (D + 2) * 4 + std::max(3 * cap, 2 * D) * 4 + cap * 4 + (cap + 2) * 2;
-  b += two ? cap * 4 + cap * 2 : cap * 2;
-  return (b + 15) & ~static_cast<size_t>(15);
-}
-
 bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
-  if (n_points <= 0 || n_cells <= 0) return false;
-  // cells are dealt to the buckets in runs of 2^rb (k1_bucket): K a power of two
+  constexpr int kMaxBuckets = kK1MaxBuckets, kMaxCells = 4096;
+  if (n_points <= 0 || n_cells <= 0 || n_cells > static_cast<long long>(kMaxBuckets) * kMaxCells) return false;
+  // ~1000 points per bucket: a bucket's per-point arrays then live in LDS and there are several blocks per CU
+  // ... and at least a bucket per CU; small clouds (the mapping nodes' 16 k points: latency-bound on their fullest bucket)
+  // get ~256 points per bucket (measured with the interleaved buckets: 16 k / 60 k / 200 k points 41 / 46 / 71 us per build,
+  // against 54 / 74 / 117 us with ~8 points per bucket and 67 / 80 / 100 us for the general chain)
+  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 256; }();
+  const long long k_small = std::min<long long>(4096, n_points / small_div);
+  const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / 1024));
+  // cells are dealt to the buckets in runs of 2^rb (k1_bucket): K a power of two, C = slots per bucket << rb
   static const int rb_env = [] { const char* v = getenv("NDT_K1_RUN_BITS"); return v ? std::max(0, std::min(8, atoi(v))) : 3; }();
   const int rb = rb_env;
-  // Buckets: as many points as one block of k1_finalize sorts in LDS (~4500 of its 6144 on a uniform cloud: a bucket per CU
-  // at 1 M points); at least 256 of them, and small clouds (the mapping nodes' 16 k points: latency-bound on their fullest
-  // bucket) get ~256 points per bucket
-  static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 256; }();
-  static const int big_div = [] { const char* v = getenv("NDT_K1_BUCKET_POINTS"); return v ? std::max(64, atoi(v)) : 4500; }();
-  long long k_target = n_points <= 262144 ? std::min<long long>(1024, n_points / small_div) : n_points / big_div;
-  int K = std::max(256, std::min(kK1MaxBuckets, pow2_ceil(k_target)));
+  int K = std::min(kMaxBuckets, pow2_ceil(k_target));
   const long long runs = (n_cells + (1ll << rb) - 1) >> rb;
-  int cbits, dbits;
+  int C;
   for (;;) {
-    const long long runs_per_bucket = (runs + K - 1) / K;
-    cbits = rb;
-    while ((1ll << (cbits - rb)) < runs_per_bucket) cbits++;
-    cbits = std::max(cbits, 1);
-    dbits = std::min(cbits, kK1DigitBits);
-    // two digits: 4096 points per block at most; keep the mean bucket within ~80 % of that
-    const bool two = cbits > dbits;
-    if (cbits > 2 * kK1DigitBits || (two && n_points / K > 3300)) {
-      if (K >= kK1MaxBuckets) {
-        if (cbits > 2 * kK1DigitBits) return false;  // (more than 4096 x 4 M cells: the general path)
-        break;  // crowded buckets take k1_finalize's streamed path
-      }
-      K <<= 1;
-      continue;
-    }
-    break;
+    C = std::max(32, pow2_ceil((runs + K - 1) / K) << rb);
+    if (C <= kMaxCells) break;
+    if (K >= kMaxBuckets) return false;
+    K <<= 1;
   }
-  P.cbits = cbits;
-  P.dbits = dbits;
+  P.cells_per_bucket = C;
   int kb = 0;
   while ((1 << kb) < K) kb++;
   P.shift = rb | (kb << 8);  // the packed cell <-> (bucket, local) map of the kernels
   P.n_buckets = K;
-  // points per thread of k1_finalize's LDS path: the mean bucket + 12 % + 160 (one-digit keys: up to 12 x 512; two digits: 8 x 512)
-  const long long want = static_cast<long long>(n_points) / K * 9 / 8 + 160;
-  const bool two = cbits > dbits;
-  P.fin_pt = want <= 1024 ? 2 : (want <= 4096 || two) ? 8 : 12;
-  static const int pt_env = [] { const char* v = getenv("NDT_K1_FIN_PT"); return v ? atoi(v) : 0; }();
-  if (pt_env == 2 || pt_env == 8 || (pt_env == 12 && !two)) P.fin_pt = pt_env;
-  if (P.fin_pt == 12 && k1_finalize_lds(12, two, dbits) > kK1MaxDynamicLds) P.fin_pt = 8;  // (wide digits: the counter rows take the room)
-  // blocks of k1_hist / k1_scatter: at most 512 rows in the count matrix; a block ranks its points in rounds of 4096
-  long long ppb = std::max(512, std::min(kK1Round, pow2_ceil((n_points + 255) / 256)));
-  if (static_cast<long long>(n_points) > 512ll * kK1Round) ppb = ((n_points + 511) / 512 + kK1Round - 1) / kK1Round * kK1Round;
+  P.pts_per_block = std::max(1024, std::min(16384, pow2_ceil((n_points + 383) / 384)));  // >= one block per CU: the LDS atomics of a block run at ~0.7 G/s
   static const int ppb_env = [] { const char* v = getenv("NDT_K1_PPB"); return v ? atoi(v) : 0; }();
-  if (ppb_env > 0) ppb = ppb_env;
-  while ((n_points + ppb - 1) / ppb > kColGroups * kColRows) ppb += kK1Round;  // k1_colscan holds a column's rows in registers
-  P.pts_per_block = static_cast<int>(ppb);
-  P.n_blocks = static_cast<int>((n_points + ppb - 1) / ppb);
+  if (ppb_env > 0) P.pts_per_block = ppb_env;
+  P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
   return true;
-}
-
-template <int PT, bool TWO>
-static void launch_k1_finalize(const GridGeom& g, const GridBuildPlan& P, int min_pts, double eig_ratio, const GridBuildScratch& S, int n,
-                               int* sorted_idx, VoxelRec* recs, VoxelSide* centroids, int* lut, hipStream_t stream) {
-  const size_t lds = k1_finalize_lds(PT, TWO, P.dbits);
-  static bool once = [] {  // more than 64 KB of dynamic LDS has to be asked for
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_finalize<PT, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
-    return true;
-  }();
-  (void)once;
-  hipLaunchKernelGGL((k1_finalize<PT, TWO>), dim3(P.n_buckets), dim3(kK1Threads), lds, stream, S.bpts, g, P.shift, P.n_buckets, P.cbits, P.dbits,
-                     min_pts, eig_ratio, S.bucket_base, sorted_idx, recs, centroids, lut, S.bucket_stat, S.leaf_slots, S.order,
-                     static_cast<unsigned>(n), S.stamps ? S.stamps + static_cast<size_t>(P.n_blocks) * kK1StampPhases : nullptr);
 }
 
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& P, int min_pts,
                                      double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream) {
-  const int K = P.n_buckets;
-  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
-                     P.pts_per_block, S.cntmat, lut, g.lut_cells);
-  const size_t lds_scatter = (static_cast<size_t>(K) + 1 + 2 * static_cast<size_t>(K)) * sizeof(unsigned) + static_cast<size_t>(kK1Waves) * K * sizeof(unsigned short);
-  static bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
-    return true;
-  }();
-  (void)once;
-  hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, S.cntmat + static_cast<size_t>(P.n_blocks) * K);
-  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
-                     S.cntmat + static_cast<size_t>(P.n_blocks) * K, S.bucket_base, S.bpts, counts, S.stamps);
-  const bool two = P.cbits > P.dbits;
-  if (two) {
-    if (P.fin_pt == 2) launch_k1_finalize<2, true>(g, P, min_pts, eig_ratio, S, n, sorted_idx, recs, centroids, lut, stream);
-    else launch_k1_finalize<8, true>(g, P, min_pts, eig_ratio, S, n, sorted_idx, recs, centroids, lut, stream);
-  } else {
-    if (P.fin_pt == 2) launch_k1_finalize<2, false>(g, P, min_pts, eig_ratio, S, n, sorted_idx, recs, centroids, lut, stream);
-    else if (P.fin_pt == 8) launch_k1_finalize<8, false>(g, P, min_pts, eig_ratio, S, n, sorted_idx, recs, centroids, lut, stream);
-    else launch_k1_finalize<12, false>(g, P, min_pts, eig_ratio, S, n, sorted_idx, recs, centroids, lut, stream);
-  }
+  const int K = P.n_buckets, C = P.cells_per_bucket;
+  const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
+  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
+                     S.bucket_count, S.blockbase, lut, g.lut_cells);
+  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k + sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
+                     P.pts_per_block, S.bucket_count, S.bucket_base, S.blockbase, S.bpts, counts);
+  // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
+  // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
+  // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
+  // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
+  const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
+  int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));
+  if (K <= 512 || n <= 262144) lds_cap = kK1LdsCap;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
+  while (lds_cap > 256 && lds_cap > (60 * 1024 / 4 - 3 * C) / 5) lds_cap >>= 1;
+  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
+  if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
+  hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
+                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut,
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.bucket_count);
   return hipGetLastError();
 }
 
@@ -1986,13 +1673,20 @@ hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec*
   return hipGetLastError();
 }
 
-hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min_pts, const uint4* leaf_slots, const unsigned* bucket_base,
-                              const unsigned* bucket_stat, unsigned* occ_base /* n_buckets + 1 words */, int* leaf_cell, unsigned* leaf_start,
-                              int* leaf_count, int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream) {
-  const int K = P.n_buckets;
-  hipLaunchKernelGGL(k1_leaf_scan, dim3(1), dim3(kBlock), 0, stream, bucket_stat, K, occ_base, counts);
-  hipLaunchKernelGGL(k1_leaves, dim3(K), dim3(kBlock), 0, stream, leaf_slots, g, min_pts, bucket_base, bucket_stat, occ_base, leaf_cell, leaf_start,
-                     leaf_count, leaf_rec, lut);
+hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min_pts, const float4* bpts, const unsigned* bucket_base,
+                              unsigned* scratch /* 4 K + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count, int* leaf_rec,
+                              unsigned* counts, const int* lut, hipStream_t stream) {
+  const int K = P.n_buckets, C = P.cells_per_bucket;
+  unsigned* ticket = scratch;
+  unsigned* tot = scratch + 2;
+  unsigned* occ_base = tot + 2 * K;
+  unsigned* cand_base = occ_base + (K + 1);
+  hipError_t e = hipMemsetAsync(ticket, 0, 2 * sizeof(unsigned), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k1_count, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, K, C,
+                     static_cast<unsigned>(min_pts), bucket_base, tot, ticket, occ_base, cand_base, counts);
+  hipLaunchKernelGGL(k1_leaves, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, C, min_pts,
+                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec, lut);
   return hipGetLastError();
 }
 

@@ -154,13 +154,20 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   void release() {
-    if (p) DevPool::instance().release(p, cls_bytes);
+    if (p && cls_bytes) DevPool::instance().release(p, cls_bytes);  // (cls_bytes == 0: borrowed memory, not ours to free)
     p = nullptr;
     cap = 0;
     cls_bytes = 0;
   }
+  // refer to n elements of memory somebody else owns and keeps alive (clouds handed over by reference)
+  void borrow(T* ptr, size_t n) {
+    release();
+    p = ptr;
+    cap = n;
+    cls_bytes = 0;
+  }
   hipError_t reserve(size_t n) {
-    if (n <= cap && p) return hipSuccess;
+    if (n <= cap && p && cls_bytes) return hipSuccess;
     release();
     void* q = nullptr;
     size_t got = 0;
@@ -212,11 +219,11 @@ struct DeviceGrid {
   DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
   DevBuf<int> row_any;      // per x-row of cells: occupied or not
   bool have_cell2leaf = false;
-  // bucket-form build (ndt_grid_kernels.hip): kept until the leaf arrays have been written (grid_counts)
+  // bucket-form build (ndt_kernels.hip): kept until the leaf arrays have been written (grid_counts)
   bool leaves_pending = false;
   ndt::GridBuildPlan plan{};
-  DevBuf<uint4> leaf_slots;          // every bucket's runs (cell, start, count) at [bucket base + ordinal]
-  DevBuf<unsigned> bucket_base, bucket_stat;
+  DevBuf<float4> bpts;
+  DevBuf<unsigned> bucket_base;
   ndt::GridView view() const {
     ndt::GridView v;
     v.lut = lut.p;
@@ -300,6 +307,8 @@ struct ndt_context {
   void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
   int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
+  DevBuf<unsigned> k1_bucket_count;  // kK1MaxBuckets counters of the bucket-form grid build, zero between builds (build_grid)
+  bool k1_bucket_count_clean = false;
   DevBuf<unsigned> server_counter;  // two sets of kServerCounterWords, used alternately (server_start)
   int server_counter_set = 0;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
@@ -368,7 +377,7 @@ ndt_status ensure_host_rows(ndt_context* h, size_t rows);
 ndt::SolverParams solver_params(const ndt_context* h);
 // ---- ndt_grid.hip
 ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride, bool on_device,
-                        std::shared_ptr<DeviceCloud>& out);
+                        std::shared_ptr<DeviceCloud>& out, bool by_reference = false);
 struct BBox {
   float mn[3], mx[3];
 };

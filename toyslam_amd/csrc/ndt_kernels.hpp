@@ -138,34 +138,26 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
 // K1 in its bucket form (ndt_kernels.hip): the voxel index space cut into n_buckets runs of cells_per_bucket = 2^shift
 // consecutive cells; pts_per_block points per block of the two point passes.
 struct GridBuildPlan {
-  int shift;          // the packed cell <-> (bucket, local cell) map: run bits | bucket bits << 8
-  int n_buckets;      // K, a power of two
-  int cbits, dbits;   // bits of a bucket's local cell index; bits of one radix digit of k1_finalize's sort (cbits <= 2 dbits)
-  int fin_pt;         // points per thread of k1_finalize's LDS path (capacity fin_pt x 512 points per bucket)
-  int pts_per_block, n_blocks;  // k1_hist / k1_scatter: rows of the count matrix
+  int shift, n_buckets, cells_per_bucket, pts_per_block, n_blocks;
 };
-// false: the grid is outside the bucket form's range (a bucket would hold more than 2^22 cells): the general path builds it
+// false: the grid is outside the bucket form's range (more than 8192 x 4096 cells): the general path builds it
 bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& plan);
-constexpr int kK1MaxBuckets = 4096;  // k1_scatter keeps eight rows of u16 counters per bucket in LDS
-constexpr int kK1DigitBits = 11;     // k1_finalize: eight rows of 2^11 u16 counters
+constexpr int kK1MaxBuckets = 8192;
 struct GridBuildScratch {
-  unsigned* cntmat;        // [n_blocks x n_buckets] points per (block of points, bucket) + [n_buckets] bucket sizes
-  unsigned* bucket_base;   // [n_buckets + 1]   (kept with the grid: the leaf pass needs it)
-  unsigned* bucket_stat;   // [n_buckets x 4] valid / occupied / candidate voxels per bucket   (kept with the grid)
-  uint4* leaf_slots;       // [n] runs of every bucket at [bucket base + ordinal]: cell, start, count   (kept with the grid until the leaf pass)
-  float4* bpts;            // [n] points in bucket order, w = point index
-  unsigned* order;         // [4 n] (key, position) pairs of buckets too crowded for LDS
-  unsigned long long* stamps;  // development aid (NDT_K1_STAMPS): [(n_blocks + n_buckets) x kK1StampWords] shader clocks, or null
+  unsigned* bucket_count;  // [n_buckets] of the HANDLE's kK1MaxBuckets counters: zero on entry, zero again when k1_finalize is through
+  unsigned* bucket_base;   // [n_buckets + 1] bases + [n_buckets] valid voxels per bucket   (kept with the grid: the leaf pass needs both)
+  unsigned* blockbase;     // [n_blocks x n_buckets]
+  float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
+  unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
 };
-constexpr int kK1StampWords = 12;
-// counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0];
-// [1..3] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
+// counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
+// [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
                                      double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream);
-hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const uint4* leaf_slots, const unsigned* bucket_base,
-                              const unsigned* bucket_stat, unsigned* occ_base /* n_buckets + 1 words */, int* leaf_cell, unsigned* leaf_start,
-                              int* leaf_count, int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream);
+hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const float4* bpts, const unsigned* bucket_base,
+                              unsigned* scratch /* 4 n_buckets + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count,
+                              int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream);
 // records of a bucket-form build -> dense, in ascending cell order (table entries rewritten); tile_sums: record_compaction_tiles words
 size_t record_compaction_tiles(long long lut_cells);
 hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,
@@ -173,7 +165,8 @@ hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec*
 
 // n dense records from page-locked host memory (read by the kernel itself) into HBM
 hipError_t launch_copy_records(const float4* src_host_pinned, float4* dst, int n, hipStream_t stream);
-// repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz)
+// repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz); 16-byte records on a
+// 16-byte boundary take a float4 path, and with d_dst == nullptr only the boxes are computed (cloud used where it lies)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
                               int n_blocks, hipStream_t stream);
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);

@@ -117,6 +117,13 @@ class NormalDistributionsTransform:
     def setInputTargetDevice(self, dev_ptr, n, stride_bytes, is_dense=True):
         check(self._L.ndt_set_input_target_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense)))
 
+    def setInputTargetDeviceRef(self, dev_ptr, n, is_dense=True):
+        """The cloud (n 16-byte records in HBM) is used where it lies: keep it alive and unchanged while it is the target."""
+        check(self._L.ndt_set_input_target_device_ref(self._h, C.c_void_p(dev_ptr), n, int(is_dense)))
+
+    def setInputSourceDeviceRef(self, dev_ptr, n):
+        check(self._L.ndt_set_input_source_device_ref(self._h, C.c_void_p(dev_ptr), n))
+
     def setInputSourceDevice(self, dev_ptr, n, stride_bytes):
         check(self._L.ndt_set_input_source_device(self._h, C.c_void_p(dev_ptr), n, stride_bytes))
 
