@@ -102,6 +102,28 @@ ndt_status ndt_set_voxel_index(ndt_handle h, int mode);
  * 2.0 -> 1.0 -> 0.5 m grids over one target, one handle per grid) take every scan from one upload this way, and a
  * second donor handle can upload the next scan on its own stream meanwhile. */
 ndt_status ndt_share_input_source(ndt_handle dst, ndt_handle src);
+/* The same for the target: `dst` takes the target cloud AND the voxel grid `src` built from it (no copy, no rebuild;
+ * resolution, min_points_per_voxel and the eigenvalue ratio of `dst` become the grid's). */
+ndt_status ndt_share_input_target(ndt_handle dst, ndt_handle src);
+
+/* CU partitions: overlapping the NEXT scan's preparation with the CURRENT registration.
+ * A registration keeps the whole chip busy for its duration -- the persistent evaluation kernel holds one workgroup per CU,
+ * the per-evaluation kernels of a multi-million-point scan fill every CU -- so the upload, spatial ordering and target grid
+ * build of the following scan, issued meanwhile by another handle on another stream, wait behind it (the reference's nodes
+ * do the two strictly one after the other: ndt_omp_mapping_node.cpp:151-169, 195-211).  With partitions the two never
+ * compete: the handle's stream is created with a CU mask (hipExtStreamCreateWithCUMask),
+ *   0  the whole device (default);
+ *   1  the registration partition: all CUs but the last NDT_SIDE_CUS (default 32) -- for the handles that align;
+ *   2  the side partition: those NDT_SIDE_CUS CUs -- for handles that only prepare inputs (ndt_set_input_*,
+ *      ndt_voxel_grid_filter*, ndt_map_update*) and hand them over with ndt_share_input_source / ndt_share_input_target.
+ * Scans of up to 512 points per CU of the registration partition (114 688 points at 224 CUs) give the same bits in any
+ * partition; above that the persistent kernel's workgroup count is capped by the partition's CUs and the partial sums are
+ * added in another (still fixed) order, as they are between the persistent and the per-evaluation kernels at that size.
+ * Call before the handle is used, or between calls (the stream is replaced).
+ * ndt_get_cu_partition reports the partition and the CUs the stream really got (the device's count when masks are
+ * unavailable). */
+ndt_status ndt_set_cu_partition(ndt_handle h, int partition);
+ndt_status ndt_get_cu_partition(ndt_handle h, int* partition, int* n_cus);
 
 /* ---- registration --------------------------------------------------------
  * pcl::Registration::align(output, guess) -> computeTransformation

@@ -177,10 +177,17 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
     (d / "cloud_3.pcd").rename(d / "cloud_03.pcd")  # numbers, not names, give the order
     exe = str(tmp_path / "map_sequence")
     libdir = os.path.join(ROOT, "toyslam_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "map_sequence.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "map_sequence.cpp"),
                            "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
     map_out = str(tmp_path / "map.pcd")
     out = subprocess.check_output([exe, str(d), "0.5", map_out], text=True)
+    # "pipeline": the steps of consecutive scans overlap (prep handles, inputs taken over by the registration handle with
+    # ndt_share_input_target / _source; with NDT_PIPELINE_PARTITION=1 on CU partitions) -- the same lines, bit for bit
+    strip = lambda o: [ln for ln in o.splitlines() if not ln.startswith("time:") and not ln.startswith("global map written")]
+    for env in ({}, {"NDT_PIPELINE_PARTITION": "1"}):
+        out_pipe = subprocess.check_output([exe, str(d), "0.5", "-", "node", "pipeline"], text=True, env=dict(os.environ, **env))
+        assert strip(out) == strip(out_pipe)
+        assert "overlapped with the registrations" in out_pipe and "file reading overlapped" in out
     lines = out.splitlines()
     traj = []
     for i, ln in enumerate(lines):
@@ -213,6 +220,7 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
     # starts from the previous result, fitness printed, pose / trajectory / map updated after every scan
     from scipy.spatial import cKDTree
     out = subprocess.check_output([exe, str(d), "0.3", "-", "rosbag"], text=True)
+    assert strip(out) == strip(subprocess.check_output([exe, str(d), "0.3", "-", "rosbag", "pipeline"], text=True))
     lines = out.splitlines()
     traj = [np.array([[float(x) for x in lines[i + 1 + r].split()] for r in range(4)]) for i, ln in enumerate(lines) if ln.startswith("trajectory[")]
     fit = [float(ln.split()[1]) for ln in lines if ln.startswith("fitness:")]

@@ -311,14 +311,74 @@ def test_point_sharded_scan_through_the_communicator(mods, map_build):
 
 
 # ------------------------------------------------------------------ configs[4]
-def test_config4_pyramid_on_a_streamed_sequence(mods, cfg_b, large_golden, tmp_path):
+@pytest.fixture(scope="module")
+def seq16(mods, cfg_b, tmp_path_factory):
+    """The 16-scan sequence of configs[4] on disk (2M-pt PCD files) and its T_gt,k."""
+    _, _, _, pyramid = mods
+    tgt, _ = cfg_b
+    d = str(tmp_path_factory.mktemp("seq16"))
+    return d, pyramid.write_sequence(d, tgt, 16, 2000000)
+
+
+def test_config4_pyramid_app_without_python(mods, cfg_b, large_golden, seq16, tmp_path):
+    """apps/pyramid_sequence.cpp: configs[4] over the C-ABI alone (three level handles, two donor handles uploading on streams
+    of their own, one upload shared by the levels, each level's result the next level's guess:
+    ndt_rosbag_mapping_node.cpp:120-144) -- scans 0 and 5 follow the oracle level by level like the Python
+    orchestration, every scan ends at its T_gt,k, and the overlapped pipeline prints what the serial one prints."""
+    import subprocess
+    from conftest import ROOT
+    ndt, _, clouds, pyramid = mods
+    tgt, _ = cfg_b
+    seq_dir, T_gts = seq16
+    tp = str(tmp_path / "target.pcd")
+    ndt.pcd_write_xyz(tp, tgt)
+    exe = str(tmp_path / "pyramid_sequence")
+    libdir = os.path.join(ROOT, "toyslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "pyramid_sequence.cpp"),
+                           "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
+
+    def run(*extra):
+        out = subprocess.check_output([exe, tp, seq_dir, "2.0,1.0,0.5"] + list(extra), text=True, timeout=600)
+        lines = out.splitlines()
+        scans = []
+        for i, ln in enumerate(lines):
+            if ln.startswith("scan cloud_"):
+                scans.append({"number": int(ln.split("cloud_")[1].split(".")[0]), "levels": []})
+            elif ln.startswith("level "):
+                f = ln.split()
+                T = np.array([[float(x) for x in lines[i + 1 + r].split()] for r in range(4)])
+                scans[-1]["levels"].append({"res": float(f[1].rstrip(":")), "iterations": int(f[3]), "converged": bool(int(f[5])), "T": T})
+        return out, scans
+
+    out, scans = run()
+    assert [s["number"] for s in scans] == list(range(1, 17)) and all(len(s["levels"]) == 3 for s in scans)
+    for k_str, gold in large_golden["pyramid"].items():
+        k = int(k_str)
+        for lvl, gl in zip(scans[k]["levels"], gold["levels"]):
+            Tg = np.array(gl["T"])
+            assert lvl["res"] == gl["resolution"]
+            assert rot_err(lvl["T"], Tg) < ROT_TOL and trans_err(lvl["T"], Tg) < TRANS_TOL, (k, gl["resolution"])
+            assert lvl["iterations"] == gl["iterations"] and lvl["converged"] == gl["converged"], (k, gl["resolution"])
+    for k in range(16):
+        T = scans[k]["levels"][-1]["T"]
+        assert rot_err(T, T_gts[k]) < 2e-4 and trans_err(T, T_gts[k]) < 2e-2, k
+    assert "scans 16 of 16 files" in out and "overlapped" in out
+    out_s, scans_s = run("serial")
+    assert all(np.array_equal(a["levels"][-1]["T"], b["levels"][-1]["T"]) for a, b in zip(scans, scans_s))
+    # ... and the Python orchestration of the same handles returns the same matrices
+    pyr = pyramid.Pyramid(levels=(2.0, 1.0, 0.5))
+    pyr.setInputTarget(tgt)
+    r = pyr.run_sequence(seq_dir, overlap=True)
+    assert all(np.array_equal(np.asarray(a, dtype=np.float32), b["levels"][-1]["T"].astype(np.float32)) for a, b in zip(r["T"], scans))
+
+
+def test_config4_pyramid_on_a_streamed_sequence(mods, cfg_b, large_golden, seq16):
     """2.0 -> 1.0 -> 0.5 m on a sequence of 16 2M-pt PCD scans streamed from disk (read-ahead + upload overlapped with
     the registration of the previous scan): scans 0 and 5 follow the oracle level by level, every scan ends at its
     T_gt,k, and the overlapped pipeline returns exactly what the strictly sequential one returns."""
     ndt, _, clouds, pyramid = mods
     tgt, _ = cfg_b
-    seq_dir = str(tmp_path / "seq")
-    T_gts = pyramid.write_sequence(seq_dir, tgt, 16, 2000000)
+    seq_dir, T_gts = seq16
     pyr = pyramid.Pyramid(levels=(2.0, 1.0, 0.5))
     pyr.setInputTarget(tgt)
     r = pyr.run_sequence(seq_dir, overlap=True)

@@ -206,6 +206,74 @@ def test_clouds_by_reference_equal_copied_clouds(mods, n, dense):
             gr.setInputTargetDeviceRef(d_t + 4, max(1, n - 1), is_dense=bool(dense))
 
 
+def test_cu_partitions_and_shared_targets(mods, pair):
+    """ndt_set_cu_partition / ndt_share_input_target: a handle that prepares the inputs on the side partition of the CUs, a
+    handle that registers on the registration partition with the inputs taken over (no copy, no rebuild) -- the pipelined
+    form of the nodes' loop (ndt_omp_mapping_node.cpp:151-169) -- gives the bits of the one-handle loop; partitions can be
+    changed on a live handle; the evaluation server and the launch path agree on a partitioned handle as everywhere."""
+    import threading
+    ndt, po, _ = mods
+    t, s = pair
+    ref = ndt.NormalDistributionsTransform()
+    ref.setInputTarget(t)
+    ref.setInputSource(s)
+    ref.align()
+    T_ref, it_ref = ref.getFinalTransformation(), ref.getFinalNumIteration()
+    prep, reg = ndt.NormalDistributionsTransform(), ndt.NormalDistributionsTransform()
+    prep.setCuPartition(2)
+    reg.setCuPartition(1)
+    part, n_side = prep.getCuPartition()
+    part_r, n_reg = reg.getCuPartition()
+    assert (part, part_r) == (2, 1)
+    assert (n_side, n_reg) in ((32, 224), (256, 256))  # masked streams, or the whole device where masks are not to be had
+    prep.setInputTarget(t)
+    prep.setInputSource(s)
+    reg.shareInputTarget(prep)
+    reg.shareInputSource(prep)
+    a, b = reg.grid(), ref.grid()
+    for k in ("idx", "n", "mean", "cov", "icov"):
+        assert np.array_equal(a[k], b[k]), k
+    reg.align()
+    assert np.array_equal(reg.getFinalTransformation(), T_ref) and reg.getFinalNumIteration() == it_ref
+    reg.setEvaluationPath(0)
+    reg.align()
+    assert np.array_equal(reg.getFinalTransformation(), T_ref)
+    reg.setEvaluationPath(1)
+    # the two really run side by side: registrations in this thread, input preparation in another
+    stop, errs, n_prep = threading.Event(), [], [0]
+
+    def preparer():
+        try:
+            while not stop.is_set():
+                prep.setInputTarget(t)
+                prep.setInputSource(s)
+                n_prep[0] += 1
+        except Exception as e:
+            errs.append(e)
+    th = threading.Thread(target=preparer)
+    th.start()
+    try:
+        for _ in range(50):
+            reg.align()
+            assert np.array_equal(reg.getFinalTransformation(), T_ref)
+    finally:
+        stop.set()
+        th.join()
+    assert not errs and n_prep[0] > 0
+    # a live handle changes partition (its stream is replaced) and keeps working
+    reg.setCuPartition(0)
+    reg.align()
+    assert np.array_equal(reg.getFinalTransformation(), T_ref)
+    reg.setCuPartition(2)
+    reg.align()
+    assert np.array_equal(reg.getFinalTransformation(), T_ref)
+    # a shared target brings its resolution along
+    other = ndt.NormalDistributionsTransform()
+    other.setResolution(3.0)
+    other.shareInputTarget(prep)
+    assert other.getResolution() == 1.0
+
+
 @pytest.mark.parametrize("res", [0.5, 2.0])
 def test_grid_other_resolutions(mods, pair, res):
     t, s = pair

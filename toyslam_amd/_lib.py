@@ -63,6 +63,9 @@ SIGNATURES = {
     "ndt_set_input_source": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
     "ndt_set_input_target_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int]),
     "ndt_set_input_source_device": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t]),
+    "ndt_share_input_target": (C.c_int, [vp, vp]),
+    "ndt_set_cu_partition": (C.c_int, [vp, C.c_int]),
+    "ndt_get_cu_partition": (C.c_int, [vp, ip, ip]),
     "ndt_set_input_target_device_ref": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
     "ndt_set_input_source_device_ref": (C.c_int, [vp, vp, C.c_size_t]),
     "ndt_share_input_source": (C.c_int, [vp, vp]),

@@ -78,7 +78,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
   static const bool fuse = [] { const char* v = getenv("NDT_K2_FUSED"); return v ? atoi(v) != 0 : true; }();
   const bool fused = fuse && spin_wait && rq.kind != ndt::EVAL_HESSIAN_F64 && ndt::derivative_variant() == 0 && !h->allreduce && !h->comm;
-  const int nblk = fused ? ndt::fused_blocks(n) : ndt::derivative_blocks(n, h->search);
+  const int nblk = fused ? ndt::fused_blocks(n, h->cu_partition ? h->cu_count : 0) : ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   if (!h->ticket.p) {
     HIP_TRY(h->ticket.reserve(32 * 17));  // top counter + 16 shard counters, one per 128-B line (k_derivatives_fused)

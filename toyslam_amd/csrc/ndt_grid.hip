@@ -823,6 +823,27 @@ ndt_status ndt_share_input_source(ndt_handle dst, ndt_handle src) {
   return NDT_OK;
 }
 
+// the target cloud and its built grid, shared like the source above: a prep handle (side partition) builds the next target
+// while the registration handle works; no copy, no rebuild
+ndt_status ndt_share_input_target(ndt_handle dst, ndt_handle src) {
+  if (!dst || !src) return fail(NDT_ERR_INVALID, "null handle");
+  if (!src->target || !src->grid) return fail(NDT_ERR_NO_INPUT, "the donor handle has no input target");
+  if (dst == src) return NDT_OK;
+  if (dst->device != src->device) return fail(NDT_ERR_INVALID, "handles on different devices");
+  HIP_TRY(hipSetDevice(src->device));
+  if (src->device_ready) HIP_TRY(hipStreamSynchronize(src->stream));  // the grid may still be under construction there
+  ndt_status s = ensure_device(dst);
+  if (s) return s;
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  dst->target = src->target;
+  dst->target_dense = src->target_dense;
+  dst->grid = src->grid;
+  dst->resolution = src->grid->resolution;  // the grid's parameters come with it (the Gauss constants follow the resolution)
+  dst->min_pts = src->grid->min_pts;
+  dst->eig_ratio = src->grid->eig_ratio;
+  return NDT_OK;
+}
+
 ndt_status ndt_calculate_score(ndt_handle h, const void* cloud, size_t n, size_t stride, double* score) {
   if (!h || !score) return fail(NDT_ERR_INVALID, "bad arguments");
   if (!h->grid || !h->target) return fail(NDT_ERR_NO_INPUT, "no input target");

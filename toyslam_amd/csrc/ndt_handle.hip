@@ -31,6 +31,36 @@ int usable_devices() {
   return n;
 }
 
+// The handle's stream, on its CU partition (ndt_set_cu_partition): the whole device, the registration partition (all CUs
+// but the last side_cus()) or the side partition (those).  hipExtStreamCreateWithCUMask takes one bit per CU; which
+// physical CU a bit stands for is the driver's business -- all that matters here is that the two partitions are
+// complementary.  If the masked stream cannot be had the handle runs unpartitioned (cu_count says which it is).
+int side_cus() {
+  static const int v = [] {
+    const char* e = getenv("NDT_SIDE_CUS");
+    return e ? std::max(8, std::min(128, atoi(e))) : 32;
+  }();
+  return v;
+}
+
+static ndt_status create_stream(ndt_context* h) {
+  const int total = h->cu_total > 0 ? h->cu_total : 256;
+  h->cu_count = total;
+  if (h->cu_partition != 0 && total > 2 * side_cus()) {
+    const int side = side_cus(), lo = h->cu_partition == 1 ? 0 : total - side, hi = h->cu_partition == 1 ? total - side : total;
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int c = lo; c < hi; c++) mask[c / 32] |= 1u << (c % 32);
+    if (hipExtStreamCreateWithCUMask(&h->stream, static_cast<uint32_t>(mask.size()), mask.data()) == hipSuccess) {
+      h->cu_count = hi - lo;
+      return NDT_OK;
+    }
+    (void)hipGetLastError();
+    h->stream = nullptr;
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  return NDT_OK;
+}
+
 ndt_status ensure_device(ndt_context* h) {
   if (h->device_ready) {
     HIP_TRY(hipSetDevice(h->device));
@@ -45,8 +75,9 @@ ndt_status ensure_device(ndt_context* h) {
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(NDT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  h->cu_count = prop.multiProcessorCount;
+  h->cu_total = prop.multiProcessorCount;
+  ndt_status cs = create_stream(h);
+  if (cs) return cs;
   h->device_ready = true;
   tls_pool_stream = h->stream;
   return NDT_OK;
@@ -109,6 +140,7 @@ ndt_status ndt_clone(ndt_handle src, ndt_handle* out) {
   h->search = src->search;
   h->num_threads = src->num_threads;
   h->persistent = src->persistent;
+  h->cu_partition = src->cu_partition;
   h->voxel_index = src->voxel_index;
   h->min_pts = src->min_pts;
   h->eig_ratio = src->eig_ratio;
@@ -181,6 +213,32 @@ ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hess, double* mean_n
   if (n_evals) *n_evals = h->n_evals;
   if (n_hess) *n_hess = h->n_hess;
   if (mean_neighbors) *mean_neighbors = h->mean_neighbors;
+  return NDT_OK;
+}
+
+ndt_status ndt_set_cu_partition(ndt_handle h, int partition) {
+  if (!h || partition < 0 || partition > 2) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->cu_partition == partition) return NDT_OK;
+  h->cu_partition = partition;
+  if (!h->device_ready) return NDT_OK;  // the stream is created on first use
+  HIP_TRY(hipSetDevice(h->device));
+  ndt_status s = server_stop(h);
+  if (s) return s;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  DevPool::instance().forget_stream(h->stream);  // blocks cached for the old stream: nobody will ask for them again
+  HIP_TRY(hipStreamDestroy(h->stream));
+  h->stream = nullptr;
+  s = create_stream(h);
+  tls_pool_stream = h->stream;
+  return s;
+}
+
+ndt_status ndt_get_cu_partition(ndt_handle h, int* partition, int* n_cus) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  if (partition) *partition = h->cu_partition;
+  if (n_cus) *n_cus = h->cu_count;
   return NDT_OK;
 }
 

@@ -313,7 +313,9 @@ struct ndt_context {
   int server_counter_set = 0;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)
   bool server_want_dbg = false;
-  int cu_count = 0;
+  int cu_count = 0;      // CUs this handle's stream may use (its partition's)
+  int cu_total = 0;      // CUs of the device
+  int cu_partition = 0;  // ndt_set_cu_partition: 0 whole device, 1 registration partition, 2 side partition
   // live kernel timing (HIP events on `stream`)
   bool profiling = false;       // mode 1: one launch per evaluation, an event pair around each
   bool profile_server = false;  // mode 2: the persistent kernel of each registration between one event pair
@@ -372,6 +374,7 @@ struct ndt_context {
 namespace ndtc {
 // ---- ndt_handle.hip
 int usable_devices();
+int side_cus();
 ndt_status ensure_device(ndt_context* h);
 ndt_status ensure_host_rows(ndt_context* h, size_t rows);
 ndt::SolverParams solver_params(const ndt_context* h);

@@ -229,7 +229,7 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
                               int n_blocks, double* partials, hipStream_t stream);
 // Single launch: derivatives + fixed-order final sum by the last-arriving block + publication of
 // the packed row and `seq` into pinned host memory (out_row).  counter: one zero-initialised u32.
-int fused_blocks(int n);
+int fused_blocks(int n, int cus = 0);  // cus: CUs of the stream's partition when it has one (two blocks per CU at most)
 int points_per_block(int n);  // 256 for small scans (only half of a block's lanes carry points), else 512
 hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
                                     bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,

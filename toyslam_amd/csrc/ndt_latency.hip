@@ -589,7 +589,7 @@ int points_per_block(int n) {
   if (forced == 256 || forced == 512) return forced;
   return (n <= 65536) ? 256 : 512;
 }
-int fused_blocks(int n) {
+int fused_blocks(int n, int cus) {
   // two 512-thread blocks per CU (126 VGPRs) = every block resident at once on 256 CUs; measured on a 2M-point scan:
   // 256 / 384 / 512 / 640 / 768 / 1024 / 2048 blocks -> 449 / 446 / 538 / 465 / 464 / 488 / 432 registrations/s
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 512);
@@ -597,6 +597,7 @@ int fused_blocks(int n) {
   size_t b = (static_cast<size_t>(n) + ppb - 1) / ppb;
   if (b < 1) b = 1;
   if (b > static_cast<size_t>(cap)) b = cap;
+  if (cus > 0 && b > static_cast<size_t>(2 * cus)) b = 2 * cus;  // a handle on a CU partition: still all blocks resident at once
   return static_cast<int>(b);
 }
 

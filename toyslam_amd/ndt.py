@@ -304,6 +304,19 @@ class NormalDistributionsTransform:
         """Register the source cloud `donor` has uploaded (ndt_share_input_source)."""
         check(self._L.ndt_share_input_source(self._h, donor._h))
 
+    def shareInputTarget(self, donor):
+        """Take the target cloud and the voxel grid `donor` built (no copy, no rebuild)."""
+        check(self._L.ndt_share_input_target(self._h, donor._h))
+
+    def setCuPartition(self, partition):
+        """0 whole device, 1 registration partition, 2 side partition (ndt_set_cu_partition)."""
+        check(self._L.ndt_set_cu_partition(self._h, int(partition)))
+
+    def getCuPartition(self):
+        a, b = C.c_int(0), C.c_int(0)
+        check(self._L.ndt_get_cu_partition(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def setInputSourceRaw(self, host_ptr, n, stride_bytes=16):
         """setInputSource from a raw host pointer (e.g. the page-locked buffer of a PcdSequence scan)."""
         check(self._L.ndt_set_input_source(self._h, C.c_void_p(host_ptr), n, stride_bytes))

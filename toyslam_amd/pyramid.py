@@ -33,11 +33,20 @@ def write_sequence(directory, target, n_scans, n_points, max_t=0.3, max_deg=0.5,
 
 
 class Pyramid:
-    def __init__(self, levels=(2.0, 1.0, 0.5), device=0, trans_eps=0.01, max_iter=35, step_size=0.1):
+    def __init__(self, levels=(2.0, 1.0, 0.5), device=0, trans_eps=0.01, max_iter=35, step_size=0.1, partition=None):
+        """partition (default: off, NDT_PYRAMID_PARTITION=1 turns it on): the level handles register on the registration
+        partition of the CUs, the donor handles upload and order the next scan on the side partition (ndt_set_cu_partition).
+        Measured on this workload (round 3, NOTES.md): 272 scans/s without, 238 with -- the registration loses an eighth of
+        the chip and the upload, eight times slower on 32 CUs, is still what the next scan waits for."""
+        if partition is None:
+            partition = os.environ.get("NDT_PYRAMID_PARTITION", "0") != "0"
+        self.partition = bool(partition)
         self.resolutions = tuple(levels)
         self.levels = []
         for r in self.resolutions:
             g = ndt.NormalDistributionsTransform(device=device)
+            if self.partition:
+                g.setCuPartition(1)
             g.setResolution(r)
             g.setNeighborhoodSearchMethod(ndt.DIRECT7)
             g.setTransformationEpsilon(trans_eps)
@@ -45,6 +54,9 @@ class Pyramid:
             g.setStepSize(step_size)
             self.levels.append(g)
         self.donors = [ndt.NormalDistributionsTransform(device=device) for _ in range(2)]
+        if self.partition:
+            for d in self.donors:
+                d.setCuPartition(2)
 
     def setInputTarget(self, target, is_dense=True):
         for g in self.levels:
