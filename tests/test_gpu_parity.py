@@ -206,6 +206,55 @@ def test_clouds_by_reference_equal_copied_clouds(mods, n, dense):
             gr.setInputTargetDeviceRef(d_t + 4, max(1, n - 1), is_dense=bool(dense))
 
 
+def test_record_compaction_is_deferred_and_changes_nothing(mods):
+    """A target of more than 65 536 points keeps k1_finalize's record numbering until the grid is registered against a second
+    time (or a lock-step batch starts): the compaction then moves records and rewrites the look-up table in place -- the
+    evaluation sums, registrations, grid dump and the other paths' answers must be the same bits before and after, and a
+    grid shared with a clone is left alone."""
+    ndt, po, clouds = mods
+    tgt = clouds.target_surfaces(150000, extent=50.0, n_boxes=20)
+    src = clouds.source_from_target(tgt, 30000)
+    p = np.array([0.25, -0.15, 0.08, 0.008, -0.004, 0.015])
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    e0 = g.eval(p, True)          # records as built
+    h0 = g.hessian_f64(p)
+    g.align()                     # first registration: still as built
+    T1 = g.getFinalTransformation()
+    e1 = g.eval(p, True)
+    g.align()                     # second registration: compacted first
+    T2 = g.getFinalTransformation()
+    e2 = g.eval(p, True)
+    for a, b in ((e0, e1), (e0, e2)):
+        assert a[0] == b[0] and a[3] == b[3] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(T1, T2) and np.array_equal(h0, g.hessian_f64(p))
+    g.setEvaluationPath(0)
+    g.align()
+    assert np.array_equal(T1, g.getFinalTransformation())
+    g.setEvaluationPath(1)
+    o = po.OracleNDT(resolution=1.0, num_threads=16)
+    o.set_target(tgt)
+    a, b = g.grid(), o.grid()     # the leaf arrays quote the records' new numbers
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["n"], b["n"]) and np.array_equal(a["mean"], b["mean"])
+    g.align()
+    assert np.array_equal(T1, g.getFinalTransformation())
+    assert g.calculateScore(src) == pytest.approx(o.calculate_score(src), rel=1e-11)
+    # a batch compacts at once; a clone taken before the second registration keeps the grid as built -- same answers
+    gb = ndt.NormalDistributionsTransform()
+    gb.setInputTarget(tgt)
+    res = gb.alignBatch([src, src[:20000]])
+    assert np.array_equal(res["T"][0], T1)
+    gc = ndt.NormalDistributionsTransform()
+    gc.setInputTarget(tgt)
+    gc.setInputSource(src)
+    gc.align()
+    clone = gc.copy()
+    gc.align()
+    clone.align()
+    assert np.array_equal(gc.getFinalTransformation(), T1) and np.array_equal(clone.getFinalTransformation(), T1)
+
+
 def test_cu_partitions_and_shared_targets(mods, pair):
     """ndt_set_cu_partition / ndt_share_input_target: a handle that prepares the inputs on the side partition of the CUs, a
     handle that registers on the registration partition with the inputs taken over (no copy, no rebuild) -- the pipelined

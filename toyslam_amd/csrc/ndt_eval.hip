@@ -363,6 +363,8 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   ndt_status s = check_ready(h);
   if (s) return s;
+  s = maybe_compact_records(h, false);  // a grid that is registered against a second time gets dense, cell-ordered records
+  if (s) return s;
   ndt::ScanSolver solver;
   size_t n_total = h->source->n;
   if (h->comm) {  // point-sharded scan: transformation_probability = score / N over ALL shards

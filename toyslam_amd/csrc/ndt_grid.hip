@@ -384,6 +384,8 @@ ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, si
   return NDT_OK;
 }
 
+static ndt_status compact_records_now(ndt_context* h, DeviceGrid* g);
+
 // VoxelGridCovariance::filter(true) on the GPU.
 ndt_status build_grid(ndt_context* h) {
   if (!h->target) return fail(NDT_ERR_NO_INPUT, "no target");
@@ -486,14 +488,6 @@ ndt_status build_grid(ndt_context* h) {
     const size_t rec_slots = static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1;  // slot = segment start / min_pts
     HIP_TRY(g->recs.reserve(rec_slots));
     HIP_TRY(g->centroids.reserve(rec_slots));
-    DevBuf<ndt::VoxelRec> recs_by_slot;  // as k1_finalize numbers them (gaps, bucket by bucket); compacted into g->recs below
-    DevBuf<ndt::VoxelSide> centroids_by_slot;
-    DevBuf<unsigned> tile_sums;
-    if (n > 65536) {
-      HIP_TRY(recs_by_slot.reserve(rec_slots));
-      HIP_TRY(centroids_by_slot.reserve(rec_slots));
-      HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(geo.lut_cells) + 1));
-    }
     DevBuf<unsigned> blockbase, order;
     // the handle's bucket counters: zero between builds (k1_finalize clears what k1_hist counted); cleared here only when
     // they are new or a build was cut short
@@ -513,19 +507,23 @@ ndt_status build_grid(ndt_context* h) {
     S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
     S.order = order.p;
-    // Records dense and in ascending cell order (launch_compact_records: two small launches, ~13 us) pay for themselves as
+    // Records dense and in ascending cell order (maybe_compact_records: two small launches, ~13 us) pay for themselves as
     // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
-    // The mapping nodes' clouds (16 k points, one registration of ~6 evaluations per target, records that fit L2 many
-    // times over) keep k1_finalize's own numbering.
-    const bool compact = n > 65536;
+    // A mapping node registers ONE scan against every target it builds (ndt_omp_mapping_node.cpp:151-169), so the build
+    // itself leaves k1_finalize's numbering and the compaction runs when the grid is seen to be reused: before the second
+    // registration against it, or before the first lock-step batch (NDT_K1_COMPACT=eager: at once, as round 2 did; off: never).
+    // The mapping nodes' 16 k-point clouds (records that fit L2 many times over) never compact.
+    static const int compact_mode = [] { const char* v = getenv("NDT_K1_COMPACT"); return !v ? 1 : std::strcmp(v, "eager") == 0 ? 2 : std::strcmp(v, "off") == 0 ? 0 : 1; }();
     HIP_TRY(ndt::launch_grid_build_buckets(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
-                                           compact ? recs_by_slot.p : g->recs.p, compact ? centroids_by_slot.p : g->centroids.p, g->lut.p,
-                                           g->counts.p, st));
-    if (compact)
-      HIP_TRY(ndt::launch_compact_records(g->lut.p, geo.lut_cells, recs_by_slot.p, centroids_by_slot.p, g->recs.p, g->centroids.p, tile_sums.p, st));
+                                           g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
+    g->compact_pending = n > 65536 && compact_mode != 0;
     h->k1_bucket_count_clean = true;
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
+    if (compact_mode == 2 && g->compact_pending) {
+      ndt_status cs = compact_records_now(h, g.get());
+      if (cs) return cs;
+    }
   } else {
   // every cell of the padded table starts out empty (kLutEmpty = -1 = all bits set); the finalize pass fills in the
   // voxels that reached min_points_per_voxel
@@ -568,6 +566,35 @@ ndt_status build_grid(ndt_context* h) {
   g->empty = false;
   h->grid = g;
   return NDT_OK;
+}
+
+// Records of a bucket-form build -> dense, ascending cell order (launch_compact_records), in place: only while this handle is
+// the grid's single holder (a clone may be evaluating on it) and before anybody has asked for the leaf arrays (they quote
+// record numbers).  eager: now; otherwise from the second registration against the grid on.
+static ndt_status compact_records_now(ndt_context* h, DeviceGrid* g) {
+  g->compact_pending = false;
+  if (!g->leaves_pending || g->empty) return NDT_OK;
+  const size_t rec_slots = g->recs.cap;
+  DevBuf<ndt::VoxelRec> recs_new;
+  DevBuf<ndt::VoxelSide> cent_new;
+  DevBuf<unsigned> tile_sums;
+  HIP_TRY(recs_new.reserve(rec_slots));
+  HIP_TRY(cent_new.reserve(rec_slots));
+  HIP_TRY(tile_sums.reserve(ndt::record_compaction_tiles(g->geom.lut_cells) + 1));
+  HIP_TRY(ndt::launch_compact_records(g->lut.p, g->geom.lut_cells, g->recs.p, g->centroids.p, recs_new.p, cent_new.p, tile_sums.p, h->stream));
+  g->recs.swap(recs_new);  // (the old arrays go back to the pool at scope exit: reused only behind these launches, stream order)
+  g->centroids.swap(cent_new);
+  return NDT_OK;
+}
+ndt_status maybe_compact_records(ndt_context* h, bool eager) {
+  DeviceGrid* g = h->grid.get();
+  if (!g || !g->compact_pending) return NDT_OK;
+  if (!eager && g->n_registrations++ == 0) return NDT_OK;
+  if (h->grid.use_count() != 1) {  // shared with a clone: leave it alone for good
+    g->compact_pending = false;
+    return NDT_OK;
+  }
+  return compact_records_now(h, g);
 }
 
 // occupied / candidate / valid voxel counts of a built grid (fetched from the device on first use)

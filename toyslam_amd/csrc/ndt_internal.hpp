@@ -166,6 +166,11 @@ struct DevBuf {
     cap = n;
     cls_bytes = 0;
   }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(cap, o.cap);
+    std::swap(cls_bytes, o.cls_bytes);
+  }
   hipError_t reserve(size_t n) {
     if (n <= cap && p && cls_bytes) return hipSuccess;
     release();
@@ -219,6 +224,10 @@ struct DeviceGrid {
   DevBuf<float4> cell_pts;  // the target points in cell order (ndt_search.hpp scans them)
   DevBuf<int> row_any;      // per x-row of cells: occupied or not
   bool have_cell2leaf = false;
+  // bucket-form build: records still numbered the way k1_finalize numbers them (slot = segment start / min_pts: gaps,
+  // bucket by bucket); maybe_compact_records makes them dense and cell-ordered once the grid is seen to be reused
+  bool compact_pending = false;
+  int n_registrations = 0;
   // bucket-form build (ndt_kernels.hip): kept until the leaf arrays have been written (grid_counts)
   bool leaves_pending = false;
   ndt::GridBuildPlan plan{};
@@ -391,6 +400,7 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
 ndt_status order_batch(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans);
 ndt_status order_cloud(ndt_context* h, DeviceCloud* c, const size_t* offsets, size_t n_scans);
 ndt_status build_grid(ndt_context* h);
+ndt_status maybe_compact_records(ndt_context* h, bool eager);
 ndt_status grid_counts(ndt_context* h, DeviceGrid* g);
 ndt_status ensure_cell2leaf(ndt_context* h, DeviceGrid* g);
 float index_slack(const DeviceGrid* g);
