@@ -507,6 +507,13 @@ ndt_status build_grid(ndt_context* h) {
     S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
     S.order = order.p;
+    static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
+    DevBuf<unsigned long long> stamps;
+    if (want_stamps) {
+      HIP_TRY(stamps.reserve(8 * K));
+      HIP_TRY(hipMemsetAsync(stamps.p, 0, 8 * K * sizeof(unsigned long long), st));
+      S.stamps = stamps.p;
+    }
     // Records dense and in ascending cell order (maybe_compact_records: two small launches, ~13 us) pay for themselves as
     // soon as a few scans are registered against the grid: +8 % on lock-step batches, +1-5 % on a single 100k-point scan.
     // A mapping node registers ONE scan against every target it builds (ndt_omp_mapping_node.cpp:151-169), so the build
@@ -517,6 +524,22 @@ ndt_status build_grid(ndt_context* h) {
     HIP_TRY(ndt::launch_grid_build_buckets(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
                                            g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
     g->compact_pending = n > 65536 && compact_mode != 0;
+    if (want_stamps) {  // k1_finalize's phase clocks: per phase the median and the maximum over the buckets (shader cycles)
+      std::vector<unsigned long long> hst(8 * K);
+      HIP_TRY(hipMemcpyAsync(hst.data(), stamps.p, 8 * K * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      static const char* names[8] = {"hist+scan", "select", "rank-sort", "teams", "sums+finish", "passes", "points", "total"};
+      std::fprintf(stderr, "[k1_finalize clocks, %zu buckets] ", K);
+      for (int q = 0; q < 8; q++) {
+        std::vector<unsigned long long> d;
+        for (size_t b = 0; b < K; b++)
+          if (hst[8 * b + 7]) d.push_back(hst[8 * b + q]);
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        std::fprintf(stderr, "%s %llu/%llu  ", names[q], d[d.size() / 2], d.back());
+      }
+      std::fprintf(stderr, "\n");
+    }
     h->k1_bucket_count_clean = true;
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)

@@ -1061,10 +1061,23 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                                       VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                       unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
                                                       unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
-                                                      unsigned* __restrict__ bucket_count) {
+                                                      unsigned* __restrict__ bucket_count,
+                                                      unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
+  // phase clocks of thread 0 (NDT_K1_STAMPS): cycles spent in 0 histogram + scan, 1 select, 2 rank sort, 3 lane teams,
+  // 4 sums + finish_voxel; 5 = passes, 6 = points, 7 = total
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_mark = 0, t_begin = 0;
+  unsigned n_passes = 0;
+  if (st && threadIdx.x == 0) t_mark = t_begin = stamp();
+  auto lap = [&](int phase) {
+    if (st && threadIdx.x == 0) {
+      const unsigned long long t = stamp();
+      ph[phase] += t - t_mark;
+      t_mark = t;
+    }
+  };
   __shared__ int s_nteam;                     // team cells of the current pass ...
   __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells ...
   __shared__ double s_team64[kMaxTeamCells][9];  // ... and their sums (sx sy sz cxx cxy cxz cyy cyz czz)
@@ -1092,6 +1105,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   float* oz = oy + lds_cap;
   k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
   k1_scan_cells(cnt, cstart, C, s_u3);
+  lap(0);
   const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
   // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
@@ -1159,6 +1173,8 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     }
     if (giant) __threadfence_block();
     __syncthreads();
+    n_passes++;
+    lap(1);
     if (!giant) {
       // rank sort inside every cell's segment, one thread per point: a point's rank is the number of points of its
       // cell with a smaller point index (indices are unique).  The sorted copy goes back IN PLACE: every thread
@@ -1233,6 +1249,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       __syncthreads();
       continue;
     }
+    lap(2);
     // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
     if (threadIdx.x == 0) s_nteam = 0;
     __syncthreads();
@@ -1283,6 +1300,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       }
     }
     __syncthreads();
+    lap(3);
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
       const int n_c = static_cast<int>(cnt[c]);
       if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
@@ -1312,6 +1330,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     }
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
+    lap(4);
+  }
+  if (st && threadIdx.x == 0) {
+    for (int q = 0; q < 5; q++) st[8 * k + q] = ph[q];
+    st[8 * k + 5] = n_passes;
+    st[8 * k + 6] = nb;
+    st[8 * k + 7] = stamp() - t_begin;
   }
   {  // the bucket's valid voxels -> its own word; k1_count adds the words up when somebody asks (grid_counts).  One atomic
      // per WAVE on a single counter was 8 of this kernel's 41 us at 1 M points: same-address atomics serialise at the
@@ -1634,7 +1659,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
                      S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut,
-                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.bucket_count);
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.bucket_count, S.stamps);
   return hipGetLastError();
 }
 

@@ -149,6 +149,7 @@ struct GridBuildScratch {
   unsigned* blockbase;     // [n_blocks x n_buckets]
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
   unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
+  unsigned long long* stamps;  // development aid (NDT_K1_STAMPS): [n_buckets x 8] phase clocks of k1_finalize, or null
 };
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
