@@ -14,10 +14,10 @@ for name, n, ext, res in cases:
     g = ndt.NormalDistributionsTransform(); g.setResolution(res)
     ts = []
     for i in range(8):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); g.setInputTargetDevice(dev.data_ptr(), n, 16); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); g.setInputTargetDeviceRef(dev.data_ptr(), n); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(6):
-        g.setInputTargetDevice(dev.data_ptr(), n, 16)
+        g.setInputTargetDeviceRef(dev.data_ptr(), n)
     torch.cuda.synchronize(); pipelined = (time.perf_counter() - t0) / 6
     ijk = np.floor(tgt / res).astype(np.int64); key = (ijk[:, 0] * 100003 + ijk[:, 1]) * 100003 + ijk[:, 2]
     _, c = np.unique(key, return_counts=True)

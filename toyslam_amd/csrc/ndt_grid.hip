@@ -488,23 +488,14 @@ ndt_status build_grid(ndt_context* h) {
     const size_t rec_slots = static_cast<size_t>(n) / static_cast<size_t>(std::max(1, h->min_pts)) + 1;  // slot = segment start / min_pts
     HIP_TRY(g->recs.reserve(rec_slots));
     HIP_TRY(g->centroids.reserve(rec_slots));
-    DevBuf<unsigned> blockbase, order;
-    // the handle's bucket counters: zero between builds (k1_finalize clears what k1_hist counted); cleared here only when
-    // they are new or a build was cut short
-    if (!h->k1_bucket_count.p) {
-      HIP_TRY(h->k1_bucket_count.reserve(ndt::kK1MaxBuckets));
-      h->k1_bucket_count_clean = false;
-    }
-    if (!h->k1_bucket_count_clean) HIP_TRY(hipMemsetAsync(h->k1_bucket_count.p, 0, ndt::kK1MaxBuckets * sizeof(unsigned), st));
-    h->k1_bucket_count_clean = false;  // until every launch of this build is queued
+    DevBuf<unsigned> cntmat, order;
     HIP_TRY(g->bucket_base.reserve(2 * K + 1));  // [K + 1] bucket bases, [K] valid voxels per bucket (k1_finalize -> k1_count)
-    HIP_TRY(blockbase.reserve(static_cast<size_t>(plan.n_blocks) * K));
+    HIP_TRY(cntmat.reserve((static_cast<size_t>(plan.n_blocks) + 1) * K));
     HIP_TRY(order.reserve(5 * static_cast<size_t>(n)));
     HIP_TRY(g->bpts.reserve(n));
     ndt::GridBuildScratch S{};
-    S.bucket_count = h->k1_bucket_count.p;
+    S.cntmat = cntmat.p;
     S.bucket_base = g->bucket_base.p;
-    S.blockbase = blockbase.p;
     S.bpts = g->bpts.p;
     S.order = order.p;
     static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
@@ -540,7 +531,6 @@ ndt_status build_grid(ndt_context* h) {
       }
       std::fprintf(stderr, "\n");
     }
-    h->k1_bucket_count_clean = true;
     g->plan = plan;
     g->leaves_pending = true;  // leaf arrays and the occupied / candidate counts: on demand (grid_counts)
     if (compact_mode == 2 && g->compact_pending) {

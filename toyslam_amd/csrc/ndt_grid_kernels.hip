@@ -4,8 +4,8 @@
 //    general chain:  bbox -> per-cell count -> 3-phase exclusive scan over cells (leaf ordinals, segment offsets, record
 //                    ordinals, LUT init) -> counting-sort scatter of point indices -> k_presort_large (crowded voxels) ->
 //                    k_finalize
-//    bucket form:    k1_hist -> k1_scatter -> k1_finalize (3 launches, LDS histograms, no per-point global
-//                    atomics; crowded cells summed by lane teams), k1_count / k1_leaves on demand
+//    bucket form:    k1_hist -> k1_colscan -> k1_scatter -> k1_finalize (order-preserving: no global atomics, no sort by
+//                    point index; crowded cells summed by lane teams), k1_count / k1_leaves on demand
 //    (the sort-based sparse form is ndt_sparse.hip; all three end in finish_voxel: index-ordered f64 sums -- bit-identical
 //    to the reference's sequential accumulation --, mean, covariance with the reference's quirks, 3x3 symmetric
 //    eigen-solve, eigenvalue inflation, inverse, validity -> 64-B VoxelRec)
@@ -798,16 +798,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
 // its points at random from the whole cloud (64-B sectors for 16-B points).  Here the voxel index space is dealt out to
 // K buckets of C cells each (short runs of consecutive cells, round-robin: k1_bucket below) and everything per-voxel is
 // staged through LDS:
-//   k1_hist     per block of points: LDS histogram over the buckets, ONE returning global atomic per (block, bucket)
-//               claims the block's run inside the bucket; the last block to finish scans the bucket totals
-//   k1_scatter  the same blocks move their points (x, y, z, point index) to their runs: bucket-contiguous copy
-//   k1_count    one block per bucket: LDS per-cell counters -> occupied / candidate cells of the bucket; the last
-//               block scans those totals (leaf ordinals: bucket by bucket, ascending local cell inside a bucket)
-//   k1_finalize one block per bucket: LDS counting sort of the bucket's points by cell, rank sort by point index inside
-//               every cell (one thread per point; any cell size), then one thread per cell: sums in ascending point
-//               order (bit-identical to the reference's sequential pass), second pass of applyFilter -> record,
-//               centroid, look-up table slot, leaf arrays, sorted_idx
-// Points are read three times and written once, contiguously; no per-point global atomic.
+//   k1_hist     per block of points: LDS histogram over the buckets -> the block's row of the count matrix [blocks][K]
+//   k1_colscan  the matrix column by column: exclusive prefix down the rows (a block's base inside every bucket), bucket sizes
+//   k1_scatter  the same blocks move their points (x, y, z, point index) to their buckets ORDER-PRESERVING: block after
+//               block, and inside a block by stable ranks (wave_rank) -- a bucket holds its points in ascending point index
+//   k1_finalize one block per bucket: per-cell counts in LDS, then a STABLE placement of the points into their cells' LDS
+//               segments (the same ranking) -- every cell's points in ascending point index, the order the reference adds
+//               them in, with no sort (round 2 sorted every cell by point index: quadratic in a cell's points, half of the
+//               kernel on crowded scenes) -- then one thread per cell (a lane team for crowded cells): sums, second pass
+//               of applyFilter -> record, centroid, look-up table slot, sorted_idx
+//   k1_count / k1_leaves  on demand: occupied / candidate counts, leaf arrays
+// Points are read three times and written once, contiguously; no global atomic at all.
 // ---------------------------------------------------------------------------
 // Cell <-> (bucket, local cell).  Buckets are NOT ranges of the linear cell index: a clustered scene (a ground plane) would
 // fill a few of those with many times the mean and leave the rest empty.  Runs of 2^rb consecutive cells (neighbours in x,
@@ -824,7 +825,9 @@ __device__ __forceinline__ int k1_cell(int bucket, int local, int map) {
   return ((((local >> rb) << kb) | bucket) << rb) | (local & ((1 << rb) - 1));
 }
 
-constexpr int kK1Threads = 512;   // k1_hist / k1_scatter
+constexpr int kK1Threads = 256;              // k1_hist / k1_scatter
+constexpr int kK1Waves = kK1Threads / kWave;  // 4
+constexpr int kK1Round = 8 * kK1Threads;     // points one block of k1_scatter ranks per round (eight 64-point chunks per wave)
 
 __device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int dense) {
   int c = -1;
@@ -835,7 +838,7 @@ __device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int de
   return c;
 }
 
-// exclusive scan of n (<= 16 * nthreads) u32 values src[] -> dst[] by one block; dst[n] = total.  lds: nthreads / 64 words
+// exclusive scan of n (<= 32 * nthreads) u32 values src[] -> dst[] by one block; dst[n] = total.  lds: nthreads / 64 words
 __device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n, int nthreads,
                                                  unsigned* lds, bool agent_loads) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -866,13 +869,48 @@ __device__ __forceinline__ void block_scan_array(const unsigned* __restrict__ sr
   if (tid == 0) dst[n] = total;
 }
 
+// Stable rank of a lane's key among the lanes of its wave that hold the same key, plus the wave's running count of that
+// key.  The lanes with equal keys find each other through LDS: every lane ORs its lane bit into the 64-bit mask of slot
+// (key mod 256) of the wave's private mask table and reads the mask back -- one DS atomic and one DS read where a ballot
+// per key bit (with its select) costs eight to thirteen times that; key bits above the eighth, if any, are settled with
+// ballots.  The lowest lane of a slot clears it again, so the table is all zero between calls.  The lowest lane of a group
+// of equal keys (the leader) bumps the wave's counter row by their number; everybody has read the old value in the same
+// instruction.  Returns old count + number of equal-key lanes below this one: the position of the lane's element among
+// ALL elements of that key the wave has ranked so far, in the order the wave met them.  `row`: this wave's counters (u16,
+// one per key); `mtab`: this wave's kMatchSlots masks.  DS operations of one wave execute in order, so a later call sees
+// this call's counter update and the cleared slot.
+constexpr int kMatchSlots = 256;
+__device__ __forceinline__ unsigned wave_rank(int key, bool valid, unsigned long long* mtab, unsigned short* row, int bits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned long long* slot = mtab + (key & (kMatchSlots - 1));
+  if (valid) (void)__hip_atomic_fetch_or(slot, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned long long slotmask = valid ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+  const unsigned old = valid ? row[key] : 0u;
+  unsigned long long peers = slotmask;
+#pragma unroll
+  for (int b = 8; b < 14; b++) {
+    if (b < bits) {  // (uniform)
+      const bool bit = ((key >> b) & 1) != 0;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+  }
+  const unsigned first_of_slot = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(slotmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(slotmask), 0u));
+  if (valid && first_of_slot == 0) __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(peers >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(peers), 0u));
+  if (valid && below == 0) row[key] = static_cast<unsigned short>(old + static_cast<unsigned>(__popcll(peers)));
+  return old + below;
+}
+
+// rows = blocks of points, columns = buckets: the block's row of bucket counts (plain stores: round 2 claimed a run per
+// (block, bucket) with a returning global atomic -- 250 k of them at 1 M points, 11 us of memory-side atomics, and runs in
+// the order the blocks happened to arrive); the look-up table is cleared on the side (nothing reads it before k1_finalize)
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                      int ppb, unsigned* __restrict__ bucket_count, unsigned* __restrict__ blockbase,
-                                                      int* __restrict__ lut, long long lut_cells) {
+                                                      int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells) {
   extern __shared__ unsigned k1_lds[];
   unsigned* h = k1_lds;
   for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
-  {  // the padded look-up table starts out empty: every block clears its slice (nothing reads the table before k1_finalize)
+  {  // the padded look-up table starts out empty: every block clears its slice
     const long long n4 = lut_cells / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
     const long long lo4 = static_cast<long long>(blockIdx.x) * per, hi4 = min(n4, lo4 + per);
     int4* l4 = reinterpret_cast<int4*>(lut);
@@ -896,47 +934,121 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kK1Threads) {
-    const unsigned v = h[k];
-    // the block's run inside bucket k starts where the bucket's counter stood (arrival order of the blocks: any)
-    blockbase[static_cast<size_t>(blockIdx.x) * K + k] = v ? __hip_atomic_fetch_add(bucket_count + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  }
-  // (no ticket, no last-block scan of the bucket counters: every block of k1_scatter scans the K counters itself --
-  // 245 returning atomics on one ticket word queued ~4 us behind each other at the end of this kernel)
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cntmat[static_cast<size_t>(blockIdx.x) * K + k] = h[k];
 }
 
+// The count matrix, column by column: cntmat[b][k] <- points of bucket k in the blocks BEFORE b (exclusive prefix down the
+// rows, in place), total[k] <- the bucket's size.  A block takes 16 columns; its 256 threads are 16 row groups x 16 columns,
+// a thread keeps its rows (at most kColRows) in registers between the two sweeps.
+constexpr int kColCols = 16, kColGroups = kK1Threads / kColCols, kColRows = 32;  // B <= kColGroups * kColRows = 512 rows
+__global__ __launch_bounds__(kK1Threads) void k1_colscan(unsigned* __restrict__ cntmat, int B, int K, unsigned* __restrict__ total) {
+  __shared__ unsigned s_part[kColGroups][kColCols + 1];
+  const int c = threadIdx.x % kColCols, rg = threadIdx.x / kColCols;
+  const int col = blockIdx.x * kColCols + c;
+  const int R = (B + kColGroups - 1) / kColGroups;  // rows per group, <= kColRows
+  const int r0 = rg * R;
+  unsigned v[kColRows];
+  unsigned sum = 0;
+#pragma unroll
+  for (int i = 0; i < kColRows; i++) {
+    const int r = r0 + i;
+    v[i] = (i < R && r < B && col < K) ? cntmat[static_cast<size_t>(r) * K + col] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < kColRows; i++) sum += v[i];
+  s_part[rg][c] = sum;
+  __syncthreads();
+  unsigned base = 0, all = 0;
+  for (int gq = 0; gq < kColGroups; gq++) {
+    const unsigned t = s_part[gq][c];
+    if (gq < rg) base += t;
+    all += t;
+  }
+#pragma unroll
+  for (int i = 0; i < kColRows; i++) {
+    const int r = r0 + i;
+    if (i < R && r < B && col < K) cntmat[static_cast<size_t>(r) * K + col] = base;
+    base += v[i];
+  }
+  if (rg == 0 && col < K) total[col] = all;
+}
+
+// The same blocks move their points to their buckets, ORDER-PRESERVING: bucket k receives the points of block 0, block 1,
+// ... (the column prefixes above), each block's in ascending point index (ranks inside a 64-point chunk from wave_rank, the
+// waves' running counts in LDS) -- so every bucket, and after k1_finalize's stable placement every CELL, holds its points
+// in ascending point index, the order the reference adds them in (_impl.hpp:233-244), and nothing has to be sorted.
+// LDS (dynamic): cursor u32 [K + 1] | tot u16 [K] | tab u16 [kK1Waves][K]; static: the mask tables of wave_rank
 __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                         int ppb, const unsigned* __restrict__ bucket_count, unsigned* __restrict__ bucket_base,
-                                                         const unsigned* __restrict__ blockbase, float4* __restrict__ bpts,
+                                                         int ppb, const unsigned* __restrict__ cntmat, const unsigned* __restrict__ total,
+                                                         unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
                                                          unsigned* __restrict__ counts) {
-  extern __shared__ unsigned k1_lds[];  // K + 1 words
-  __shared__ unsigned s_scan[kK1Threads / kWave];
-  unsigned* cursor = k1_lds;
-  // bucket bases = exclusive scan of the K bucket counters, by every block for itself (1 us); block 0 keeps them for
-  // k1_finalize and the leaf pass
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] = bucket_count[k];
+  extern __shared__ unsigned k1_lds[];
+  __shared__ unsigned s_scan[kK1Waves];
+  __shared__ unsigned long long s_mtab[kK1Waves * kMatchSlots];  // (static: 8-byte aligned whatever precedes the dynamic part)
+  unsigned long long* mtab_all = s_mtab;
+  unsigned* cursor = k1_lds;                                                         // [K + 1] (+ 1 pad word)
+  unsigned short* tot = reinterpret_cast<unsigned short*>(cursor + K + 2);           // [K]
+  unsigned short* tab = tot + K;                                                     // [kK1Waves][K]
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int b = blockIdx.x;
+  const int kbits = map >> 8;
+  for (int i = threadIdx.x; i < kK1Waves * kMatchSlots; i += kK1Threads) mtab_all[i] = 0ull;
+  for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
+  // bucket bases = exclusive scan of the bucket sizes, by every block for itself; block 0 keeps them for k1_finalize
+  block_scan_array(total, cursor, K, kK1Threads, s_scan, false);
   __syncthreads();
-  block_scan_array(cursor, cursor, K, kK1Threads, s_scan, false);
-  __syncthreads();
-  if (blockIdx.x == 0) {
+  if (b == 0) {
     for (int k = threadIdx.x; k <= K; k += kK1Threads) bucket_base[k] = cursor[k];
     if (threadIdx.x == 0) counts[0] = cursor[K];  // points binned
   }
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += blockbase[static_cast<size_t>(blockIdx.x) * K + k];
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += cntmat[static_cast<size_t>(b) * K + k];
   __syncthreads();
-  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
-  for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {
+  // ---- stable split: rounds of 2048 points; wave w ranks the eight 64-point chunks [w * 512, (w + 1) * 512) of the round
+  const int lo = b * ppb, hi = min(n, lo + ppb);
+  unsigned short* row = tab + wave * K;
+  unsigned long long* mtab = mtab_all + wave * kMatchSlots;
+  for (int r0 = lo; r0 < hi; r0 += kK1Round) {
     float4 p[8];
+    int key[8];
+    unsigned rk[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
+      const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
       p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
+      const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
       const int c = (i < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) bpts[atomicAdd(&cursor[k1_bucket(c, map)], 1u)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
+      key[u] = (c >= 0) ? k1_bucket(c, map) : -1;
+      rk[u] = 0;
+      if (r0 + wave * (8 * kWave) + u * kWave < hi) rk[u] = wave_rank(key[u], key[u] >= 0, mtab, row, kbits);  // (uniform: the chunk has points)
+    }
+    __syncthreads();
+    // per bucket: the waves' counts -> exclusive prefix over the waves (in place), the round's total -> the cursor afterwards
+    for (int k = threadIdx.x; k < K; k += kK1Threads) {
+      unsigned s_ = 0;
+#pragma unroll
+      for (int w = 0; w < kK1Waves; w++) {
+        const unsigned t = tab[w * K + k];
+        tab[w * K + k] = static_cast<unsigned short>(s_);
+        s_ += t;
+      }
+      tot[k] = static_cast<unsigned short>(s_);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (key[u] >= 0) {
+        const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
+        bpts[cursor[key[u]] + row[key[u]] + rk[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
+      }
+    }
+    __syncthreads();
+    if (r0 + kK1Round < hi) {  // (uniform) another round: advance the cursors, clear the counters
+      for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += tot[k];
+      for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
+      __syncthreads();
     }
   }
 }
@@ -1047,21 +1159,21 @@ __device__ __forceinline__ void k1_scan_cells(const unsigned* cnt, unsigned* cen
 }
 
 constexpr int kK1PerThread = 8;                   // points per thread of one LDS pass
-constexpr int kK1LdsCap = kK1PerThread * kBlock;  // 2048: points one LDS pass can hold
+constexpr int kK1LdsCap = 2 * kK1PerThread * kBlock;  // 4096: points one LDS pass can hold (two rounds of the stable placement)
 // Cells with more points than this are summed by a TEAM of 16 lanes, one accumulator per lane: the nine f64 sums and the
 // three f32 centroid sums of a voxel are twelve independent chains of strictly ordered additions (the reference's order,
 // _impl.hpp:233-244) -- one thread walking a 400-point voxel of a real scan issues 15 f64 instructions per point by
 // itself (~20 us per voxel), a lane per chain issues two.
 constexpr int kTeamCell = 32, kTeamLanes = 16;
+constexpr size_t kK1MaxDynamicLds = 136 * 1024;  // of the CU's 160 KB (the kernels also hold up to ~20 KB of static LDS)
 constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
 __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
-                                                      double eig_ratio, int lds_cap, const unsigned* __restrict__ bucket_base,
-                                                      int* __restrict__ sorted_idx,
+                                                      double eig_ratio, int lds_cap, int wmax /* cells one pass may span (power of two <= C) */,
+                                                      const unsigned* __restrict__ bucket_base, int* __restrict__ sorted_idx,
                                                       VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                       unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
                                                       unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
-                                                      unsigned* __restrict__ bucket_count,
                                                       unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
   extern __shared__ unsigned k1_lds[];
   __shared__ U3 s_u3[kBlock / kWave];
@@ -1084,9 +1196,6 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
   __shared__ float s_one;
   const int k = blockIdx.x;
-  // the handle's bucket counters are zero between builds: k1_hist counted into them, k1_scatter has read them, this block
-  // clears its own -- instead of a clearing launch in front of every build
-  if (threadIdx.x == 0) bucket_count[k] = 0u;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) {  // empty bucket (uniform)
     if (threadIdx.x == 0) bucket_valid[k] = 0u;
@@ -1096,13 +1205,19 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   if (threadIdx.x == 0) s_one = 1.0f;
   unsigned* cnt = k1_lds;          // [C] points per cell
   unsigned* cstart = k1_lds + C;   // [C] start of the cell's segment inside the bucket (exclusive prefix of cnt)
-  unsigned* cur = k1_lds + 2 * C;  // [C] scatter cursors of the current pass
-  // per point of the current pass, in cell order (slot q) and then, in place, in (cell, point index) order:
-  unsigned* oidx = k1_lds + 3 * C;  // point index
-  unsigned* ocell = oidx + lds_cap;
-  float* ox = reinterpret_cast<float*>(ocell + lds_cap);
+  unsigned* cur = k1_lds + 2 * C;  // [C] of the current pass: points already placed in the cell's segment
+  // the points of the current pass in (cell, point index) order
+  float* ox = reinterpret_cast<float*>(k1_lds + 3 * C);
   float* oy = ox + lds_cap;
   float* oz = oy + lds_cap;
+  __shared__ unsigned long long s_mtab[(kBlock / kWave) * kMatchSlots];  // wave_rank's mask tables (static: 8-byte aligned whatever precedes the dynamic part)
+  unsigned long long* mtab_all = s_mtab;
+  unsigned short* tab = reinterpret_cast<unsigned short*>(oz + lds_cap);  // [4 waves + totals][wmax], indexed by cell - c_lo
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  int wbits = 0;
+  while ((1 << wbits) < wmax) wbits++;
+  for (int i = threadIdx.x; i < (kBlock / kWave) * kMatchSlots; i += kBlock) mtab_all[i] = 0ull;
+  for (int i = threadIdx.x; i < (kBlock / kWave + 1) * wmax / 2; i += kBlock) reinterpret_cast<unsigned*>(tab)[i] = 0u;
   k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
   k1_scan_cells(cnt, cstart, C, s_u3);
   lap(0);
@@ -1115,13 +1230,14 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   for (int c_lo = 0; c_lo < C;) {
     if (threadIdx.x == 0) {
       int c = c_lo;
-      if (nb <= static_cast<unsigned>(lds_cap)) {
+      if (nb <= static_cast<unsigned>(lds_cap) && C <= wmax) {
         c = C;
       } else {
-        // the last cell whose END stays within lds_cap points of c_lo's start: binary search in the prefix sums
+        // the last cell whose END stays within lds_cap points of c_lo's start (and within wmax cells: the counter rows of
+        // the stable placement are that wide): binary search in the prefix sums
         // (cstart[c] = points before cell c; a linear walk by one thread cost 30 us per pass at C = 4096)
         const unsigned limit = cstart[c_lo] + static_cast<unsigned>(lds_cap);
-        int lo = c_lo, hi = C;  // invariant: cells [c_lo, lo) fit; answer in [lo, hi]
+        int lo = c_lo, hi = min(C, c_lo + wmax);  // invariant: cells [c_lo, lo) fit; answer in [lo, hi]
         while (lo < hi) {
           const int mid = (lo + hi + 1) >> 1;  // candidate: cells [c_lo, mid) -- they end at cstart[mid] (mid < C) or nb
           const unsigned end = (mid < C) ? cstart[mid] : nb;
@@ -1143,92 +1259,82 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     }
     const bool giant = n_pass > static_cast<unsigned>(lds_cap);  // then c_hi == c_lo + 1
     // arrays of this pass: LDS, or (one cell too crowded for LDS) the bucket's slices of the global scratch
-    unsigned* pidx = giant ? scratch + bb + base : oidx;
     float* px = giant ? reinterpret_cast<float*>(scratch + n_total + bb + base) : ox;
     float* py = giant ? reinterpret_cast<float*>(scratch + 2 * static_cast<size_t>(n_total) + bb + base) : oy;
     float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
-    unsigned* pcell = giant ? nullptr : ocell;
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
     __syncthreads();
-    for (unsigned j0 = 0; j0 < nb; j0 += kK1PerThread * kBlock) {  // select this pass's points, eight loads in flight
-      float4 p[kK1PerThread];
+    // Select this pass's points, ORDER-PRESERVING.  The bucket holds its points in ascending point index (k1_scatter), and
+    // a point's slot inside its cell's segment is its stable rank: points of the cell placed by earlier rounds (cur) +
+    // points of the cell in the waves before mine this round (tab, after the column scan) + rank inside my wave
+    // (wave_rank).  Every cell's segment therefore ends up in ascending point index -- the order the reference adds the
+    // points in -- without the sort by index that round 2 spent a quarter (uniform cloud) to half (crowded cells: it is
+    // quadratic in a cell's points) of this kernel on.  Rounds of 2048 points; wave w takes the eight 64-point chunks
+    // [w * 512, (w + 1) * 512) of a round.
+    {
+      unsigned short* row = tab + wave * wmax;
+      unsigned long long* mtab = mtab_all + wave * kMatchSlots;
+      for (unsigned j0 = 0; j0 < nb; j0 += kK1PerThread * kBlock) {
+        // the round's points (at most 2048) in four equal, contiguous shares of whole chunks: wave w ranks chunks
+        // [w * per_wave, (w + 1) * per_wave) -- a bucket of 1000 points keeps all four waves busy, not the first two
+        const unsigned round_n = min(static_cast<unsigned>(kK1PerThread * kBlock), nb - j0);
+        const int per_wave = static_cast<int>(((round_n + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave));  // <= kK1PerThread
+        float4 p[kK1PerThread];
+        int cc[kK1PerThread];
+        unsigned rk[kK1PerThread];
 #pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned j = j0 + threadIdx.x + u * kBlock;
-        p[u] = (j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
-      }
+        for (int u = 0; u < kK1PerThread; u++) {
+          const unsigned j = j0 + static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
+          p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
+        }
 #pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned j = j0 + threadIdx.x + u * kBlock;
-        if (j >= nb) continue;
-        const int c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map);
-        if (c < c_lo || c >= c_hi) continue;
-        const unsigned q = atomicAdd(&cur[c], 1u);
-        pidx[q] = static_cast<unsigned>(__float_as_int(p[u].w));
-        if (pcell) pcell[q] = static_cast<unsigned>(c);
-        px[q] = p[u].x;
-        py[q] = p[u].y;
-        pz[q] = p[u].z;
+        for (int u = 0; u < kK1PerThread; u++) {
+          const unsigned j = j0 + static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
+          int c = -1;
+          if (u < per_wave && j < nb) {
+            c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map);
+            if (c < c_lo || c >= c_hi) c = -1;
+          }
+          cc[u] = c;
+          rk[u] = 0;
+          if (u < per_wave) rk[u] = wave_rank(c - c_lo, c >= 0, mtab, row, wbits);  // (uniform)
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // the waves' counts of a cell -> exclusive prefix over the waves, total
+          unsigned s_ = 0;
+#pragma unroll
+          for (int w = 0; w < kBlock / kWave; w++) {
+            const unsigned t = tab[w * wmax + c];
+            tab[w * wmax + c] = static_cast<unsigned short>(s_);
+            s_ += t;
+          }
+          tab[(kBlock / kWave) * wmax + c] = static_cast<unsigned short>(s_);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kK1PerThread; u++) {
+          if (cc[u] >= 0) {
+            const unsigned q = cur[cc[u]] + row[cc[u] - c_lo] + rk[u];
+            px[q] = p[u].x;
+            py[q] = p[u].y;
+            pz[q] = p[u].z;
+            sorted_idx[bb + base + q] = __float_as_int(p[u].w);
+          }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // next round: behind what this one placed; counters cleared
+          cur[c_lo + c] += tab[(kBlock / kWave) * wmax + c];
+#pragma unroll
+          for (int w = 0; w < kBlock / kWave; w++) tab[w * wmax + c] = 0;
+        }
+        __syncthreads();
       }
     }
-    if (giant) __threadfence_block();
-    __syncthreads();
     n_passes++;
     lap(1);
-    if (!giant) {
-      // rank sort inside every cell's segment, one thread per point: a point's rank is the number of points of its
-      // cell with a smaller point index (indices are unique).  The sorted copy goes back IN PLACE: every thread
-      // reads its points' data first, the block synchronises, then everybody writes.
-      unsigned dst[kK1PerThread], di[kK1PerThread];
-      float rx[kK1PerThread], ry[kK1PerThread], rz[kK1PerThread];
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        const unsigned q = threadIdx.x + u * kBlock;
-        dst[u] = ~0u;
-        if (q < n_pass) {
-          const unsigned c = ocell[q], beg = cstart[c] - base, end = beg + cnt[c], mine = oidx[q];
-          unsigned r = 0, t = beg;
-          for (; t + 4 <= end; t += 4) {  // four independent LDS reads per step (a dependent read per step costs its full latency)
-            const unsigned a0 = oidx[t], a1 = oidx[t + 1], a2 = oidx[t + 2], a3 = oidx[t + 3];
-            r += (a0 < mine ? 1u : 0u) + (a1 < mine ? 1u : 0u) + (a2 < mine ? 1u : 0u) + (a3 < mine ? 1u : 0u);
-          }
-          for (; t < end; t++) r += (oidx[t] < mine) ? 1u : 0u;
-          dst[u] = beg + r;
-          di[u] = mine;
-          rx[u] = ox[q];
-          ry[u] = oy[q];
-          rz[u] = oz[q];
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kK1PerThread; u++) {
-        if (dst[u] != ~0u) {
-          ox[dst[u]] = rx[u];
-          oy[dst[u]] = ry[u];
-          oz[dst[u]] = rz[u];
-          sorted_idx[bb + base + dst[u]] = static_cast<int>(di[u]);
-        }
-      }
-      __syncthreads();
-    } else {
-      // one cell with more points than LDS holds (thousands per voxel): rank sort through global scratch into a second
-      // set of slices.  O(n^2) reads by the block: slow, and rare.
-      unsigned* sidx = scratch + 4 * static_cast<size_t>(n_total) + bb + base;  // ranks
-      for (unsigned q = threadIdx.x; q < n_pass; q += kBlock) {
-        const unsigned mine = pidx[q];
-        unsigned r = 0, t = 0;
-        for (; t + 8 <= n_pass; t += 8) {
-          unsigned a[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) a[u] = pidx[t + u];
-#pragma unroll
-          for (int u = 0; u < 8; u++) r += (a[u] < mine) ? 1u : 0u;
-        }
-        for (; t < n_pass; t++) r += (pidx[t] < mine) ? 1u : 0u;
-        sidx[r] = q;
-        sorted_idx[bb + base + r] = static_cast<int>(mine);
-      }
+    if (giant) {
+      // one cell with more points than LDS holds (thousands per voxel): its points lie in order in the global scratch; one
+      // thread adds them up.  Slow, and rare.
       __threadfence_block();
       __syncthreads();
       if (threadIdx.x == 0 && static_cast<int>(n_pass) >= min_pts) {
@@ -1237,11 +1343,11 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         for (; i + 8 <= n_pass; i += 8) {
           float x[8], y[8], z[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) { const unsigned q = sidx[i + u]; x[u] = px[q]; y[u] = py[q]; z[u] = pz[q]; }
+          for (int u = 0; u < 8; u++) { x[u] = px[i + u]; y[u] = py[i + u]; z[u] = pz[i + u]; }
 #pragma unroll
           for (int u = 0; u < 8; u++) S.add(x[u], y[u], z[u]);
         }
-        for (; i < n_pass; i++) { const unsigned q = sidx[i]; S.add(px[q], py[q], pz[q]); }
+        for (; i < n_pass; i++) S.add(px[i], py[i], pz[i]);
         const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
         n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
@@ -1613,7 +1719,8 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   // against 54 / 74 / 117 us with ~8 points per bucket and 67 / 80 / 100 us for the general chain)
   static const int small_div = [] { const char* v = getenv("NDT_K1_SMALL_DIV"); return v ? std::max(1, atoi(v)) : 256; }();
   const long long k_small = std::min<long long>(4096, n_points / small_div);
-  const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / 1024));
+  static const int big_div = [] { const char* v = getenv("NDT_K1_BUCKET_POINTS"); return v ? std::max(64, atoi(v)) : 1024; }();
+  const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / big_div));
   // cells are dealt to the buckets in runs of 2^rb (k1_bucket): K a power of two, C = slots per bucket << rb
   static const int rb_env = [] { const char* v = getenv("NDT_K1_RUN_BITS"); return v ? std::max(0, std::min(8, atoi(v))) : 3; }();
   const int rb = rb_env;
@@ -1631,9 +1738,12 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   while ((1 << kb) < K) kb++;
   P.shift = rb | (kb << 8);  // the packed cell <-> (bucket, local) map of the kernels
   P.n_buckets = K;
-  P.pts_per_block = std::max(1024, std::min(16384, pow2_ceil((n_points + 383) / 384)));  // >= one block per CU: the LDS atomics of a block run at ~0.7 G/s
+  // blocks of k1_hist / k1_scatter: two per CU at 1 M points; at most 512 rows in the count matrix (k1_colscan)
+  long long ppb = std::max(512, std::min(kK1Round, pow2_ceil((n_points + 511) / 512)));
   static const int ppb_env = [] { const char* v = getenv("NDT_K1_PPB"); return v ? atoi(v) : 0; }();
-  if (ppb_env > 0) P.pts_per_block = ppb_env;
+  if (ppb_env > 0) ppb = ppb_env;
+  while ((n_points + ppb - 1) / ppb > kColGroups * kColRows) ppb += kK1Round;
+  P.pts_per_block = static_cast<int>(ppb);
   P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
   return true;
 }
@@ -1642,24 +1752,49 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                                      double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
-  const size_t lds_k = static_cast<size_t>(K) * sizeof(unsigned);
-  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), lds_k, stream, pts, n, dense, g, P.shift, K, P.pts_per_block,
-                     S.bucket_count, S.blockbase, lut, g.lut_cells);
-  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_k + sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
-                     P.pts_per_block, S.bucket_count, S.bucket_base, S.blockbase, S.bpts, counts);
+  const size_t lds_scatter = (static_cast<size_t>(K) + 2) * sizeof(unsigned) +
+                             static_cast<size_t>(K) * sizeof(unsigned short) + static_cast<size_t>(kK1Waves) * K * sizeof(unsigned short);
+  if (lds_scatter > kK1MaxDynamicLds || P.n_blocks > kColGroups * kColRows) return hipErrorInvalidValue;  // (grid_build_plan never asks for this)
+  static bool once = [] {  // more than 64 KB of dynamic LDS has to be asked for
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    return true;
+  }();
+  (void)once;
+  unsigned* total = S.cntmat + static_cast<size_t>(P.n_blocks) * K;
+  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
+                     P.pts_per_block, S.cntmat, lut, g.lut_cells);
+  hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
+  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
+                     total, S.bucket_base, S.bpts, counts);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
   // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
   // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
   const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
   int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));
-  if (K <= 512 || n <= 262144) lds_cap = kK1LdsCap;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
-  while (lds_cap > 256 && lds_cap > (60 * 1024 / 4 - 3 * C) / 5) lds_cap >>= 1;
-  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? atoi(v) : 0; }();
-  if (cap_env > 0) lds_cap = std::min(kK1LdsCap, cap_env);
-  hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), (static_cast<size_t>(3) * C + 5 * static_cast<size_t>(lds_cap)) * sizeof(unsigned), stream,
-                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, S.bucket_base, sorted_idx, recs, centroids, lut,
-                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.bucket_count, S.stamps);
+  if (n <= 262144) lds_cap = 2048;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
+  // LDS: 3 C words of per-cell state, 3 words per point, 5 rows of wmax u16 counters (+ ~10 KB static: the mask tables of
+  // wave_rank and the team sums).  Three blocks per CU where that leaves a pass at least 1024 points, else two.
+  const int wmax = std::min(C, 1024);
+  auto fin_lds = [&](int cap) { return (static_cast<size_t>(3) * C + 3 * static_cast<size_t>(cap)) * sizeof(unsigned) + 5 * static_cast<size_t>(wmax) * 2; };
+  {
+    int cap3 = lds_cap;
+    while (cap3 > 256 && fin_lds(cap3) > 42 * 1024) cap3 >>= 1;
+    if (fin_lds(cap3) <= 42 * 1024 && (cap3 >= 1024 || cap3 == lds_cap)) {
+      lds_cap = cap3;
+    } else {
+      while (lds_cap > 256 && fin_lds(lds_cap) > 68 * 1024) lds_cap >>= 1;
+    }
+  }
+  if (fin_lds(lds_cap) > kK1MaxDynamicLds) return hipErrorInvalidValue;
+  static bool once_f = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_finalize), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    return true;
+  }();
+  (void)once_f;
+  hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), fin_lds(lds_cap), stream,
+                     S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, wmax, S.bucket_base, sorted_idx, recs, centroids, lut,
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.stamps);
   return hipGetLastError();
 }
 

@@ -16,7 +16,6 @@ void ndt_context::release_buffers() {
   map_pts.release();
   server_dev_mb.release();
   server_counter.release();
-  k1_bucket_count.release();
   server_dbg.release();
 }
 

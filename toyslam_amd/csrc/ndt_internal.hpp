@@ -316,8 +316,6 @@ struct ndt_context {
   void* server_host_mb = nullptr;   // the running (or next) instance's mailbox
   int server_flip = 0;
   DevBuf<unsigned char> server_dev_mb;
-  DevBuf<unsigned> k1_bucket_count;  // kK1MaxBuckets counters of the bucket-form grid build, zero between builds (build_grid)
-  bool k1_bucket_count_clean = false;
   DevBuf<unsigned> server_counter;  // two sets of kServerCounterWords, used alternately (server_start)
   int server_counter_set = 0;
   DevBuf<unsigned long long> server_dbg;  // diagnostics only (ndt_diag_server_roundtrip)

@@ -144,9 +144,8 @@ struct GridBuildPlan {
 bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& plan);
 constexpr int kK1MaxBuckets = 8192;
 struct GridBuildScratch {
-  unsigned* bucket_count;  // [n_buckets] of the HANDLE's kK1MaxBuckets counters: zero on entry, zero again when k1_finalize is through
+  unsigned* cntmat;        // [n_blocks x n_buckets] points per (block of points, bucket), then [n_buckets] bucket sizes
   unsigned* bucket_base;   // [n_buckets + 1] bases + [n_buckets] valid voxels per bucket   (kept with the grid: the leaf pass needs both)
-  unsigned* blockbase;     // [n_blocks x n_buckets]
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
   unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
   unsigned long long* stamps;  // development aid (NDT_K1_STAMPS): [n_buckets x 8] phase clocks of k1_finalize, or null
