@@ -501,8 +501,8 @@ ndt_status build_grid(ndt_context* h) {
     static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
     DevBuf<unsigned long long> stamps;
     if (want_stamps) {
-      HIP_TRY(stamps.reserve(8 * K));
-      HIP_TRY(hipMemsetAsync(stamps.p, 0, 8 * K * sizeof(unsigned long long), st));
+      HIP_TRY(stamps.reserve(8 * (K + static_cast<size_t>(plan.n_blocks))));
+      HIP_TRY(hipMemsetAsync(stamps.p, 0, 8 * (K + static_cast<size_t>(plan.n_blocks)) * sizeof(unsigned long long), st));
       S.stamps = stamps.p;
     }
     // Records dense and in ascending cell order (maybe_compact_records: two small launches, ~13 us) pay for themselves as
@@ -528,6 +528,19 @@ ndt_status build_grid(ndt_context* h) {
         if (d.empty()) continue;
         std::sort(d.begin(), d.end());
         std::fprintf(stderr, "%s %llu/%llu  ", names[q], d[d.size() / 2], d.back());
+      }
+      std::fprintf(stderr, "\n");
+      const size_t B = static_cast<size_t>(plan.n_blocks);
+      std::vector<unsigned long long> hs(8 * B);
+      HIP_TRY(hipMemcpy(hs.data(), stamps.p + 8 * K, 8 * B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[k1_scatter clocks, %zu blocks, cycles since the block's start: tables / ranks / column scan / stores] ", B);
+      for (int q = 1; q < 5; q++) {
+        std::vector<unsigned long long> d;
+        for (size_t bq = 0; bq < B; bq++)
+          if (hs[8 * bq] && hs[8 * bq + q]) d.push_back(hs[8 * bq + q] - hs[8 * bq]);
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        std::fprintf(stderr, "%llu/%llu  ", d[d.size() / 2], d.back());
       }
       std::fprintf(stderr, "\n");
     }

@@ -909,6 +909,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
                                                       int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells) {
   extern __shared__ unsigned k1_lds[];
   unsigned* h = k1_lds;
+  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
+  float4 p[8];  // the first eight points per thread: requested before the clearing below
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = lo + threadIdx.x + u * kK1Threads;
+    p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+  }
   for (int k = threadIdx.x; k < K; k += kK1Threads) h[k] = 0;
   {  // the padded look-up table starts out empty: every block clears its slice
     const long long n4 = lut_cells / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
@@ -919,13 +926,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
       for (long long i = n4 * 4 + threadIdx.x; i < lut_cells; i += kK1Threads) lut[i] = kLutEmpty;
   }
   __syncthreads();
-  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
   for (int base = lo + threadIdx.x; base < hi; base += 8 * kK1Threads) {  // eight loads in flight per thread
-    float4 p[8];
+    if (base != lo + static_cast<int>(threadIdx.x)) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = base + u * kK1Threads;
-      p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+      for (int u = 0; u < 8; u++) {
+        const int i = base + u * kK1Threads;
+        p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -981,9 +988,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_colscan(unsigned* __restrict__ 
 __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                          int ppb, const unsigned* __restrict__ cntmat, const unsigned* __restrict__ total,
                                                          unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
-                                                         unsigned* __restrict__ counts) {
+                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st) {
   extern __shared__ unsigned k1_lds[];
   __shared__ unsigned s_scan[kK1Waves];
+  auto mark = [&](int q) {  // development aid (NDT_K1_STAMPS): thread 0's clock at the phase boundaries
+    if (st && threadIdx.x == 0) st[8 * blockIdx.x + q] = stamp();
+  };
+  mark(0);
   __shared__ unsigned long long s_mtab[kK1Waves * kMatchSlots];  // (static: 8-byte aligned whatever precedes the dynamic part)
   unsigned long long* mtab_all = s_mtab;
   unsigned* cursor = k1_lds;                                                         // [K + 1] (+ 1 pad word)
@@ -992,6 +1003,14 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int b = blockIdx.x;
   const int kbits = map >> 8;
+  const int lo = b * ppb, hi = min(n, lo + ppb);
+  // the first round's points: requested before anything else, so that they arrive while the tables below are set up
+  float4 p[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int i = lo + wave * (8 * kWave) + u * kWave + lane;
+    p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+  }
   for (int i = threadIdx.x; i < kK1Waves * kMatchSlots; i += kK1Threads) mtab_all[i] = 0ull;
   for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
   // bucket bases = exclusive scan of the bucket sizes, by every block for itself; block 0 keeps them for k1_finalize
@@ -1003,18 +1022,19 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
   }
   for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += cntmat[static_cast<size_t>(b) * K + k];
   __syncthreads();
+  mark(1);
   // ---- stable split: rounds of 2048 points; wave w ranks the eight 64-point chunks [w * 512, (w + 1) * 512) of the round
-  const int lo = b * ppb, hi = min(n, lo + ppb);
   unsigned short* row = tab + wave * K;
   unsigned long long* mtab = mtab_all + wave * kMatchSlots;
   for (int r0 = lo; r0 < hi; r0 += kK1Round) {
-    float4 p[8];
     int key[8];
     unsigned rk[8];
+    if (r0 != lo) {  // (uniform; the first round's points are on their way already)
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
-      p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+      for (int u = 0; u < 8; u++) {
+        const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
+        p[u] = (i < hi) ? pts[i] : make_float4(NAN, NAN, NAN, 0.f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1025,6 +1045,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       if (r0 + wave * (8 * kWave) + u * kWave < hi) rk[u] = wave_rank(key[u], key[u] >= 0, mtab, row, kbits);  // (uniform: the chunk has points)
     }
     __syncthreads();
+    if (r0 == lo) mark(2);
     // per bucket: the waves' counts -> exclusive prefix over the waves (in place), the round's total -> the cursor afterwards
     for (int k = threadIdx.x; k < K; k += kK1Threads) {
       unsigned s_ = 0;
@@ -1037,6 +1058,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       tot[k] = static_cast<unsigned short>(s_);
     }
     __syncthreads();
+    if (r0 == lo) mark(3);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       if (key[u] >= 0) {
@@ -1045,6 +1067,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       }
     }
     __syncthreads();
+    if (r0 == lo) mark(4);
     if (r0 + kK1Round < hi) {  // (uniform) another round: advance the cursors, clear the counters
       for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += tot[k];
       for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
@@ -1218,8 +1241,59 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   while ((1 << wbits) < wmax) wbits++;
   for (int i = threadIdx.x; i < (kBlock / kWave) * kMatchSlots; i += kBlock) mtab_all[i] = 0ull;
   for (int i = threadIdx.x; i < (kBlock / kWave + 1) * wmax / 2; i += kBlock) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
-  k1_scan_cells(cnt, cstart, C, s_u3);
+  // A bucket that fits one round of the stable placement (2048 points; every bucket of a uniform cloud) reads its points
+  // ONCE: the ranking's per-wave counts ARE the per-cell histogram, so the separate counting pass over the bucket and
+  // its LDS atomics are skipped -- rank, column scan (-> counts), scan over the cells (-> segment starts), place.
+  const bool one_shot = nb <= static_cast<unsigned>(kK1PerThread * kBlock) && nb <= static_cast<unsigned>(lds_cap) && C <= wmax;
+  if (one_shot) {
+    unsigned short* row = tab + wave * wmax;
+    unsigned long long* mtab = mtab_all + wave * kMatchSlots;
+    const int per_wave = static_cast<int>(((nb + kWave - 1) / kWave + kBlock / kWave - 1) / (kBlock / kWave));  // <= kK1PerThread
+    float4 p[kK1PerThread];
+    int cc[kK1PerThread];
+    unsigned rk[kK1PerThread];
+#pragma unroll
+    for (int u = 0; u < kK1PerThread; u++) {
+      const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
+      p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
+    }
+    __syncthreads();  // (the counter rows are cleared)
+#pragma unroll
+    for (int u = 0; u < kK1PerThread; u++) {
+      const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
+      const int c = (u < per_wave && j < nb) ? k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map) : -1;
+      cc[u] = c;
+      rk[u] = 0;
+      if (u < per_wave) rk[u] = wave_rank(c, c >= 0, mtab, row, wbits);  // (uniform)
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+      unsigned s_ = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / kWave; w++) {
+        const unsigned t = tab[w * wmax + c];
+        tab[w * wmax + c] = static_cast<unsigned short>(s_);
+        s_ += t;
+      }
+      cnt[c] = s_;
+    }
+    __syncthreads();
+    k1_scan_cells(cnt, cstart, C, s_u3);
+#pragma unroll
+    for (int u = 0; u < kK1PerThread; u++) {
+      if (cc[u] >= 0) {
+        const unsigned q = cstart[cc[u]] + row[cc[u]] + rk[u];
+        ox[q] = p[u].x;
+        oy[q] = p[u].y;
+        oz[q] = p[u].z;
+        sorted_idx[bb + q] = __float_as_int(p[u].w);
+      }
+    }
+    __syncthreads();
+  } else {
+    k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
+    k1_scan_cells(cnt, cstart, C, s_u3);
+  }
   lap(0);
   const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
@@ -1230,7 +1304,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   for (int c_lo = 0; c_lo < C;) {
     if (threadIdx.x == 0) {
       int c = c_lo;
-      if (nb <= static_cast<unsigned>(lds_cap) && C <= wmax) {
+      if (one_shot || (nb <= static_cast<unsigned>(lds_cap) && C <= wmax)) {
         c = C;
       } else {
         // the last cell whose END stays within lds_cap points of c_lo's start (and within wmax cells: the counter rows of
@@ -1262,6 +1336,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     float* px = giant ? reinterpret_cast<float*>(scratch + n_total + bb + base) : ox;
     float* py = giant ? reinterpret_cast<float*>(scratch + 2 * static_cast<size_t>(n_total) + bb + base) : oy;
     float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
+    if (!one_shot) {
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
     __syncthreads();
     // Select this pass's points, ORDER-PRESERVING.  The bucket holds its points in ascending point index (k1_scatter), and
@@ -1330,6 +1405,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         __syncthreads();
       }
     }
+    }  // !one_shot
     n_passes++;
     lap(1);
     if (giant) {
@@ -1765,7 +1841,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                      P.pts_per_block, S.cntmat, lut, g.lut_cells);
   hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
-                     total, S.bucket_base, S.bpts, counts);
+                     total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
   // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
