@@ -19,7 +19,7 @@ out = {"command": "python bench.py --steps K --warmup W --no-cpu-baseline --no-m
 f = glob.glob(O + "/stats/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 open(O + "/kernel_stats.csv", "w").write(open(f).read())
-for r in rows[:20]:
+for r in rows[:28]:
     out["kernels"][r["Name"][:100]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
 for name in ("fetch", "write", "tcc"):
     for f in glob.glob(O + "/%s/*/*counter_collection.csv" % name):
@@ -27,7 +27,7 @@ for name in ("fetch", "write", "tcc"):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"][:100]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            if "k_derivatives" in k or "k_eval_server" in k or "k_hessian64" in k or "k1_" in k:
+            if any(t in k for t in ("k_derivatives", "k_eval_server", "k_hessian64", "k1_", "k_bbox", "k_repack", "k_rc_")):
                 out["pmc"].setdefault(k, {}).update({c: {"mean": sum(x) / len(x), "n": len(x)} for c, x in v.items()})
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
