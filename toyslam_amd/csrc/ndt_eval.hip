@@ -400,7 +400,7 @@ ndt_status ndt_align(ndt_handle h, const float* guess, float* final_transformati
   const bool alone = active.mine == 1 || h->persistent > 0;  // (ndt_set_evaluation_path(h, 1) insists on the server)
   // Multi-million-point scans: the launch path's kernel runs two blocks per CU where the server has one, and at ~60 us per
   // evaluation a launch is cheap -- 10M-point target at 0.5 m, server / launch path: 200k points 0.59 / 0.77 ms, 500k
-  // 0.81 / 0.95, 1M 1.23 / 1.23, 2M 2.07 / 1.83 (tools/time_paths_by_size.py).
+  // 0.81 / 0.95, 1M 1.23 / 1.23, 2M 2.07 / 1.83 (NOTES.md, round 2).
   const bool big_scan = h->source->k2_n() >= 1500000 && h->persistent <= 0;
   const bool use_server = (h->persistent < 0 ? server_enabled() : h->persistent != 0) && alone && !big_scan && !h->profiling && !h->allreduce && !h->comm &&
                           ndt::derivative_variant() == 0 && h->source->k2_n() > 0 && !h->grid->empty;
