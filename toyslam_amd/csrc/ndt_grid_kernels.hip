@@ -812,22 +812,53 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const float4* __restrict__ 
 // ---------------------------------------------------------------------------
 // Cell <-> (bucket, local cell).  Buckets are NOT ranges of the linear cell index: a clustered scene (a ground plane) would
 // fill a few of those with many times the mean and leave the rest empty.  Runs of 2^rb consecutive cells (neighbours in x,
-// whose points a spatially ordered cloud delivers together) are dealt round-robin to the K = 2^kb buckets:
-//   bucket = (cell >> rb) mod K,   local = ((cell >> rb) / K) << rb | (cell mod 2^rb)
-// `map` packs rb (bits 0-7) and kb (bits 8-15).
-__device__ __forceinline__ int k1_bucket(int cell, int map) { return (cell >> (map & 255)) & ((1 << (map >> 8)) - 1); }
-__device__ __forceinline__ int k1_local(int cell, int map) {
-  const int rb = map & 255, kb = map >> 8;
-  return ((cell >> (rb + kb)) << rb) | (cell & ((1 << rb) - 1));
+// whose points a spatially ordered cloud delivers together) are dealt round-robin to the K buckets:
+//   run = cell >> rb,   bucket = run mod K,   local = (run / K) << rb | (cell mod 2^rb)
+// K is any number (grid_build_plan picks a multiple of the blocks the chip holds at once, so that k1_finalize's one block
+// per bucket runs in whole rounds); the division is a multiply-high by floor(2^32 / K) and one correction step.
+struct K1Deal {
+  int rb;
+  unsigned K, M;
+  __device__ __forceinline__ K1Deal(int rb_, int K_) : rb(rb_), K(static_cast<unsigned>(K_)), M(0xffffffffu / static_cast<unsigned>(K_)) {}
+  __device__ __forceinline__ void divmod(unsigned run, unsigned& q, unsigned& r) const {
+    q = __umulhi(run, M);  // floor(run / K) or one less
+    r = run - q * K;
+    if (r >= K) {
+      r -= K;
+      q++;
+    }
+  }
+};
+__device__ __forceinline__ int k1_bucket(int cell, const K1Deal& d) {
+  unsigned q, r;
+  d.divmod(static_cast<unsigned>(cell) >> d.rb, q, r);
+  return static_cast<int>(r);
 }
-__device__ __forceinline__ int k1_cell(int bucket, int local, int map) {
-  const int rb = map & 255, kb = map >> 8;
-  return ((((local >> rb) << kb) | bucket) << rb) | (local & ((1 << rb) - 1));
+__device__ __forceinline__ int k1_local(int cell, const K1Deal& d) {
+  unsigned q, r;
+  d.divmod(static_cast<unsigned>(cell) >> d.rb, q, r);
+  return static_cast<int>((q << d.rb) | (static_cast<unsigned>(cell) & ((1u << d.rb) - 1u)));
+}
+__device__ __forceinline__ int k1_cell(int bucket, int local, const K1Deal& d) {
+  const unsigned l = static_cast<unsigned>(local);
+  return static_cast<int>((((l >> d.rb) * d.K + static_cast<unsigned>(bucket)) << d.rb) | (l & ((1u << d.rb) - 1u)));
+}
+__device__ __forceinline__ int k1_key_bits(int K) {  // bits of the largest bucket number
+  int b = 0;
+  while ((1 << b) < K) b++;
+  return b;
 }
 
 constexpr int kK1Threads = 256;              // k1_hist / k1_scatter
 constexpr int kK1Waves = kK1Threads / kWave;  // 4
 constexpr int kK1Round = 8 * kK1Threads;     // points one block of k1_scatter ranks per round (eight 64-point chunks per wave)
+
+// Which slice of the cloud a block of k1_hist / k1_scatter takes.  Workgroups are dealt to the eight XCDs round-robin (block b
+// runs on XCD b mod 8) and every XCD has an L2 of its own: with slice = block index, the 32-byte runs that neighbouring
+// slices add to a bucket would come from eight different L2s and reach memory as eight partial lines.  XCD x takes the
+// x-th eighth of the slices instead, so the runs one L2 collects for a bucket are adjacent and leave it as whole lines.
+// (B, the grid size, is a multiple of 8.)
+__device__ __forceinline__ int k1_slice(int b, int B) { return (b & 7) * (B >> 3) + (b >> 3); }
 
 __device__ __forceinline__ int key_of(const GridGeom& g, const float4& p, int dense) {
   int c = -1;
@@ -908,8 +939,10 @@ __device__ __forceinline__ unsigned wave_rank(int key, bool valid, unsigned long
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                       int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells) {
   extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
   unsigned* h = k1_lds;
-  const int lo = blockIdx.x * ppb, hi = min(n, lo + ppb);
+  const int slice = k1_slice(blockIdx.x, gridDim.x);
+  const int lo = min(static_cast<long long>(n), static_cast<long long>(slice) * ppb), hi = min(static_cast<long long>(n), static_cast<long long>(lo) + ppb);
   float4 p[8];  // the first eight points per thread: requested before the clearing below
 #pragma unroll
   for (int u = 0; u < 8; u++) {
@@ -937,11 +970,11 @@ __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int c = (base + u * kK1Threads < hi) ? key_of(g, p[u], dense) : -1;
-      if (c >= 0) atomicAdd(&h[k1_bucket(c, map)], 1u);
+      if (c >= 0) atomicAdd(&h[k1_bucket(c, deal)], 1u);
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kK1Threads) cntmat[static_cast<size_t>(blockIdx.x) * K + k] = h[k];
+  for (int k = threadIdx.x; k < K; k += kK1Threads) cntmat[static_cast<size_t>(slice) * K + k] = h[k];
 }
 
 // The count matrix, column by column: cntmat[b][k] <- points of bucket k in the blocks BEFORE b (exclusive prefix down the
@@ -990,6 +1023,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
                                                          unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
                                                          unsigned* __restrict__ counts, unsigned long long* __restrict__ st) {
   extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
   __shared__ unsigned s_scan[kK1Waves];
   auto mark = [&](int q) {  // development aid (NDT_K1_STAMPS): thread 0's clock at the phase boundaries
     if (st && threadIdx.x == 0) st[8 * blockIdx.x + q] = stamp();
@@ -1001,9 +1035,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
   unsigned short* tot = reinterpret_cast<unsigned short*>(cursor + K + 2);           // [K]
   unsigned short* tab = tot + K;                                                     // [kK1Waves][K]
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int b = blockIdx.x;
-  const int kbits = map >> 8;
-  const int lo = b * ppb, hi = min(n, lo + ppb);
+  const int b = k1_slice(blockIdx.x, gridDim.x);  // the slice = the row of the count matrix
+  const int kbits = k1_key_bits(K);
+  const int lo = min(static_cast<long long>(n), static_cast<long long>(b) * ppb), hi = min(static_cast<long long>(n), static_cast<long long>(lo) + ppb);
   // the first round's points: requested before anything else, so that they arrive while the tables below are set up
   float4 p[8];
 #pragma unroll
@@ -1040,7 +1074,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
     for (int u = 0; u < 8; u++) {
       const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
       const int c = (i < hi) ? key_of(g, p[u], dense) : -1;
-      key[u] = (c >= 0) ? k1_bucket(c, map) : -1;
+      key[u] = (c >= 0) ? k1_bucket(c, deal) : -1;
       rk[u] = 0;
       if (r0 + wave * (8 * kWave) + u * kWave < hi) rk[u] = wave_rank(key[u], key[u] >= 0, mtab, row, kbits);  // (uniform: the chunk has points)
     }
@@ -1078,12 +1112,12 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
 
 // per-bucket cell histogram in LDS (cnt[C], zeroed here)
 __device__ __forceinline__ void k1_cell_histogram(const float4* __restrict__ bpts, unsigned bb, unsigned be, const GridGeom& g,
-                                                  int map, int C, unsigned* cnt) {
+                                                  const K1Deal& deal, int C, unsigned* cnt) {
   for (int c = threadIdx.x; c < C; c += kBlock) cnt[c] = 0;
   __syncthreads();
   for (unsigned j = bb + threadIdx.x; j < be; j += kBlock) {
     const float4 p = bpts[j];
-    atomicAdd(&cnt[k1_local(build_cell(g, p.x, p.y, p.z), map)], 1u);
+    atomicAdd(&cnt[k1_local(build_cell(g, p.x, p.y, p.z), deal)], 1u);
   }
   __syncthreads();
 }
@@ -1093,6 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
                                                    unsigned* __restrict__ ticket, unsigned* __restrict__ occ_base,
                                                    unsigned* __restrict__ cand_base, unsigned* __restrict__ counts) {
   extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ unsigned s_scan[kBlock / kWave];
   __shared__ int s_last;
@@ -1100,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   U3 t = {0, 0, 0};
   if (be > bb) {  // uniform
-    k1_cell_histogram(bpts, bb, be, g, map, C, k1_lds);
+    k1_cell_histogram(bpts, bb, be, g, deal, C, k1_lds);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       const unsigned v = k1_lds[c];
       t.occ += (v > 0);
@@ -1199,6 +1234,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                                       unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
                                                       unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
   extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
   // phase clocks of thread 0 (NDT_K1_STAMPS): cycles spent in 0 histogram + scan, 1 select, 2 rank sort, 3 lane teams,
@@ -1213,10 +1249,11 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       t_mark = t;
     }
   };
+  __shared__ int s_ncand;                     // cells of the current pass that get a record
   __shared__ int s_nteam;                     // team cells of the current pass ...
-  __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells ...
-  __shared__ double s_team64[kMaxTeamCells][9];  // ... and their sums (sx sy sz cxx cxy cxz cyy cyz czz)
-  __shared__ float s_team32[kMaxTeamCells][3];   // (fx fy fz)
+  __shared__ int s_team_cell[kMaxTeamCells];  // ... their cells.  A team leaves its sums where the cell's points were: the nine f64
+                                              // (sx sy sz cxx cxy cxz cyy cyz czz) as 18 words at the head of the cell's x segment,
+                                              // fx fy fz at the head of its y segment (a team cell has more than 32 points)
   __shared__ float s_one;
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
@@ -1261,7 +1298,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
 #pragma unroll
     for (int u = 0; u < kK1PerThread; u++) {
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-      const int c = (u < per_wave && j < nb) ? k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map) : -1;
+      const int c = (u < per_wave && j < nb) ? k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), deal) : -1;
       cc[u] = c;
       rk[u] = 0;
       if (u < per_wave) rk[u] = wave_rank(c, c >= 0, mtab, row, wbits);  // (uniform)
@@ -1291,7 +1328,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     }
     __syncthreads();
   } else {
-    k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
+    k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
     k1_scan_cells(cnt, cstart, C, s_u3);
   }
   lap(0);
@@ -1367,7 +1404,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           const unsigned j = j0 + static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
           int c = -1;
           if (u < per_wave && j < nb) {
-            c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), map);
+            c = k1_local(build_cell(g, p[u].x, p[u].y, p[u].z), deal);
             if (c < c_lo || c >= c_hi) c = -1;
           }
           cc[u] = c;
@@ -1425,7 +1462,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_pass; i++) S.add(px[i], py[i], pz[i]);
         const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
-        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
       c_lo = c_hi;
       __syncthreads();
@@ -1440,7 +1477,6 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       if (n_c > kTeamCell && n_c >= min_pts) {
         const int slot = atomicAdd(&s_nteam, 1);
         s_team_cell[slot] = c;
-        cur[c] = static_cast<unsigned>(slot);  // (the scatter cursors are free again)
       }
     }
     __syncthreads();
@@ -1477,26 +1513,42 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           acc += prod;
           acc32 += a;
         }
-        if (tl < 9) s_team64[s][tl] = acc;
-        else if (tl < 12) s_team32[s][tl - 9] = acc32;
+        // (the 16 lanes of a team are lanes of one wave and walk the same n_c points: every read of the segment above has
+        // been issued before these stores, and a wave's DS operations execute in order)
+        if (tl < 9) {
+          ox[beg + 2 * tl] = __int_as_float(__double2loint(acc));
+          ox[beg + 2 * tl + 1] = __int_as_float(__double2hiint(acc));
+        } else if (tl < 12) {
+          oy[beg + tl - 9] = acc32;
+        }
       }
     }
     __syncthreads();
     lap(3);
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
+    // The cells that get a record (min_pts points and more: the reference skips the others at look-up, _impl.hpp:395), compacted
+    // into a list first (cur[] is free after the placement): on a sparsely occupied grid -- 4096 cells per bucket for ~200
+    // occupied ones at 10 M points / 0.5 m -- a thread per CELL left one lane in twenty with work and every wave ran
+    // finish_voxel sixteen times over.  (The order of the list varies from run to run; nothing depends on it.)
+    if (threadIdx.x == 0) s_ncand = 0;
+    __syncthreads();
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock)
+      if (static_cast<int>(cnt[c]) >= min_pts) cur[atomicAdd(&s_ncand, 1)] = static_cast<unsigned>(c);
+    __syncthreads();
+    const int n_cand = s_ncand;
+    for (int ci = threadIdx.x; ci < n_cand; ci += kBlock) {
+      const int c = static_cast<int>(cur[ci]);
       const int n_c = static_cast<int>(cnt[c]);
-      if (n_c < min_pts) continue;  // (cells with fewer points get no record: the reference skips them at look-up, _impl.hpp:395)
       const unsigned beg = cstart[c] - base;
       // record slot: candidates' segments start at least min_pts apart, so start / min_pts is unique per candidate --
       // no scan over the buckets is needed to number the records (k1_leaves numbers the LEAVES when somebody asks)
       const int r = static_cast<int>((bb + cstart[c]) / static_cast<unsigned>(min_pts));
       VoxelSums S;
       if (n_c > kTeamCell) {
-        const unsigned slot = cur[c];
-        S.sx = s_team64[slot][0]; S.sy = s_team64[slot][1]; S.sz = s_team64[slot][2];
-        S.cxx = s_team64[slot][3]; S.cxy = s_team64[slot][4]; S.cxz = s_team64[slot][5];
-        S.cyy = s_team64[slot][6]; S.cyz = s_team64[slot][7]; S.czz = s_team64[slot][8];
-        S.fx = s_team32[slot][0]; S.fy = s_team32[slot][1]; S.fz = s_team32[slot][2];
+        auto f64_at = [&](int q) { return __hiloint2double(__float_as_int(ox[beg + 2 * q + 1]), __float_as_int(ox[beg + 2 * q])); };
+        S.sx = f64_at(0); S.sy = f64_at(1); S.sz = f64_at(2);
+        S.cxx = f64_at(3); S.cxy = f64_at(4); S.cxz = f64_at(5);
+        S.cyy = f64_at(6); S.cyz = f64_at(7); S.czz = f64_at(8);
+        S.fx = oy[beg]; S.fy = oy[beg + 1]; S.fz = oy[beg + 2];
       } else {
         int i = 0;
         for (; i + 4 <= n_c; i += 4) {  // ascending point order, contiguous; twelve reads in flight per step
@@ -1508,7 +1560,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
         for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       }
-      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, map), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
@@ -1650,12 +1702,13 @@ __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ b
                                                     int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
                                                     int* __restrict__ leaf_count, int* __restrict__ leaf_rec, const int* __restrict__ lut) {
   extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) return;
   unsigned* cnt = k1_lds;
-  k1_cell_histogram(bpts, bb, be, g, map, C, cnt);
+  k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
   const int per = C / kBlock > 0 ? C / kBlock : 1;
   const int lo = threadIdx.x * per;
   U3 t = {0, 0, 0};
@@ -1670,12 +1723,12 @@ __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ b
     const unsigned v = cnt[c];
     if (v > 0) {
       const unsigned o = ob + run.occ;
-      leaf_cell[o] = k1_cell(k, c, map);
+      leaf_cell[o] = k1_cell(k, c, deal);
       leaf_start[o] = bb + run.pts;
       leaf_count[o] = static_cast<int>(v);
       int rec = -1;
       if (v >= static_cast<unsigned>(min_pts)) {  // the voxel's record: wherever the compaction put it (read back from the table)
-        const int cell = k1_cell(k, c, map);
+        const int cell = k1_cell(k, c, deal);
         const int cz = cell / g.mul[2], cy = (cell - cz * g.mul[2]) / g.mul[1], cx = cell - cz * g.mul[2] - cy * g.mul[1];
         const int e = lut[static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * g.pmul[1] +
                           static_cast<long long>(cz + kLutBorder) * g.pmul[2]];
@@ -1797,22 +1850,33 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   const long long k_small = std::min<long long>(4096, n_points / small_div);
   static const int big_div = [] { const char* v = getenv("NDT_K1_BUCKET_POINTS"); return v ? std::max(64, atoi(v)) : 1024; }();
   const long long k_target = std::max<long long>(std::max<long long>(256, n_points <= 262144 ? k_small : 0), std::min<long long>(kMaxBuckets, n_points / big_div));
-  // cells are dealt to the buckets in runs of 2^rb (k1_bucket): K a power of two, C = slots per bucket << rb
+  // cells are dealt to the buckets in runs of 2^rb (k1_bucket); C = slots per bucket << rb
   static const int rb_env = [] { const char* v = getenv("NDT_K1_RUN_BITS"); return v ? std::max(0, std::min(8, atoi(v))) : 3; }();
   const int rb = rb_env;
-  int K = std::min(kMaxBuckets, pow2_ceil(k_target));
+  // K: a power of two by default; NDT_K1_BUCKETS forces any multiple of 8.  (Measured and dropped: 768 buckets at 1 M points,
+  // one block per bucket = exactly the three blocks per CU that k1_finalize's registers allow, so that the kernel runs in
+  // one round instead of one and a third -- 27.4 against 26.0 us on the uniform scene, 54.7 against 41.5 us on surfaces:
+  // the blocks of a round are in the same phase at the same time, and fewer, longer blocks overlap less.)
+  static const int k_env = [] { const char* v = getenv("NDT_K1_BUCKETS"); return v ? std::max(8, atoi(v)) / 8 * 8 : 0; }();
+  int K, k_step;
+  if (k_env > 0) {
+    K = std::min(kMaxBuckets, k_env);
+    k_step = 8;
+  } else {
+    K = std::min(kMaxBuckets, pow2_ceil(k_target));
+    k_step = -1;  // (doubling)
+  }
   const long long runs = (n_cells + (1ll << rb) - 1) >> rb;
   int C;
   for (;;) {
     C = std::max(32, pow2_ceil((runs + K - 1) / K) << rb);
     if (C <= kMaxCells) break;
-    if (K >= kMaxBuckets) return false;
-    K <<= 1;
+    const int next = k_step < 0 ? K * 2 : K + k_step;
+    if (next > kMaxBuckets) return false;
+    K = next;
   }
   P.cells_per_bucket = C;
-  int kb = 0;
-  while ((1 << kb) < K) kb++;
-  P.shift = rb | (kb << 8);  // the packed cell <-> (bucket, local) map of the kernels
+  P.shift = rb | (K << 8);  // the packed cell <-> (bucket, local) map of the kernels: run bits, bucket count (K1Deal)
   P.n_buckets = K;
   // blocks of k1_hist / k1_scatter: two per CU at 1 M points; at most 512 rows in the count matrix (k1_colscan)
   long long ppb = std::max(512, std::min(kK1Round, pow2_ceil((n_points + 511) / 512)));
@@ -1820,7 +1884,7 @@ bool grid_build_plan(long long n_cells, int n_points, GridBuildPlan& P) {
   if (ppb_env > 0) ppb = ppb_env;
   while ((n_points + ppb - 1) / ppb > kColGroups * kColRows) ppb += kK1Round;
   P.pts_per_block = static_cast<int>(ppb);
-  P.n_blocks = (n_points + P.pts_per_block - 1) / P.pts_per_block;
+  P.n_blocks = ((n_points + P.pts_per_block - 1) / P.pts_per_block + 7) / 8 * 8;  // a multiple of 8: k1_slice (empty slices cost nothing)
   return true;
 }
 
@@ -1844,24 +1908,21 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                      total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
-  // sized for the mean bucket + 25 % (+128), in steps of 256: every block of a uniform cloud then fits while four to five
-  // blocks share a CU's 160 KB (782 blocks of 42 KB each were 14 more than the chip holds at once: a second round)
-  const long long mean_pts = static_cast<long long>(n) / std::max(1, K);
-  int lds_cap = std::max(512, std::min(kK1LdsCap, pow2_ceil(mean_pts * 5 / 4 + 128)));
-  if (n <= 262144) lds_cap = 2048;  // small clouds: LDS is not what limits residency, and a crowded bucket needs fewer passes
-  // LDS: 3 C words of per-cell state, 3 words per point, 5 rows of wmax u16 counters (+ ~10 KB static: the mask tables of
-  // wave_rank and the team sums).  Three blocks per CU where that leaves a pass at least 1024 points, else two.
+  // The kernel's registers allow three blocks per CU, so a pass gets what a third of the CU's LDS holds (the host does not
+  // know the fullest bucket: on clustered scenes it has three times the mean, and every pass it needs beyond the first reads
+  // and ranks the whole bucket again) -- or half / all of it where the per-cell state of a big C leaves less than 1024 points.
+  // LDS: 3 C words of per-cell state, 3 words per point, 5 rows of wmax u16 counters (+ ~9 KB static: wave_rank's mask tables)
   const int wmax = std::min(C, 1024);
   auto fin_lds = [&](int cap) { return (static_cast<size_t>(3) * C + 3 * static_cast<size_t>(cap)) * sizeof(unsigned) + 5 * static_cast<size_t>(wmax) * 2; };
-  {
-    int cap3 = lds_cap;
-    while (cap3 > 256 && fin_lds(cap3) > 42 * 1024) cap3 >>= 1;
-    if (fin_lds(cap3) <= 42 * 1024 && (cap3 >= 1024 || cap3 == lds_cap)) {
-      lds_cap = cap3;
-    } else {
-      while (lds_cap > 256 && fin_lds(lds_cap) > 68 * 1024) lds_cap >>= 1;
-    }
+  int lds_cap = 256;
+  for (const size_t budget : {static_cast<size_t>(44 * 1024), static_cast<size_t>(70 * 1024), kK1MaxDynamicLds}) {
+    int cap = kK1LdsCap;
+    while (cap > 256 && fin_lds(cap) > budget) cap -= 256;
+    lds_cap = cap;
+    if (fin_lds(cap) <= budget && cap >= 1024) break;
   }
+  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? std::max(256, atoi(v)) / 256 * 256 : 0; }();
+  if (cap_env > 0) lds_cap = std::min(lds_cap, cap_env);  // (tests: small passes, so that ordinary clouds take the multi-pass and crowded-cell paths)
   if (fin_lds(lds_cap) > kK1MaxDynamicLds) return hipErrorInvalidValue;
   static bool once_f = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_finalize), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
