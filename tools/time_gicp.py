@@ -2,6 +2,10 @@
 usage: time_gicp.py [pair | N_TARGET N_SOURCE] [--oracle]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--oracle" in sys.argv:  # before any OpenMP runtime is loaded: the CPUs this box grants the process (cgroup quota,
+    import bench            # affinity) -- more threads than that are throttled
+    granted = int(bench.host_info()["granted_cpus"])
+    os.environ["OMP_NUM_THREADS"] = str(granted)
 import numpy as np
 import torch  # noqa: F401
 from toyslam_amd import clouds, gicp
@@ -38,6 +42,6 @@ if "--oracle" in sys.argv:
     o = po.OracleGICP(); o.setInputTarget(tgt); o.setInputSource(src)
     t0 = time.perf_counter(); r = o.align(); out["oracle_first_align_ms"] = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter(); r = o.align(); out["oracle_align_ms"] = (time.perf_counter() - t0) * 1e3
-    out["oracle_threads"] = os.cpu_count()
+    out["oracle_threads"] = granted
     out["T_max_abs_diff_vs_oracle"] = float(np.abs(g.getFinalTransformation() - r["T"]).max())
 print(json.dumps(out))

@@ -519,7 +519,7 @@ ndt_status build_grid(ndt_context* h) {
       std::vector<unsigned long long> hst(8 * K);
       HIP_TRY(hipMemcpyAsync(hst.data(), stamps.p, 8 * K * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      static const char* names[8] = {"hist+scan", "select", "rank-sort", "teams", "sums+finish", "passes", "points", "total"};
+      static const char* names[8] = {"load+rank", "scans+select", "place", "teams", "sums+finish", "passes", "points", "total"};
       std::fprintf(stderr, "[k1_finalize clocks, %zu buckets] ", K);
       for (int q = 0; q < 8; q++) {
         std::vector<unsigned long long> d;

@@ -849,6 +849,12 @@ __device__ __forceinline__ int k1_key_bits(int K) {  // bits of the largest buck
   return b;
 }
 
+// Barrier for data exchanged through LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL loads and stores
+// (s_waitcnt vmcnt(0)): after a round of scattered 16-byte stores that is 3-8 k cycles of a block doing nothing -- a third of
+// k1_scatter's rounds at 10 M points, a fifth of a k1_finalize block.  Nothing in these kernels reads global memory that another
+// wave of the same block wrote (the one exception, a crowded cell's scratch, keeps its fence + __syncthreads()).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kK1Threads = 256;              // k1_hist / k1_scatter
 constexpr int kK1Waves = kK1Threads / kWave;  // 4
 constexpr int kK1Round = 8 * kK1Threads;     // points one block of k1_scatter ranks per round (eight 64-point chunks per wave)
@@ -1049,13 +1055,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
   for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
   // bucket bases = exclusive scan of the bucket sizes, by every block for itself; block 0 keeps them for k1_finalize
   block_scan_array(total, cursor, K, kK1Threads, s_scan, false);
-  __syncthreads();
+  lds_barrier();
   if (b == 0) {
     for (int k = threadIdx.x; k <= K; k += kK1Threads) bucket_base[k] = cursor[k];
     if (threadIdx.x == 0) counts[0] = cursor[K];  // points binned
   }
   for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += cntmat[static_cast<size_t>(b) * K + k];
-  __syncthreads();
+  lds_barrier();
   mark(1);
   // ---- stable split: rounds of 2048 points; wave w ranks the eight 64-point chunks [w * 512, (w + 1) * 512) of the round
   unsigned short* row = tab + wave * K;
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       rk[u] = 0;
       if (r0 + wave * (8 * kWave) + u * kWave < hi) rk[u] = wave_rank(key[u], key[u] >= 0, mtab, row, kbits);  // (uniform: the chunk has points)
     }
-    __syncthreads();
+    lds_barrier();
     if (r0 == lo) mark(2);
     // per bucket: the waves' counts -> exclusive prefix over the waves (in place), the round's total -> the cursor afterwards
     for (int k = threadIdx.x; k < K; k += kK1Threads) {
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       }
       tot[k] = static_cast<unsigned short>(s_);
     }
-    __syncthreads();
+    lds_barrier();
     if (r0 == lo) mark(3);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1100,12 +1106,12 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
         bpts[cursor[key[u]] + row[key[u]] + rk[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (r0 == lo) mark(4);
     if (r0 + kK1Round < hi) {  // (uniform) another round: advance the cursors, clear the counters
       for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += tot[k];
       for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-      __syncthreads();
+      lds_barrier();
     }
   }
 }
@@ -1237,8 +1243,8 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
-  // phase clocks of thread 0 (NDT_K1_STAMPS): cycles spent in 0 histogram + scan, 1 select, 2 rank sort, 3 lane teams,
-  // 4 sums + finish_voxel; 5 = passes, 6 = points, 7 = total
+  // phase clocks of thread 0 (NDT_K1_STAMPS): cycles spent in 0 loads + ranks (or the histogram pass), 1 column / cell scans
+  // and the passes' selection, 2 placement, 3 lane teams, 4 sums + finish_voxel; 5 = passes, 6 = points, 7 = total
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_mark = 0, t_begin = 0;
   unsigned n_passes = 0;
   if (st && threadIdx.x == 0) t_mark = t_begin = stamp();
@@ -1294,7 +1300,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
       p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
     }
-    __syncthreads();  // (the counter rows are cleared)
+    lds_barrier();  // (the counter rows are cleared)
 #pragma unroll
     for (int u = 0; u < kK1PerThread; u++) {
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
@@ -1303,7 +1309,8 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       rk[u] = 0;
       if (u < per_wave) rk[u] = wave_rank(c, c >= 0, mtab, row, wbits);  // (uniform)
     }
-    __syncthreads();
+    lds_barrier();
+    lap(0);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       unsigned s_ = 0;
 #pragma unroll
@@ -1314,8 +1321,9 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       }
       cnt[c] = s_;
     }
-    __syncthreads();
+    lds_barrier();
     k1_scan_cells(cnt, cstart, C, s_u3);
+    lap(1);
 #pragma unroll
     for (int u = 0; u < kK1PerThread; u++) {
       if (cc[u] >= 0) {
@@ -1326,12 +1334,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         sorted_idx[bb + q] = __float_as_int(p[u].w);
       }
     }
-    __syncthreads();
+    lds_barrier();
+    lap(2);
   } else {
     k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
     k1_scan_cells(cnt, cstart, C, s_u3);
+    lap(0);
   }
-  lap(0);
   const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
   // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
@@ -1359,13 +1368,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       }
       s_hi = c;
     }
-    __syncthreads();
+    lds_barrier();
     const int c_hi = s_hi;
     const unsigned base = cstart[c_lo];
     const unsigned n_pass = ((c_hi < C) ? cstart[c_hi] : nb) - base;
     if (n_pass == 0) {  // (uniform)
       c_lo = c_hi;
-      __syncthreads();
+      lds_barrier();
       continue;
     }
     const bool giant = n_pass > static_cast<unsigned>(lds_cap);  // then c_hi == c_lo + 1
@@ -1375,7 +1384,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
     if (!one_shot) {
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
-    __syncthreads();
+    lds_barrier();
     // Select this pass's points, ORDER-PRESERVING.  The bucket holds its points in ascending point index (k1_scatter), and
     // a point's slot inside its cell's segment is its stable rank: points of the cell placed by earlier rounds (cur) +
     // points of the cell in the waves before mine this round (tab, after the column scan) + rank inside my wave
@@ -1411,7 +1420,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           rk[u] = 0;
           if (u < per_wave) rk[u] = wave_rank(c - c_lo, c >= 0, mtab, row, wbits);  // (uniform)
         }
-        __syncthreads();
+        lds_barrier();
         for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // the waves' counts of a cell -> exclusive prefix over the waves, total
           unsigned s_ = 0;
 #pragma unroll
@@ -1422,7 +1431,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           }
           tab[(kBlock / kWave) * wmax + c] = static_cast<unsigned short>(s_);
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < kK1PerThread; u++) {
           if (cc[u] >= 0) {
@@ -1433,13 +1442,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
             sorted_idx[bb + base + q] = __float_as_int(p[u].w);
           }
         }
-        __syncthreads();
+        lds_barrier();
         for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // next round: behind what this one placed; counters cleared
           cur[c_lo + c] += tab[(kBlock / kWave) * wmax + c];
 #pragma unroll
           for (int w = 0; w < kBlock / kWave; w++) tab[w * wmax + c] = 0;
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
     }  // !one_shot
@@ -1465,13 +1474,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
       c_lo = c_hi;
-      __syncthreads();
+      lds_barrier();
       continue;
     }
     lap(2);
     // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
     if (threadIdx.x == 0) s_nteam = 0;
-    __syncthreads();
+    lds_barrier();
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
       const int n_c = static_cast<int>(cnt[c]);
       if (n_c > kTeamCell && n_c >= min_pts) {
@@ -1479,7 +1488,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         s_team_cell[slot] = c;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (s_nteam > 0) {
 #pragma clang fp contract(off)
       const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
@@ -1523,17 +1532,17 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     lap(3);
     // The cells that get a record (min_pts points and more: the reference skips the others at look-up, _impl.hpp:395), compacted
     // into a list first (cur[] is free after the placement): on a sparsely occupied grid -- 4096 cells per bucket for ~200
     // occupied ones at 10 M points / 0.5 m -- a thread per CELL left one lane in twenty with work and every wave ran
     // finish_voxel sixteen times over.  (The order of the list varies from run to run; nothing depends on it.)
     if (threadIdx.x == 0) s_ncand = 0;
-    __syncthreads();
+    lds_barrier();
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock)
       if (static_cast<int>(cnt[c]) >= min_pts) cur[atomicAdd(&s_ncand, 1)] = static_cast<unsigned>(c);
-    __syncthreads();
+    lds_barrier();
     const int n_cand = s_ncand;
     for (int ci = threadIdx.x; ci < n_cand; ci += kBlock) {
       const int c = static_cast<int>(cur[ci]);
@@ -1563,7 +1572,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
-    __syncthreads();  // the LDS arrays are reused by the next pass
+    lds_barrier();  // the LDS arrays are reused by the next pass
     lap(4);
   }
   if (st && threadIdx.x == 0) {
@@ -1578,9 +1587,9 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     unsigned v = n_ok;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    __syncthreads();  // (s_u3 is free)
+    lds_barrier();  // (s_u3 is free)
     if ((threadIdx.x & (kWave - 1)) == 0) s_u3[threadIdx.x / kWave].pts = v;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
       unsigned t = 0;
       for (int w = 0; w < kBlock / kWave; w++) t += s_u3[w].pts;
