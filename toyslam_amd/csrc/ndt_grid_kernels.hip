@@ -849,12 +849,6 @@ __device__ __forceinline__ int k1_key_bits(int K) {  // bits of the largest buck
   return b;
 }
 
-// Barrier for data exchanged through LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL loads and stores
-// (s_waitcnt vmcnt(0)): after a round of scattered 16-byte stores that is 3-8 k cycles of a block doing nothing -- a third of
-// k1_scatter's rounds at 10 M points, a fifth of a k1_finalize block.  Nothing in these kernels reads global memory that another
-// wave of the same block wrote (the one exception, a crowded cell's scratch, keeps its fence + __syncthreads()).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 constexpr int kK1Threads = 256;              // k1_hist / k1_scatter
 constexpr int kK1Waves = kK1Threads / kWave;  // 4
 constexpr int kK1Round = 8 * kK1Threads;     // points one block of k1_scatter ranks per round (eight 64-point chunks per wave)
@@ -1055,13 +1049,13 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
   for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
   // bucket bases = exclusive scan of the bucket sizes, by every block for itself; block 0 keeps them for k1_finalize
   block_scan_array(total, cursor, K, kK1Threads, s_scan, false);
-  lds_barrier();
+  __syncthreads();
   if (b == 0) {
     for (int k = threadIdx.x; k <= K; k += kK1Threads) bucket_base[k] = cursor[k];
     if (threadIdx.x == 0) counts[0] = cursor[K];  // points binned
   }
   for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += cntmat[static_cast<size_t>(b) * K + k];
-  lds_barrier();
+  __syncthreads();
   mark(1);
   // ---- stable split: rounds of 2048 points; wave w ranks the eight 64-point chunks [w * 512, (w + 1) * 512) of the round
   unsigned short* row = tab + wave * K;
@@ -1084,7 +1078,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       rk[u] = 0;
       if (r0 + wave * (8 * kWave) + u * kWave < hi) rk[u] = wave_rank(key[u], key[u] >= 0, mtab, row, kbits);  // (uniform: the chunk has points)
     }
-    lds_barrier();
+    __syncthreads();
     if (r0 == lo) mark(2);
     // per bucket: the waves' counts -> exclusive prefix over the waves (in place), the round's total -> the cursor afterwards
     for (int k = threadIdx.x; k < K; k += kK1Threads) {
@@ -1097,7 +1091,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
       }
       tot[k] = static_cast<unsigned short>(s_);
     }
-    lds_barrier();
+    __syncthreads();
     if (r0 == lo) mark(3);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1106,12 +1100,12 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
         bpts[cursor[key[u]] + row[key[u]] + rk[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
       }
     }
-    lds_barrier();
+    __syncthreads();
     if (r0 == lo) mark(4);
     if (r0 + kK1Round < hi) {  // (uniform) another round: advance the cursors, clear the counters
       for (int k = threadIdx.x; k < K; k += kK1Threads) cursor[k] += tot[k];
       for (int i = threadIdx.x; i < kK1Waves * K / 2; i += kK1Threads) reinterpret_cast<unsigned*>(tab)[i] = 0u;
-      lds_barrier();
+      __syncthreads();
     }
   }
 }
@@ -1300,7 +1294,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
       p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
     }
-    lds_barrier();  // (the counter rows are cleared)
+    __syncthreads();  // (the counter rows are cleared)
 #pragma unroll
     for (int u = 0; u < kK1PerThread; u++) {
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
@@ -1309,7 +1303,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       rk[u] = 0;
       if (u < per_wave) rk[u] = wave_rank(c, c >= 0, mtab, row, wbits);  // (uniform)
     }
-    lds_barrier();
+    __syncthreads();
     lap(0);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       unsigned s_ = 0;
@@ -1321,7 +1315,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       }
       cnt[c] = s_;
     }
-    lds_barrier();
+    __syncthreads();
     k1_scan_cells(cnt, cstart, C, s_u3);
     lap(1);
 #pragma unroll
@@ -1334,7 +1328,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         sorted_idx[bb + q] = __float_as_int(p[u].w);
       }
     }
-    lds_barrier();
+    __syncthreads();
     lap(2);
   } else {
     k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
@@ -1368,13 +1362,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       }
       s_hi = c;
     }
-    lds_barrier();
+    __syncthreads();
     const int c_hi = s_hi;
     const unsigned base = cstart[c_lo];
     const unsigned n_pass = ((c_hi < C) ? cstart[c_hi] : nb) - base;
     if (n_pass == 0) {  // (uniform)
       c_lo = c_hi;
-      lds_barrier();
+      __syncthreads();
       continue;
     }
     const bool giant = n_pass > static_cast<unsigned>(lds_cap);  // then c_hi == c_lo + 1
@@ -1384,7 +1378,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     float* pz = giant ? reinterpret_cast<float*>(scratch + 3 * static_cast<size_t>(n_total) + bb + base) : oz;
     if (!one_shot) {
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) cur[c] = cstart[c] - base;
-    lds_barrier();
+    __syncthreads();
     // Select this pass's points, ORDER-PRESERVING.  The bucket holds its points in ascending point index (k1_scatter), and
     // a point's slot inside its cell's segment is its stable rank: points of the cell placed by earlier rounds (cur) +
     // points of the cell in the waves before mine this round (tab, after the column scan) + rank inside my wave
@@ -1420,7 +1414,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           rk[u] = 0;
           if (u < per_wave) rk[u] = wave_rank(c - c_lo, c >= 0, mtab, row, wbits);  // (uniform)
         }
-        lds_barrier();
+        __syncthreads();
         for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // the waves' counts of a cell -> exclusive prefix over the waves, total
           unsigned s_ = 0;
 #pragma unroll
@@ -1431,7 +1425,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
           }
           tab[(kBlock / kWave) * wmax + c] = static_cast<unsigned short>(s_);
         }
-        lds_barrier();
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < kK1PerThread; u++) {
           if (cc[u] >= 0) {
@@ -1442,13 +1436,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
             sorted_idx[bb + base + q] = __float_as_int(p[u].w);
           }
         }
-        lds_barrier();
+        __syncthreads();
         for (int c = threadIdx.x; c < c_hi - c_lo; c += kBlock) {  // next round: behind what this one placed; counters cleared
           cur[c_lo + c] += tab[(kBlock / kWave) * wmax + c];
 #pragma unroll
           for (int w = 0; w < kBlock / kWave; w++) tab[w * wmax + c] = 0;
         }
-        lds_barrier();
+        __syncthreads();
       }
     }
     }  // !one_shot
@@ -1474,13 +1468,13 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
       }
       c_lo = c_hi;
-      lds_barrier();
+      __syncthreads();
       continue;
     }
     lap(2);
     // ---- crowded cells of this pass: a team of 16 lanes per cell, a lane per accumulator (see kTeamCell) ----
     if (threadIdx.x == 0) s_nteam = 0;
-    lds_barrier();
+    __syncthreads();
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock) {
       const int n_c = static_cast<int>(cnt[c]);
       if (n_c > kTeamCell && n_c >= min_pts) {
@@ -1488,7 +1482,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         s_team_cell[slot] = c;
       }
     }
-    lds_barrier();
+    __syncthreads();
     if (s_nteam > 0) {
 #pragma clang fp contract(off)
       const int tl = threadIdx.x & (kTeamLanes - 1), team = threadIdx.x / kTeamLanes;
@@ -1532,17 +1526,17 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
         }
       }
     }
-    lds_barrier();
+    __syncthreads();
     lap(3);
     // The cells that get a record (min_pts points and more: the reference skips the others at look-up, _impl.hpp:395), compacted
     // into a list first (cur[] is free after the placement): on a sparsely occupied grid -- 4096 cells per bucket for ~200
     // occupied ones at 10 M points / 0.5 m -- a thread per CELL left one lane in twenty with work and every wave ran
     // finish_voxel sixteen times over.  (The order of the list varies from run to run; nothing depends on it.)
     if (threadIdx.x == 0) s_ncand = 0;
-    lds_barrier();
+    __syncthreads();
     for (int c = c_lo + threadIdx.x; c < c_hi; c += kBlock)
       if (static_cast<int>(cnt[c]) >= min_pts) cur[atomicAdd(&s_ncand, 1)] = static_cast<unsigned>(c);
-    lds_barrier();
+    __syncthreads();
     const int n_cand = s_ncand;
     for (int ci = threadIdx.x; ci < n_cand; ci += kBlock) {
       const int c = static_cast<int>(cur[ci]);
@@ -1572,7 +1566,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
       n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
     }
     c_lo = c_hi;
-    lds_barrier();  // the LDS arrays are reused by the next pass
+    __syncthreads();  // the LDS arrays are reused by the next pass
     lap(4);
   }
   if (st && threadIdx.x == 0) {
@@ -1587,9 +1581,9 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     unsigned v = n_ok;
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    lds_barrier();  // (s_u3 is free)
+    __syncthreads();  // (s_u3 is free)
     if ((threadIdx.x & (kWave - 1)) == 0) s_u3[threadIdx.x / kWave].pts = v;
-    lds_barrier();
+    __syncthreads();
     if (threadIdx.x == 0) {
       unsigned t = 0;
       for (int w = 0; w < kBlock / kWave; w++) t += s_u3[w].pts;
