@@ -78,7 +78,7 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
   static const bool spin_wait = [] { const char* v = getenv("NDT_SPIN_WAIT"); return v ? atoi(v) != 0 : true; }();
   static const bool fuse = [] { const char* v = getenv("NDT_K2_FUSED"); return v ? atoi(v) != 0 : true; }();
   const bool fused = fuse && spin_wait && rq.kind != ndt::EVAL_HESSIAN_F64 && ndt::derivative_variant() == 0 && !h->allreduce && !h->comm;
-  const int nblk = fused ? ndt::fused_blocks(n, h->cu_partition ? h->cu_count : 0) : ndt::derivative_blocks(n, h->search);
+  const int nblk = fused ? ndt::fused_blocks(n, h->cu_count, h->cu_partition != 0) : ndt::derivative_blocks(n, h->search);
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
   if (!h->ticket.p) {
     HIP_TRY(h->ticket.reserve(32 * 17));  // top counter + 16 shard counters, one per 128-B line (k_derivatives_fused)
@@ -97,8 +97,8 @@ ndt_status evaluate_single(ndt_context* h, const ndt::EvalRequest& rq, ndt::Eval
     fill_eval_params(rq, gs, kd_radius2(h->resolution), P);
     if (fused) {
       seq = ++h->eval_seq;
-      HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, h->partials.p,
-                                            h->ticket.p, h->host_pub, seq, h->stream));
+      HIP_TRY(ndt::launch_derivatives_fused(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nblk, ndt::points_per_block(n, h->cu_count),
+                                            h->partials.p, h->ticket.p, h->host_pub, seq, h->stream));
     } else {
       HIP_TRY(ndt::launch_derivatives(src, n, gv, P, h->search, rq.kind == ndt::EVAL_WITH_HESSIAN, nullptr, nullptr, 1, nblk, nblk,
                                       h->partials.p, h->stream));
@@ -255,7 +255,7 @@ ndt_status server_start(ndt_context* h) {
   unsigned* const counter_now = h->server_counter.p + h->server_counter_set * ndt::kServerCounterWords;
   unsigned* const counter_next = h->server_counter.p + (h->server_counter_set ^ 1) * ndt::kServerCounterWords;
   // one 512-thread block per CU at most: every block must be resident for the round to complete
-  const int ppb = ndt::points_per_block(n);
+  const int ppb = ndt::points_per_block(n, h->cu_count);
   int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + ppb - 1) / ppb));
   h->server_blocks = nblk;
   HIP_TRY(h->partials.reserve(static_cast<size_t>(nblk) * ndt::kEvalStride));
@@ -269,7 +269,7 @@ ndt_status server_start(ndt_context* h) {
   std::memcpy(&pad_bits, &r2, sizeof(int));
   h->server_timed = h->profile_server;
   if (h->server_timed) HIP_TRY(hipEventRecord(h->ev_a, h->stream));
-  HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk,
+  HIP_TRY(ndt::launch_eval_server(h->source->k2_pts(), n, h->grid->view(), h->search, h->server_host_mb, dev_mb, nblk, ppb,
                                   h->partials.p, counter_now, h->host_pub, h->eval_seq + 1, idle_ticks, gs.d1,
                                   gs.d2, pad_bits, h->source->pts.p, h->out_cloud.p, n_out, h->stream,
                                   h->server_want_dbg ? h->server_dbg.p : nullptr,
@@ -588,7 +588,7 @@ ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double*
   if (s) return s;
   std::lock_guard<std::mutex> turn(server_device_mutex(h->device));
   const int n = h->source->k2_n();
-  const int ppb = ndt::points_per_block(n);
+  const int ppb = ndt::points_per_block(n, h->cu_count);
   const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (n + ppb - 1) / ppb));
   const size_t mb_bytes = ndt::server_mailbox_bytes();
   DevBuf<unsigned char> mb;
@@ -620,7 +620,7 @@ ndt_status ndt_diag_selfdrive(ndt_handle h, const double* p, int rounds, double*
     HIP_TRY(hipMemcpyAsync(mb.p, staged, mb_bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->server_counter.p, 0, 32 * (1 + ndt::kServerParts) * sizeof(unsigned), h->stream));
     HIP_TRY(hipEventRecord(e0, h->stream));
-    HIP_TRY(ndt::launch_selfdrive(h->source->k2_pts(), n, h->grid->view(), h->search, mb.p, nblk, h->partials.p, h->server_counter.p, parts.p,
+    HIP_TRY(ndt::launch_selfdrive(h->source->k2_pts(), n, h->grid->view(), h->search, mb.p, nblk, ppb, h->partials.p, h->server_counter.p, parts.p,
                                   h->host_pub, first_seq, rounds, with_body, gs.d1, gs.d2, pad_bits, h->stream));
     HIP_TRY(hipEventRecord(e1, h->stream));
     HIP_TRY(hipEventSynchronize(e1));
@@ -675,7 +675,7 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   {  // device-side stamps of the LAST round (with Hessian), s_memrealtime ticks of 10 ns
     std::vector<unsigned long long> d(8 + 10 * 1024);
     HIP_TRY(hipMemcpy(d.data(), h->server_dbg.p, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    const int ppb_diag = ndt::points_per_block(h->source->k2_n());
+    const int ppb_diag = ndt::points_per_block(h->source->k2_n(), h->cu_count);
     const int nblk = std::max(1, std::min(h->cu_count > 0 ? h->cu_count : 64, (h->source->k2_n() + ppb_diag - 1) / ppb_diag));
     unsigned long long got_min = ~0ull, got_max = 0, tk_min = ~0ull, tk_max = 0;
     for (int b = 0; b < nblk; b++) {

@@ -229,10 +229,13 @@ hipError_t launch_derivatives(const float4* src, int n, const GridView& gv, cons
                               int n_blocks, double* partials, hipStream_t stream);
 // Single launch: derivatives + fixed-order final sum by the last-arriving block + publication of
 // the packed row and `seq` into pinned host memory (out_row).  counter: one zero-initialised u32.
-int fused_blocks(int n, int cus = 0);  // cus: CUs of the stream's partition when it has one (two blocks per CU at most)
-int points_per_block(int n);  // 256 for small scans (only half of a block's lanes carry points), else 512
+// points per 512-thread block of the latency kernels: a block per CU of the handle's `cus` while 512 points per block allow
+// that (64 at least: small scans use only the first lanes of a block); blocks of the one-launch kernel (two per CU at most
+// on a CU partition)
+int points_per_block(int n, int cus);
+int fused_blocks(int n, int cus, bool partition);
 hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
-                                    bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                                    bool want_hessian, int n_blocks, int ppb, double* partials, unsigned* counter, double* out_row,
                                     unsigned long long seq, hipStream_t stream);
 // Persistent evaluation server (one launch per align): see ndt_kernels.hip.
 constexpr int kPublishSlots = 64;  // tagged publication row: value k as words 2k, 2k+1 = (half << 32) | seq32
@@ -245,11 +248,11 @@ void server_reset_mailbox(void* host_mailbox);
 void server_post(void* host_mailbox, unsigned long long seq, int kind, const float* T12, const double* cos_sin6);
 unsigned long long server_dead_word(const void* host_mailbox);
 // diagnostic: the server's round driven from the device (k_selfdrive, ndt_latency.hip); server_post fills a host copy of the mailbox
-hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, double* partials,
+hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, int ppb, double* partials,
                             unsigned* counter, double* parts, double* out_row, unsigned long long first_seq, int rounds, int with_body,
                             double gauss_d1, double gauss_d2, int param_pad, hipStream_t stream);
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
-                              void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                              void* dev_mailbox, int n_blocks, int ppb, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
                               unsigned long long* dbg, int direct, float4* out_host, unsigned* counter_next);

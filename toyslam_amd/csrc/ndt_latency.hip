@@ -584,29 +584,36 @@ constexpr int kFusedTPB = 512;
 // VALU-issue-bound: two waves on a SIMD take ~4.4 us where one takes ~2.9.  A scan small enough to leave most of the
 // chip empty anyway (the mapping nodes' real size: 16 k points = 32 full blocks on 256 CUs) therefore fills only the
 // first half of each block's lanes -- twice the blocks, every busy wave with a SIMD of its own.
-int points_per_block(int n) {
+int points_per_block(int n, int cus) {
   static const int forced = env_int("NDT_K2_PPB", 0);
-  if (forced == 256 || forced == 512) return forced;
-  return (n <= 65536) ? 256 : 512;
+  if (forced >= 64 && forced <= 512 && forced % 8 == 0) return forced;
+  // A block per CU while 512 points per block allow that (then 512, grid-strided): an evaluation's probes and record gathers
+  // go through each CU's 64 B / clock vector memory path, and the fewer of them a CU has, the sooner its waves compute; with
+  // up to 256 points per block every busy wave also has a SIMD of its own.  Measured (us per evaluation, set U): 16 k points
+  // 10.7 at 256 points per block, 9.7 at 64; 30 k 11.4 -> 10.7 at 128; 48 k 12.0 -> 11.4 at 192; 100 k 12.2 at 512 (196
+  // blocks) -> 11.6 at 392 (256 blocks).  More blocks than CUs is the one thing to avoid: 48 k at 128 per block, 14.3.
+  if (cus <= 0) cus = 256;
+  const int per_cu = ((n + cus - 1) / cus + 7) / 8 * 8;
+  return std::max(64, std::min(512, per_cu));
 }
-int fused_blocks(int n, int cus) {
+int fused_blocks(int n, int cus, bool partition) {
   // two 512-thread blocks per CU (126 VGPRs) = every block resident at once on 256 CUs; measured on a 2M-point scan:
   // 256 / 384 / 512 / 640 / 768 / 1024 / 2048 blocks -> 449 / 446 / 538 / 465 / 464 / 488 / 432 registrations/s
   static const int cap = env_int("NDT_K2_MAX_BLOCKS", 512);
-  const int ppb = points_per_block(n);
+  const int ppb = points_per_block(n, cus);
   size_t b = (static_cast<size_t>(n) + ppb - 1) / ppb;
   if (b < 1) b = 1;
   if (b > static_cast<size_t>(cap)) b = cap;
-  if (cus > 0 && b > static_cast<size_t>(2 * cus)) b = 2 * cus;  // a handle on a CU partition: still all blocks resident at once
+  if (partition && cus > 0 && b > static_cast<size_t>(2 * cus)) b = 2 * cus;  // a handle on a CU partition: still all blocks resident at once
   return static_cast<int>(b);
 }
 
 hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv, const EvalParams& P, int search,
-                                    bool want_hessian, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                                    bool want_hessian, int n_blocks, int ppb, double* partials, unsigned* counter, double* out_row,
                                     unsigned long long seq, hipStream_t stream) {
 #define NDT_LAUNCH_FUSED(NNB, H)                                                                                        \
   hipLaunchKernelGGL((k_derivatives_fused<NNB, H, kFusedTPB>), dim3(n_blocks), dim3(kFusedTPB), 0, stream, src, n, gv, P, \
-                     partials, counter, out_row, seq, points_per_block(n))
+                     partials, counter, out_row, seq, ppb)
   if (search == 0) {
     if (want_hessian) NDT_LAUNCH_FUSED(27, true); else NDT_LAUNCH_FUSED(27, false);
   } else if (search == 1) {
@@ -647,12 +654,12 @@ void server_post(void* host_mailbox, unsigned long long seq, int kind, const flo
     _mm_stream_si128(reinterpret_cast<__m128i*>(&mb->cmd[2 * i]), _mm_load_si128(reinterpret_cast<const __m128i*>(&c[2 * i])));
   _mm_sfence();
 }
-hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, double* partials,
+hipError_t launch_selfdrive(const float4* src, int n, const GridView& gv, int search, void* dev_mailbox, int n_blocks, int ppb, double* partials,
                             unsigned* counter, double* parts, double* out_row, unsigned long long first_seq, int rounds, int with_body,
                             double gauss_d1, double gauss_d2, int param_pad, hipStream_t stream) {
   if (search != 2) return hipErrorInvalidValue;  // DIRECT7 only: a diagnostic
   hipLaunchKernelGGL(k_selfdrive<7>, dim3(n_blocks), dim3(kServerTPB), 0, stream, src, n, gv, static_cast<ServerMailbox*>(dev_mailbox), partials,
-                     counter, parts, out_row, first_seq, rounds, with_body, gauss_d1, gauss_d2, param_pad, points_per_block(n));
+                     counter, parts, out_row, first_seq, rounds, with_body, gauss_d1, gauss_d2, param_pad, ppb);
   return hipGetLastError();
 }
 unsigned long long server_dead_word(const void* host_mailbox) {
@@ -661,11 +668,10 @@ unsigned long long server_dead_word(const void* host_mailbox) {
 void server_reset_mailbox(void* host_mailbox) { std::memset(host_mailbox, 0, sizeof(ServerMailbox)); }
 
 hipError_t launch_eval_server(const float4* src, int n, const GridView& gv, int search, void* host_mailbox,
-                              void* dev_mailbox, int n_blocks, double* partials, unsigned* counter, double* out_row,
+                              void* dev_mailbox, int n_blocks, int ppb, double* partials, unsigned* counter, double* out_row,
                               unsigned long long first_seq, unsigned long long idle_ticks, double gauss_d1, double gauss_d2,
                               int param_pad, const float4* out_src, float4* out_dst, int out_n, hipStream_t stream,
                               unsigned long long* dbg, int direct, float4* out_host, unsigned* counter_next) {
-  const int ppb = points_per_block(n);
   ServerMailbox* hm = static_cast<ServerMailbox*>(host_mailbox);
   ServerMailbox* dm = static_cast<ServerMailbox*>(dev_mailbox);
   if (search == 0)
