@@ -119,7 +119,7 @@ ndt_status ndt_share_input_target(ndt_handle dst, ndt_handle src);
  * Scans of up to 512 points per CU of the registration partition (114 688 points at 224 CUs) give the same bits in any
  * partition; above that the persistent kernel's workgroup count is capped by the partition's CUs and the partial sums are
  * added in another (still fixed) order, as they are between the persistent and the per-evaluation kernels at that size.
- * Call before the handle is used, or between calls (the stream is replaced).
+ * Call before the handle is used, or between calls (the handle waits for its work in flight and moves to the stream of the new partition; it keeps the streams it has had until ndt_destroy).
  * ndt_get_cu_partition reports the partition and the CUs the stream really got (the device's count when masks are
  * unavailable). */
 ndt_status ndt_set_cu_partition(ndt_handle h, int partition);

@@ -309,7 +309,7 @@ def test_cu_partitions_and_shared_targets(mods, pair):
         stop.set()
         th.join()
     assert not errs and n_prep[0] > 0
-    # a live handle changes partition (its stream is replaced) and keeps working
+    # a live handle changes partition (it moves to the stream of the new partition) and keeps working
     reg.setCuPartition(0)
     reg.align()
     assert np.array_equal(reg.getFinalTransformation(), T_ref)
@@ -1234,10 +1234,15 @@ def test_evaluation_server_gives_up_when_the_host_goes_quiet(mods, pair):
     g.setInputTarget(t)
     g.setInputSource(s)
     p = np.array([0.1, -0.05, 0.02, 0.003, -0.002, 0.01])
+    # (the launch path in the middle is the one-launch kernel, which cuts the scan into the server's blocks; with
+    # NDT_K2_FUSED=0 / NDT_SPIN_WAIT=0 it is the throughput kernel and its own blocks: same sums to the last bits but two)
+    same_blocks = os.environ.get("NDT_K2_FUSED", "1") != "0" and os.environ.get("NDT_SPIN_WAIT", "1") != "0"
     served, scores = g.selftest_server_idle(p, 150)
-    assert not served and scores[0] == scores[1] == scores[2] and scores[0] != 0
+    assert not served and scores[0] == scores[2] and scores[0] != 0
+    assert scores[1] == scores[0] if same_blocks else abs(scores[1] - scores[0]) <= 1e-13 * abs(scores[0])
     served, scores = g.selftest_server_idle(p, 2)
-    assert served and scores[0] == scores[1] == scores[2]
+    assert served and scores[0] == scores[2]
+    assert scores[1] == scores[0] if same_blocks else abs(scores[1] - scores[0]) <= 1e-13 * abs(scores[0])
     g.align()  # and the handle is fine afterwards
     assert g.hasConverged()
 

@@ -218,16 +218,28 @@ ndt_status ndt_get_stats(ndt_handle h, int* n_evals, int* n_hess, double* mean_n
 ndt_status ndt_set_cu_partition(ndt_handle h, int partition) {
   if (!h || partition < 0 || partition > 2) return fail(NDT_ERR_INVALID, "bad arguments");
   if (h->cu_partition == partition) return NDT_OK;
+  const int old_partition = h->cu_partition;
   h->cu_partition = partition;
   if (!h->device_ready) return NDT_OK;  // the stream is created on first use
   HIP_TRY(hipSetDevice(h->device));
   ndt_status s = server_stop(h);
   if (s) return s;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  DevPool::instance().forget_stream(h->stream);  // blocks cached for the old stream: nobody will ask for them again
-  HIP_TRY(hipStreamDestroy(h->stream));
-  h->stream = nullptr;
-  s = create_stream(h);
+  // The handle keeps the streams it has had, one per partition, and switches between them: destroying a stream here --
+  // hipStreamDestroy of the plain stream of a handle whose other handle had been fed from pageable memory on a CU-masked
+  // stream by a second host thread -- never returned (ROCm 7.2; tools/test_switches.sh: NDT_HOST_STAGE_MAX=0, NDT_SORT_SOURCE=1).
+  // Buffers the handle still holds go back to the pool of the stream they were allocated for; only this handle uses it.
+  const int total = h->cu_total > 0 ? h->cu_total : 256;
+  h->partition_stream[old_partition] = h->stream;
+  h->stream_masked[old_partition] = h->cu_count != total;
+  h->stream = h->partition_stream[partition];
+  if (h->stream) {
+    h->cu_count = h->stream_masked[partition] ? (partition == 1 ? total - side_cus() : side_cus()) : total;
+  } else {
+    s = create_stream(h);
+    h->stream_masked[partition] = h->cu_count != total;
+    h->partition_stream[partition] = h->stream;
+  }
   tls_pool_stream = h->stream;
   return s;
 }

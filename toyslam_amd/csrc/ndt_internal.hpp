@@ -256,6 +256,8 @@ struct ndt_context {
   int device = 0;
   bool device_ready = false;
   hipStream_t stream = nullptr;
+  bool stream_masked[3] = {false, false, false};
+  hipStream_t partition_stream[3] = {nullptr, nullptr, nullptr};  // the streams this handle has had, by CU partition (ndt_set_cu_partition switches, nothing is destroyed before the handle is)
   // parameters (ctor defaults ndt_omp_impl.hpp:47-76, voxel_grid_covariance_omp.h:208-223)
   float resolution = 1.0f;
   double step_size = 0.1, outlier_ratio = 0.55, trans_eps = 0.1;
@@ -369,6 +371,13 @@ struct ndt_context {
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
     if (ev_d) (void)hipEventDestroy(ev_d);
+    for (hipStream_t& ps : partition_stream) {
+      if (ps && ps != stream) {
+        DevPool::instance().forget_stream(ps);
+        (void)hipStreamDestroy(ps);
+      }
+      ps = nullptr;
+    }
     if (stream) {
       DevPool::instance().forget_stream(stream);
       (void)hipStreamDestroy(stream);
