@@ -116,9 +116,9 @@ ndt_status ndt_share_input_target(ndt_handle dst, ndt_handle src);
  *   1  the registration partition: all CUs but the last NDT_SIDE_CUS (default 32) -- for the handles that align;
  *   2  the side partition: those NDT_SIDE_CUS CUs -- for handles that only prepare inputs (ndt_set_input_*,
  *      ndt_voxel_grid_filter*, ndt_map_update*) and hand them over with ndt_share_input_source / ndt_share_input_target.
- * Scans of up to 512 points per CU of the registration partition (114 688 points at 224 CUs) give the same bits in any
- * partition; above that the persistent kernel's workgroup count is capped by the partition's CUs and the partial sums are
- * added in another (still fixed) order, as they are between the persistent and the per-evaluation kernels at that size.
+ * The latency kernels cut a scan into one workgroup per CU of the handle's partition, so a partitioned handle adds the same
+ * per-point terms in another (still fixed) order: sums equal to the unpartitioned handle's to the last bits of an f64, as
+ * between the lock-step batches and ndt_align; grids, voxel filters and map updates are bit-identical in any partition.
  * Call before the handle is used, or between calls (the handle waits for its work in flight and moves to the stream of the new partition; it keeps the streams it has had until ndt_destroy).
  * ndt_get_cu_partition reports the partition and the CUs the stream really got (the device's count when masks are
  * unavailable). */
