@@ -40,7 +40,7 @@ class PcdSequence {
   // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following kSlots - 1 files are being
   // read and parsed, one background thread each (a 2M-point scan takes longer to read and parse than to register).
   int next(Scan& out, std::string& err);
-  static constexpr size_t kSlots = 6;
+  static constexpr size_t kSlots = 10;  // (six left a 2 M-point sequence waiting 0.6 ms per scan for its files: a file is ~8 ms of read + repack)
 
  private:
   struct Entry {
