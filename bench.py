@@ -883,7 +883,7 @@ def run_pyramid(args, ndt, clouds, tgt, device, steps, warmup, binding, world=1,
             "value": world * steps * n_scans / dt, "unit": "scans/s", "n_gpus": world, "steps": steps, "warmup": max(1, warmup),
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[4]: %d x 2M-pt PCD scans per GPU streamed from disk (nine files read and parsed ahead, page-locked "
+            "config": {"workload": "configs[4]: %d x 2M-pt PCD scans per GPU streamed from disk (five files read and parsed ahead, page-locked "
                                    "buffers), three resident grids 2.0 / 1.0 / 0.5 m over one 10M-pt target (%g m scene), each level's result "
                                    "the next level's guess; one independent sequence per rank" % (n_scans, args.extent)},
             "world_size": world, "pass_ms_rank0": pass_ms, "per_level_ms": r["per_level_ms"], "upload_ms_per_scan": r["upload_ms"], "wait_for_file_ms_per_scan": r["wait_ms"],

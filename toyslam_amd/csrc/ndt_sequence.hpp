@@ -40,7 +40,7 @@ class PcdSequence {
   // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following kSlots - 1 files are being
   // read and parsed, one background thread each (a 2M-point scan takes longer to read and parse than to register).
   int next(Scan& out, std::string& err);
-  static constexpr size_t kSlots = 10;  // (six left a 2 M-point sequence waiting 0.6 ms per scan for its files: a file is ~8 ms of read + repack)
+  static constexpr size_t kSlots = 6;  // (ten: no faster -- the readers share the host's memory bandwidth: 2 M-point sequence 229-237 scans/s on the box that gave six 194-281)
 
  private:
   struct Entry {
