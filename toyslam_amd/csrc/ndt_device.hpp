@@ -357,16 +357,15 @@ struct RecRegs {
 };
 __device__ __forceinline__ RecRegs load_rec(const VoxelRec* __restrict__ recs, int r) {
   const float4* p = reinterpret_cast<const float4*>(recs + r);
-  const float4 a = p[0], b = p[1], c = p[2];
-  const float2 d = *reinterpret_cast<const float2*>(p + 3);
+  const float4 a = p[0], b = p[1], c = p[2];  // mean x, y | mean z, c00, c01 | c02, c12, c11, c22
   RecRegs o;
   o.mx = __hiloint2double(__float_as_int(a.y), __float_as_int(a.x));
   o.my = __hiloint2double(__float_as_int(a.w), __float_as_int(a.z));
   o.mz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
   o.p0 = f2{b.z, b.w};
-  o.p1 = f2{c.x, c.y};
-  o.p2 = f2{c.z, c.w};
-  o.p3 = f2{d.x, d.y};
+  o.p1 = f2{b.w, c.z};
+  o.p2 = f2{c.x, c.y};
+  o.p3 = f2{c.z, c.w};
   return o;
 }
 
@@ -575,12 +574,30 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
       const unsigned centre = lut_index(gv.g, vi, vj, vk);
       int rec[NNB];
       bool any = false;
+      if (NNB == 7 && gv.g.hash_bits == 0) {
+        // the voxel and its two x neighbours are three consecutive table entries: one 12-byte load instead of three probes
+        // (every load instruction of every wave goes through the CU's one vector memory path); same entries, same order
+        struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
+        const Int3 t = *reinterpret_cast<const Int3*>(gv.lut + (centre - 1u));
+        rec[0] = t.b;
+        rec[1 % NNB] = t.c;
+        rec[2 % NNB] = t.a;
 #pragma unroll
-      for (int k = 0; k < NNB; k++) {
-        int dx, dy, dz;
-        nb_offset<NNB>(k, dx, dy, dz);
-        rec[k] = probe(gv, vi, vj, vk, centre, dx, dy, dz);
-        any |= (rec[k] >= 0);
+        for (int k = 3; k < NNB; k++) {
+          int dx, dy, dz;
+          nb_offset<NNB>(k, dx, dy, dz);
+          rec[k] = probe(gv, vi, vj, vk, centre, dx, dy, dz);
+        }
+#pragma unroll
+        for (int k = 0; k < NNB; k++) any |= (rec[k] >= 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NNB; k++) {
+          int dx, dy, dz;
+          nb_offset<NNB>(k, dx, dy, dz);
+          rec[k] = probe(gv, vi, vj, vk, centre, dx, dy, dz);
+          any |= (rec[k] >= 0);
+        }
       }
       if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[2] = stamp(); }
       if (any) {

@@ -659,12 +659,10 @@ __device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o,
       rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
       const float c00 = static_cast<float>(icov[0][0]), c01 = static_cast<float>(icov[0][1]), c02 = static_cast<float>(icov[0][2]);
       const float c11 = static_cast<float>(icov[1][1]), c12 = static_cast<float>(icov[1][2]), c22 = static_cast<float>(icov[2][2]);
-      rec.p0[0] = c00; rec.p0[1] = c01;
-      rec.p1[0] = c01; rec.p1[1] = c11;
-      rec.p2[0] = c02; rec.p2[1] = c12;
-      rec.p3[0] = c11; rec.p3[1] = c22;
+      rec.c[0] = c00; rec.c[1] = c01; rec.c[2] = c02;
+      rec.c[3] = c12; rec.c[4] = c11; rec.c[5] = c22;
       rec.n = cnt;
-      rec.pad = 0;
+      rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
       recs[r] = rec;
       VoxelSide side;
       side.cx = fx; side.cy = fy; side.cz = fz; side.pad = 0.0f;

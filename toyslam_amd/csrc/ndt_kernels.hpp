@@ -11,17 +11,17 @@ namespace ndt {
 // One valid target voxel, exactly one 64-byte sector (half a 128-B L2 line):
 //   mean  : 3 x f64  -- the reference subtracts the f64 mean from the f32 point
 //                       in f64 and only then rounds to f32 (ndt_omp_impl.hpp:262,492)
-//   icov  : the six entries of Sigma^-1 (symmetric) as the f32 the reference casts to per use (:494), laid out
-//           as the four register PAIRS the packed f32 math of the derivative kernels multiplies by
-//           (v_pk_fma_f32 takes both halves of an operand from ONE aligned register pair):
-//             p0 = (c00, c01)   p1 = (c01, c11)   p2 = (c02, c12)   p3 = (c11, c22)
-//           -- c01 and c11 are stored twice so that no pair has to be assembled with moves
+//   icov  : the six entries of Sigma^-1 (symmetric) as the f32 the reference casts to per use (:494), in the order
+//           c00 c01 c02 c12 c11 c22: with the means the FIRST 48 BYTES of the record -- three 16-byte loads per neighbour
+//           (every gather instruction of every wave goes through the CU's one vector memory path: round 2's layout stored
+//           c01 and c11 twice, so that all four register pairs of the packed math came out of the loads ready-made, and
+//           needed a fourth load).  Pairs (c00,c01) (c02,c12) (c11,c22) are adjacent; (c01,c11) is assembled with a move.
 //   n     : point count.  (The voxel centroid and the f64 inverse covariance live in the side sector, VoxelSide.)
 struct alignas(64) VoxelRec {
   double mean[3];
-  float p0[2], p1[2], p2[2], p3[2];
+  float c[6];
   int n;
-  int pad;
+  int pad[3];
 };
 static_assert(sizeof(VoxelRec) == 64, "VoxelRec must be one 64-B sector");
 // What the f32 evaluation does not read, one 64-B sector per record again: the voxel centroid (voxel_centroids_ entry,
