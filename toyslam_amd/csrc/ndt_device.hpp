@@ -355,6 +355,8 @@ struct RecRegs {
   double mx, my, mz;
   f2 p0, p1, p2, p3;  // (c00,c01) (c01,c11) (c02,c12) (c11,c22)
 };
+// REC4: a fourth load for the (c01,c11) pair instead of assembling it (see VoxelRec)
+template <bool REC4 = false>
 __device__ __forceinline__ RecRegs load_rec(const VoxelRec* __restrict__ recs, int r) {
   const float4* p = reinterpret_cast<const float4*>(recs + r);
   const float4 a = p[0], b = p[1], c = p[2];  // mean x, y | mean z, c00, c01 | c02, c12, c11, c22
@@ -363,7 +365,12 @@ __device__ __forceinline__ RecRegs load_rec(const VoxelRec* __restrict__ recs, i
   o.my = __hiloint2double(__float_as_int(a.w), __float_as_int(a.z));
   o.mz = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
   o.p0 = f2{b.z, b.w};
-  o.p1 = f2{b.w, c.z};
+  if (REC4) {
+    const float2 d = reinterpret_cast<const float2*>(recs + r)[7];
+    o.p1 = f2{d.x, d.y};
+  } else {
+    o.p1 = f2{b.w, c.z};
+  }
   o.p2 = f2{c.x, c.y};
   o.p3 = f2{c.z, c.w};
   return o;
@@ -554,7 +561,7 @@ constexpr bool kLimitRecordLoads = false;
 #endif
 // LIMIT: at most two voxel records in flight per point (see the neighbour loop): the throughput kernels and the one-launch
 // kernel of the launch path, whose blocks share CUs with other blocks; not the evaluation server (one block per CU).
-template <int NNB, bool WANT_H, bool STAMP = false, bool PRELOADED = false, bool LIMIT = kLimitRecordLoads>
+template <int NNB, bool WANT_H, bool STAMP = false, bool PRELOADED = false, bool LIMIT = kLimitRecordLoads, bool REC4 = false>
 __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src, int n, const GridView& gv, const EvalParams& prm,
                                                  const PackedTables& tab, int first, int stride, double (&acc)[kNumAcc],
                                                  unsigned long long* st = nullptr, float4 first_pt = float4{0.f, 0.f, 0.f, 0.f}) {
@@ -606,7 +613,7 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
         // clamped, so the load is unconditional and hoistable) before neighbour k's math runs; one
         // record gather latency is exposed per point instead of one per neighbour.
         PointAcc pa = point_acc_zero();
-        RecRegs cur = load_rec(gv.recs, rec[0] < 0 ? 0 : rec[0]);
+        RecRegs cur = load_rec<REC4>(gv.recs, rec[0] < 0 ? 0 : rec[0]);
         if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = stamp(); }
 #pragma unroll
         for (int k = 0; k < NNB; k++) {
@@ -616,7 +623,7 @@ __device__ __forceinline__ void derivatives_body(const float4* __restrict__ src,
           // two, and a 512-scan map build runs 9-13 % faster.  The evaluation server (one block per CU by design) keeps
           // every load in flight: limited, a 2M-point registration through it is 11 % slower.
           if (LIMIT && WANT_H) asm volatile("" ::: "memory");
-          if (k + 1 < NNB) nxt = load_rec(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
+          if (k + 1 < NNB) nxt = load_rec<REC4>(gv.recs, rec[k + 1] < 0 ? 0 : rec[k + 1]);
           if (rec[k] >= 0) {
             // x_trans (f32 -> f64) - mean (f64), rounded to f32  (:259-262, :492)
             const float x0 = static_cast<float>(txd - cur.mx);

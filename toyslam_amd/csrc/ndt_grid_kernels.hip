@@ -662,7 +662,8 @@ __device__ __forceinline__ bool finish_voxel(const VoxelSums& S, int cnt, int o,
       rec.c[0] = c00; rec.c[1] = c01; rec.c[2] = c02;
       rec.c[3] = c12; rec.c[4] = c11; rec.c[5] = c22;
       rec.n = cnt;
-      rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+      rec.pad = 0;
+      rec.c01c11[0] = c01; rec.c01c11[1] = c11;
       recs[r] = rec;
       VoxelSide side;
       side.cx = fx; side.cy = fy; side.cz = fz; side.pad = 0.0f;

@@ -13,15 +13,18 @@ namespace ndt {
 //                       in f64 and only then rounds to f32 (ndt_omp_impl.hpp:262,492)
 //   icov  : the six entries of Sigma^-1 (symmetric) as the f32 the reference casts to per use (:494), in the order
 //           c00 c01 c02 c12 c11 c22: with the means the FIRST 48 BYTES of the record -- three 16-byte loads per neighbour
-//           (every gather instruction of every wave goes through the CU's one vector memory path: round 2's layout stored
-//           c01 and c11 twice, so that all four register pairs of the packed math came out of the loads ready-made, and
-//           needed a fourth load).  Pairs (c00,c01) (c02,c12) (c11,c22) are adjacent; (c01,c11) is assembled with a move.
+//           (every gather instruction of every wave goes through the CU's one vector memory path).  The packed f32 math
+//           multiplies by four register pairs: (c00,c01) (c02,c12) (c11,c22) are adjacent in the loads, (c01,c11) is
+//           assembled with a move -- or, for the one kernel that is better off with a fourth load than with ten more
+//           registers (the launch path's one-launch kernel: 126 VGPRs, four waves per SIMD), read from the copy at the
+//           end of the sector.
 //   n     : point count.  (The voxel centroid and the f64 inverse covariance live in the side sector, VoxelSide.)
 struct alignas(64) VoxelRec {
   double mean[3];
   float c[6];
   int n;
-  int pad[3];
+  int pad;
+  float c01c11[2];
 };
 static_assert(sizeof(VoxelRec) == 64, "VoxelRec must be one 64-B sector");
 // What the f32 evaluation does not read, one 64-B sector per record again: the voxel centroid (voxel_centroids_ entry,

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   // ppb points per block (points_per_block(n)): small scans use only the first ppb lanes of a block, see there
   const int first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
   if (NNB == 27) derivatives_body_kd<WANT_H>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);
-  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, false, false, true>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);  // (LIMIT: 126 VGPRs)
+  else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, false, false, true, true>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);  // (LIMIT, REC4: 126 VGPRs)
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const double tot = wave_fold<kNumAcc>(acc);
