@@ -86,6 +86,15 @@ __device__ __forceinline__ void publish_row_tagged(double* __restrict__ pub, con
   }
 }
 
+// one wave publishes a row to the host without a trip through LDS: lane l < kEvalStride holds value l; word w of the row is
+// half (w & 1) of value w >> 1
+__device__ __forceinline__ void publish_lanes_tagged(double* __restrict__ pub, double value, int lane, unsigned long long seq) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(value));
+  const unsigned lo = __shfl(static_cast<unsigned>(bits), lane >> 1, kWave), hi = __shfl(static_cast<unsigned>(bits >> 32), lane >> 1, kWave);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(pub) + lane, tag_word((lane & 1) ? hi : lo, seq), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Fixed-order sum over the per-block partial rows by one workgroup of PARTS * kEvalStride threads:
 // thread (part, k) adds rows part, part + PARTS, ... of column k, 16 loads (sc1: the rows were
 // written through by other CUs) in flight at a time; the PARTS partial sums meet in lds2.

@@ -235,7 +235,6 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
   __shared__ PackedTables sT;
   __shared__ double s_f[8];  // 1, sx, cx, sy, cy, sz, cz
   __shared__ int s_kind;
-  __shared__ int s_last;
   unsigned long long expect = first_seq;
   // this lane's first point of every round (see derivatives_body PRELOADED)
   const int my_first = (static_cast<int>(threadIdx.x) < ppb) ? xcd_chunk(blockIdx.x, gridDim.x) * ppb + static_cast<int>(threadIdx.x) : n;
@@ -405,33 +404,32 @@ __global__ __launch_bounds__(kServerTPB) void k_eval_server(const float4* __rest
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (fine && lane == 0) fine[4] = __builtin_amdgcn_s_memrealtime();
+      // Fan-in over kParts = 16 shard counters: shard p = the blocks b with b % 16 == p, exactly the rows that part p
+      // of the fixed-order sum (sum_rows_fixed) adds.  The last arriver of a shard adds its shard's rows and publishes
+      // that PART sum to the host, which adds the 16 parts in order -- the same additions in the same order as one
+      // last block doing both stages, without the top-level ticket and the second stage on the device
+      // (~200 returning atomics on ONE word would serialise at ~13 ns each; a shard sees 12-13).
+      // Counters live 128 B apart and are never reset inside a launch.  All of it stays inside this wave: the ticket's
+      // answer, the part sum and its publication (lane to lane by shuffles) need neither LDS nor the block's other
+      // waves, which wait at the round's last barrier (one block barrier and an LDS round trip less per evaluation).
+      const unsigned round = static_cast<unsigned>(expect - first_seq);
+      const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
+      const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
+      unsigned t1 = 0u;
       if (lane == 0) {
-        // Fan-in over kParts = 16 shard counters: shard p = the blocks b with b % 16 == p, exactly the rows that part p
-        // of the fixed-order sum (sum_rows_fixed) adds.  The last arriver of a shard adds its shard's rows and publishes
-        // that PART sum to the host, which adds the 16 parts in order -- the same additions in the same order as one
-        // last block doing both stages, without the top-level ticket and the second stage on the device
-        // (~200 returning atomics on ONE word would serialise at ~13 ns each; a shard sees 12-13).
-        // Counters live 128 B apart and are never reset inside a launch.
-        const unsigned round = static_cast<unsigned>(expect - first_seq);
-        const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
-        const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
-        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t1 == (round + 1u) * in_shard - 1u) ? 1 : 0;
+        t1 = __hip_atomic_fetch_add(counter + 32u * (1u + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) dbg[9 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();  // block has its ticket
       }
+      if (__builtin_amdgcn_readfirstlane(t1) == (round + 1u) * in_shard - 1u) {
+        if (dbg && lane == 0)  // a shard's last arriver starts its part sum (the latest writer is the one that matters)
+          __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double part = (lane < kEvalStride) ? sum_rows_fixed<kParts>(partials, gridDim.x, static_cast<int>(shard) * kEvalStride + lane) : 0.0;
+        publish_lanes_tagged(out_row + static_cast<size_t>(shard) * kPublishSlots, part, lane, expect);
+        if (dbg && lane == 0)  // published
+          __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    __syncthreads();
-    if (s_last) {
-      const int shard = static_cast<int>(blockIdx.x % static_cast<unsigned>(kParts));
-      if (dbg && tid == 0)  // a shard's last arriver starts its part sum (the latest writer is the one that matters)
-        __hip_atomic_store(&dbg[2], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid < kEvalStride) lds[tid] = sum_rows_fixed<kParts>(partials, gridDim.x, shard * kEvalStride + tid);
-      __syncthreads();
-      publish_row_tagged(out_row + static_cast<size_t>(shard) * kPublishSlots, lds, tid, expect);
-      if (dbg && tid == 0)  // published
-        __hip_atomic_store(&dbg[3], static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();  // s_kind / s_last / lds are rewritten by the next round
+    __syncthreads();  // s_kind / lds are rewritten by the next round
     expect++;
   }
 }
