@@ -36,9 +36,29 @@ struct Matrix {
     return m;
   }
   bool operator!=(const Matrix& o) const { return std::memcmp(v, o.v, sizeof(v)) != 0; }
+  S& operator[](int i) { return v[i]; }
+  const S& operator[](int i) const { return v[i]; }
+  static Matrix Zero() {
+    Matrix m;
+    std::memset(m.v, 0, sizeof(m.v));
+    return m;
+  }
+  void setZero() { std::memset(v, 0, sizeof(v)); }
 };
 typedef Matrix<float, 4, 4> Matrix4f;
 typedef Matrix<double, 3, 3> Matrix3d;
+typedef Matrix<double, 3, 1> Vector3d;
+typedef Matrix<float, 3, 1> Vector3f;
+typedef Matrix<float, 4, 1> Vector4f;
+typedef Matrix<float, 4, 1> Array4f;
+typedef Matrix<int, 4, 1> Vector4i;
+struct VectorXf {  // dynamic-size float vector: resize / size / operator[] only
+  std::vector<float> v;
+  void resize(int n) { v.assign(static_cast<size_t>(n), 0.f); }
+  int size() const { return static_cast<int>(v.size()); }
+  float& operator[](int i) { return v[static_cast<size_t>(i)]; }
+  const float& operator[](int i) const { return v[static_cast<size_t>(i)]; }
+};
 template <class T>
 using aligned_allocator = std::allocator<T>;
 struct Affine3f {

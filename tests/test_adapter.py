@@ -238,3 +238,101 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
         pres = r["T"]
         pose = ndt.host_chain_pose(pose, r["T"])
         assert rot_err(traj[k - 1], pose) < 2e-4 and trans_err(traj[k - 1], pose) < 2e-3, k
+
+
+VGC_SRC = os.path.join(ROOT, "tests", "vgc_harness.cpp")
+
+
+def test_voxel_grid_covariance_adapter_compiles_and_declares_reference_surface():
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + INC + [VGC_SRC])
+    hdr = open(os.path.join(ROOT, "include", "pclomp", "voxel_grid_covariance_omp.h")).read()
+    for name in ["class VoxelGridCovariance : public pcl::VoxelGrid<PointT>", "struct Leaf", "typedef std::map<size_t, Leaf> Map",
+                 "setMinPointPerVoxel", "getMinPointPerVoxel", "setCovEigValueInflationRatio", "getCovEigValueInflationRatio",
+                 "filter(PointCloud& output, bool searchable = false)", "filter(bool searchable = false)", "getLeaf(int index)",
+                 "getLeaf(PointT& p)", "getLeaf(Eigen::Vector3f& p)", "getNeighborhoodAtPoint7", "getNeighborhoodAtPoint1",
+                 "getLeaves()", "getCentroids()", "nearestKSearch", "radiusSearch", "getEvecs", "getEvals", "getInverseCov",
+                 "getPointCount", "voxel_centroids_leaf_indices_"]:
+        assert name in hdr, name
+
+
+@pytest.mark.gpu
+def test_voxel_grid_covariance_adapter_matches_oracle(built_lib, pair, tmp_path):
+    """pclomp::VoxelGridCovariance (voxel_grid_covariance_omp.h:59-556) over the C-ABI: leaves, centroid cloud and every query
+    against the oracle's leaves and a restatement of the reference's index arithmetic (_impl.hpp:372-444, .h:309-375)."""
+    from oracle import pyoracle as po
+    t, _ = pair
+    exe = str(tmp_path / "vgc_harness")
+    libdir = os.path.join(ROOT, "toyslam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + INC + [VGC_SRC, "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
+    tf = str(tmp_path / "t.f32")
+    t.astype("<f4").tofile(tf)
+    nq = 300
+    out = subprocess.check_output([exe, tf, str(len(t)), "1.0", str(nq)], text=True, stderr=subprocess.DEVNULL)
+    lines = out.splitlines()
+    o = po.OracleNDT(resolution=1.0, num_threads=8)
+    o.set_target(t)
+    G = o.grid()
+    assert lines[0] == "min_points_clamped 3"
+    cand = (G["n"] >= 6) | (G["n"] == -1)
+    assert lines[1] == "leaves %d output %d centroids %d" % (len(G["idx"]), cand.sum(), cand.sum())
+    leaf_lines = [l for l in lines if l.startswith("leaf ")]
+    assert len(leaf_lines) == len(G["idx"])
+    for i, l in enumerate(leaf_lines):
+        f = l.replace("|", " ").split()
+        assert int(f[1]) == G["idx"][i] and int(f[2]) == G["n"][i]
+        assert np.array_equal(np.array(f[3:6], dtype=np.float64), G["mean"][i])          # means: bit for bit
+        if cand[i]:
+            c = np.array(f[6:12], dtype=np.float64)
+            C = G["cov"][i]
+            ref = np.array([C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]])
+            assert np.allclose(c, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+            if G["n"][i] >= 6:
+                assert np.allclose(np.array(f[12:15], dtype=np.float64), np.diag(G["icov"][i]), rtol=1e-9)
+                assert np.allclose(np.array(f[15:18], dtype=np.float64), G["evals"][i], rtol=1e-9, atol=1e-12 * G["evals"][i].max())
+        else:
+            assert len(f) == 6
+    resid, ortho = [float(x) for x in [l for l in lines if l.startswith("eigenbasis")][0].split()[1:]]
+    assert resid < 1e-9 and ortho < 1e-12   # C v = lambda v for every valid leaf, V orthonormal
+    first = np.flatnonzero(cand)[:5]
+    for k, l in enumerate([l for l in lines if l.startswith("centroid ")]):
+        assert np.array_equal(np.array(l.split()[2:], dtype=np.float32), G["mean"][first[k]].astype(np.float32))
+    # the queries, restated from the reference's index arithmetic over the oracle's leaves
+    leaves = {int(ix): i for i, ix in enumerate(G["idx"])}
+    mb, xb, db = G["min_b"].astype(np.int64), G["max_b"].astype(np.int64), G["div_b"].astype(np.int64)
+    mul = np.array([1, db[0], db[0] * db[1]])
+    half = [(-1, -1, -1), (-1, 0, -1), (-1, 1, -1), (0, -1, -1), (0, 0, -1), (0, 1, -1), (1, -1, -1), (1, 0, -1), (1, 1, -1), (-1, -1, 0),
+            (0, -1, 0), (1, -1, 0), (-1, 0, 0)]
+    off26 = half + [tuple(-a for a in h) for h in half]
+    off7 = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    cents = G["mean"][cand].astype(np.float32)
+    def neighbours(p, offs):
+        ijk = np.floor(p / np.float32(1.0)).astype(np.int64)
+        got = []
+        for d in offs:
+            d = np.array(d)
+            if np.all(mb - ijk <= d) and np.all(xb - ijk >= d):
+                i = leaves.get(int(((ijk + d - mb) * mul).sum()))
+                if i is not None and G["n"][i] >= 6:
+                    got.append(i)
+        return got
+    qlines = [l for l in lines if l.startswith("query ")]
+    assert len(qlines) == nq
+    for l in qlines:
+        f = l.split()
+        i = int(f[1])
+        p = t[i].astype(np.float32).copy()
+        p[0] += np.float32(0.37) * np.float32(i % 5 - 2)
+        p[1] -= np.float32(0.21) * np.float32(i % 3 - 1)
+        n7 = neighbours(p, off7)
+        assert int(f[2]) == len(neighbours(p, off26)) and int(f[3]) == len(n7) and int(f[5]) == len(neighbours(p, off7[:1]))
+        assert float(f[4]) == pytest.approx(sum(G["mean"][j][0] * (k + 1) for k, j in enumerate(n7)), rel=1e-14, abs=1e-14)
+        c = (np.floor(p * np.float32(1.0)) - mb.astype(np.float32)).astype(np.int64)   # getLeaf: no bounds test (.h:326-346)
+        own = leaves.get(int((c * mul).sum()))
+        assert int(f[6]) == (G["n"][own] if own is not None else -999)
+        d = p[None, :] - cents
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        inside = np.sort(d2[d2 < np.float32(1.0)])
+        assert int(f[7]) == len(inside) and float(f[8]) == pytest.approx(float(inside[0]) if len(inside) else -1.0, rel=1e-6)
+        srt = np.sort(d2)
+        assert int(f[9]) == 3 and float(f[10]) == pytest.approx(float(srt[0]), rel=1e-6) and float(f[11]) == pytest.approx(float(srt[2]), rel=1e-6)
+    assert lines[-1] == "copy %d %d" % (len(G["idx"]), len(neighbours(t[0].astype(np.float32), off7)))
