@@ -491,7 +491,6 @@ __global__ __launch_bounds__(kBlock) void k_gicp_server(const float4* __restrict
   __shared__ double lds[kWaves * 32];
   __shared__ float sT[12];
   __shared__ int s_mode;
-  __shared__ int s_last;
   unsigned long long expect = first_seq;
   for (;;) {
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -576,22 +575,19 @@ __global__ __launch_bounds__(kBlock) void k_gicp_server(const float4* __restrict
                            __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        const unsigned round = static_cast<unsigned>(expect - first_seq);
-        const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
-        const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
-        const unsigned t1 = __hip_atomic_fetch_add(counter + 32u * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t1 == (round + 1u) * in_shard - 1u) ? 1 : 0;
+      // the ticket's answer, the shard's part sum and its publication stay inside this wave (as in k_eval_server): no LDS
+      // stage, no block barrier -- the other waves wait at the round's last barrier
+      const unsigned round = static_cast<unsigned>(expect - first_seq);
+      const unsigned shard = blockIdx.x % static_cast<unsigned>(kParts);
+      const unsigned in_shard = (gridDim.x + static_cast<unsigned>(kParts) - 1u - shard) / static_cast<unsigned>(kParts);
+      unsigned t1 = 0u;
+      if (lane == 0) t1 = __hip_atomic_fetch_add(counter + 32u * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane(t1) == (round + 1u) * in_shard - 1u) {
+        const double part = (lane < kEvalStride) ? sum_rows_fixed<kParts>(partials, gridDim.x, static_cast<int>(shard) * kEvalStride + lane) : 0.0;
+        publish_lanes_tagged(out_rows + static_cast<size_t>(shard) * kPubWords, part, lane, expect);
       }
     }
-    __syncthreads();
-    if (s_last) {
-      const int shard = static_cast<int>(blockIdx.x % static_cast<unsigned>(kParts));
-      if (tid < kEvalStride) lds[tid] = sum_rows_fixed<kParts>(partials, gridDim.x, shard * kEvalStride + tid);
-      __syncthreads();
-      publish_row_tagged(out_rows + static_cast<size_t>(shard) * kPubWords, lds, tid, expect);
-    }
-    __syncthreads();  // s_mode / s_last / lds are rewritten by the next round
+    __syncthreads();  // s_mode / lds are rewritten by the next round
     expect++;
   }
 }
