@@ -117,8 +117,42 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
     const int nb = static_cast<int>(std::min<size_t>(rec16 ? 256 : 1024, (n + 255) / 256));
     if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
     // the kernel stores its per-block rows straight into pinned host memory (no D2H copy to queue)
-    HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, borrowed ? nullptr : c->pts.p, h->bbox_rows, nb, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    static const bool poll_rows = [] { const char* v = getenv("NDT_BBOX_POLL"); return !v || atoi(v) != 0; }();
+    bool polled = false;
+    if (borrowed && rec16 && poll_rows) {
+      // A cloud used where it lies: nothing is copied, so nothing has to be waited for but the rows themselves -- tagged
+      // word by word and polled here (a stream synchronisation costs several microseconds beyond the kernel's end)
+      if (!h->bbox_tagged) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_tagged), 256 * 12 * sizeof(unsigned long long), hipHostMallocDefault));
+        std::memset(h->bbox_tagged, 0, 256 * 12 * sizeof(unsigned long long));
+      }
+      if (++h->bbox_tag == 0) h->bbox_tag = 1;
+      const unsigned tag = h->bbox_tag;
+      HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, nullptr, reinterpret_cast<float*>(h->bbox_tagged), nb, h->stream, tag));
+      const volatile unsigned long long* w = h->bbox_tagged;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      polled = true;
+      for (int i = nb * 12 - 1; i >= 0 && polled; i--)
+        while (static_cast<unsigned>(w[i]) != tag) {
+          __builtin_ia32_pause();
+          if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { polled = false; break; }
+        }
+      if (polled) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int i = 0; i < nb * 12; i++) {
+          const unsigned bits = static_cast<unsigned>(w[i] >> 32);
+          std::memcpy(&h->bbox_rows[i], &bits, sizeof(float));
+        }
+      } else {  // (a launch that failed, a device that hung: let the runtime say what happened)
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return fail(NDT_ERR_HIP, "bounding-box rows did not arrive");
+      }
+    }
+    if (!polled) {
+      HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, borrowed ? nullptr : c->pts.p, h->bbox_rows, nb, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     const float* mm = h->bbox_rows;
     for (int b = 0; b < nb; b++)
       for (int v = 0; v < 2; v++)

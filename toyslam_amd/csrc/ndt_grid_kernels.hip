@@ -99,9 +99,11 @@ __global__ __launch_bounds__(kBlock) void k_repack_bbox(const unsigned char* __r
 
 // The same for clouds that already are dense 16-byte records (pcl::PointXYZ in HBM): 16-byte loads, and -- COPY false --
 // no copy at all: a cloud handed over by reference only needs its bounding boxes (ndt_set_input_*_device_ref).
+// tag != 0: the row goes out as 12 self-validating words, (value bits << 32) | tag, so that the host can POLL the pinned rows
+// instead of synchronising the stream (a cloud handed over by reference has no copy the host would have to wait for anyway)
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_bbox16(const float4* __restrict__ src, size_t n, float4* __restrict__ dst,
-                                                  float* __restrict__ block_minmax) {
+                                                  float* __restrict__ block_minmax, unsigned tag) {
   float mn[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
   float mx[6] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
@@ -137,7 +139,11 @@ __global__ __launch_bounds__(kBlock) void k_bbox16(const float4* __restrict__ sr
     const bool is_min = (threadIdx.x % 6) < 3;
     float v = s[0][threadIdx.x];
     for (int w = 1; w < kBlock / kWave; w++) v = is_min ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    block_minmax[blockIdx.x * 12 + threadIdx.x] = v;
+    if (tag)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(block_minmax) + blockIdx.x * 12 + threadIdx.x,
+                         (static_cast<unsigned long long>(__float_as_uint(v)) << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+      block_minmax[blockIdx.x * 12 + threadIdx.x] = v;
   }
 }
 
@@ -1769,13 +1775,14 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
 }
 
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
-                              int n_blocks, hipStream_t stream) {
+                              int n_blocks, hipStream_t stream, unsigned tag) {
   if (n == 0) return hipSuccess;
   const bool rec16 = stride_bytes == 16 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0;
+  if (tag && !(rec16 && !d_dst)) return hipErrorInvalidValue;  // tagged rows: the by-reference form only
   if (rec16 && !d_dst)
-    hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax);
+    hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax, tag);
   else if (rec16)
-    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax);
+    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax, 0u);
   else
     hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
                        stride_bytes, d_dst, d_block_minmax);

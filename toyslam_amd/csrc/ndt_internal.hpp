@@ -282,6 +282,8 @@ struct ndt_context {
   DevBuf<unsigned char> staging;
   double* host_result = nullptr;  // pinned, kEvalStride doubles (+ batch rows)
   float* bbox_rows = nullptr;     // pinned, per-block bounding-box rows of the last upload (k_repack_bbox)
+  unsigned long long* bbox_tagged = nullptr;  // pinned: the same rows as self-validating words, polled (clouds by reference)
+  unsigned bbox_tag = 0;
   // small host clouds (the mapping nodes' 16 k-point scans): repacked to float4 and bounded ON THE HOST into one of these
   // page-locked slots and DMA'd from there -- no repack kernel, no wait for the device (upload_cloud)
   static constexpr int kStageSlots = 4;
@@ -361,6 +363,7 @@ struct ndt_context {
     if (host_pub) (void)hipHostFree(host_pub);
     if (out_pinned) (void)hipHostFree(out_pinned);
     if (bbox_rows) (void)hipHostFree(bbox_rows);
+    if (bbox_tagged) (void)hipHostFree(bbox_tagged);
     for (int k = 0; k < kStageSlots; k++) {
       if (stage_host[k]) (void)hipHostFree(stage_host[k]);
       if (stage_done[k]) (void)hipEventDestroy(stage_done[k]);
