@@ -792,10 +792,25 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
                 uid = torch.from_numpy(np.frombuffer(ndt.comm_get_unique_id(), dtype=np.uint8).copy())
             uid = uid.to(on_dev)
             dist.broadcast(uid, 0)
-            reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            def all_ranks_ok(step, fn):
+                """Runs fn on this rank; every rank then learns whether ALL ranks got through (one torch all-reduce, which every
+                rank reaches whatever fn did): a rank that failed must not leave the others waiting in the next collective."""
+                err = None
+                try:
+                    fn()
+                except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                    err = repr(e)
+                flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=on_dev)
+                dist.all_reduce(flag)
+                if flag.item() != 0:
+                    raise RuntimeError("%s failed on %d of %d ranks%s" % (step, int(flag.item()), world, "" if err is None else " (this rank: %s)" % err))
+
+            all_ranks_ok("ndt_comm_init_rank", lambda: reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world))
             kw = dict(device_ptr=dev.data_ptr() if dev is not None else 0, offsets=offsets, stride_bytes=16,
                       first_scan=lo, total_scans=args.scans)
-            res = reg.alignBatchSharded(**kw)  # warm-up (communicator set-up, first collective)
+            warm = {}
+            all_ranks_ok("the first sharded lock-step batch", lambda: warm.update(res=reg.alignBatchSharded(**kw)))  # warm-up (communicator set-up, first collective)
+            res = warm["res"]
             torch.cuda.synchronize()
             n_ls = max(1, args.lockstep_steps)
             thr0 = cgroup_throttle_counters()
