@@ -119,16 +119,18 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
     // the kernel stores its per-block rows straight into pinned host memory (no D2H copy to queue)
     static const bool poll_rows = [] { const char* v = getenv("NDT_BBOX_POLL"); return !v || atoi(v) != 0; }();
     bool polled = false;
-    if (borrowed && rec16 && poll_rows) {
+    if (on_device && rec16 && poll_rows) {
       // A cloud used where it lies: nothing is copied, so nothing has to be waited for but the rows themselves -- tagged
-      // word by word and polled here (a stream synchronisation costs several microseconds beyond the kernel's end)
+      // word by word and polled here (a stream synchronisation costs several microseconds beyond the kernel's end).
+      // A device cloud the library copies: a block writes its row after its last read of the caller's records, so all rows
+      // in = the caller's buffer is free; the copy's own stores are ordered before whatever this stream runs next.
       if (!h->bbox_tagged) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_tagged), 256 * 12 * sizeof(unsigned long long), hipHostMallocDefault));
         std::memset(h->bbox_tagged, 0, 256 * 12 * sizeof(unsigned long long));
       }
       if (++h->bbox_tag == 0) h->bbox_tag = 1;
       const unsigned tag = h->bbox_tag;
-      HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, nullptr, reinterpret_cast<float*>(h->bbox_tagged), nb, h->stream, tag));
+      HIP_TRY(ndt::launch_repack_bbox(d_src, n, stride, borrowed ? nullptr : c->pts.p, reinterpret_cast<float*>(h->bbox_tagged), nb, h->stream, tag));
       const volatile unsigned long long* w = h->bbox_tagged;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;

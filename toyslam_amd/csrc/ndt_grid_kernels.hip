@@ -1778,11 +1778,11 @@ hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, 
                               int n_blocks, hipStream_t stream, unsigned tag) {
   if (n == 0) return hipSuccess;
   const bool rec16 = stride_bytes == 16 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0;
-  if (tag && !(rec16 && !d_dst)) return hipErrorInvalidValue;  // tagged rows: the by-reference form only
+  if (tag && !rec16) return hipErrorInvalidValue;  // tagged rows: the 16-byte-record forms only
   if (rec16 && !d_dst)
     hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax, tag);
   else if (rec16)
-    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax, 0u);
+    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax, tag);
   else
     hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
                        stride_bytes, d_dst, d_block_minmax);
