@@ -314,10 +314,12 @@ static int run_pipelined(Node& node, ndt_pcd_sequence_handle seq, float voxel_le
   });
 
   int rc = 0;
+  bool producer_done = false;  // the prep thread's end message has been taken: nothing more will come
   Prepared previous;
   for (;;) {
     Prepared cur = prepared.take();
     if (cur.end) {
+      producer_done = true;
       if (!cur.error.empty()) {
         std::fprintf(stderr, "%s\n", cur.error.c_str());
         rc = 1;
@@ -341,6 +343,7 @@ static int run_pipelined(Node& node, ndt_pcd_sequence_handle seq, float voxel_le
           ndt_align(h, node.rosbag ? node.pres_transform.data() : nullptr, T, &converged, &iterations, &probability, nullptr, 0) != NDT_OK) {
         std::fprintf(stderr, "registration failed: %s\n", ndt_last_error());
         rc = 1;
+        free_prep.put(cur.h);
         break;
       }
       node.t_align += since(t0);
@@ -350,6 +353,7 @@ static int run_pipelined(Node& node, ndt_pcd_sequence_handle seq, float voxel_le
       if (!err.empty()) {
         std::fprintf(stderr, "%s\n", err.c_str());
         rc = 1;
+        free_prep.put(cur.h);
         break;
       }
       if (into_map) {
@@ -362,11 +366,12 @@ static int run_pipelined(Node& node, ndt_pcd_sequence_handle seq, float voxel_le
     if (previous.h) free_prep.put(previous.h);  // its grid stays alive for as long as the registration handle shares it
     previous = std::move(cur);
   }
-  if (rc) {  // let the prep thread run dry (it may be waiting for a handle)
-    for (int i = 0; i < 2 * kPrep; i++) free_prep.put(prep[i % kPrep]);
+  if (rc && !producer_done) {  // let the prep thread run dry: every handle it may be waiting for goes back to it
+    if (previous.h) free_prep.put(previous.h);
     for (;;) {
       Prepared p = prepared.take();
       if (p.end) break;
+      free_prep.put(p.h);
     }
   }
   MapJob stop;

@@ -177,6 +177,7 @@ int main(int argc, char** argv) {
   }
 
   int rc = 0;
+  bool producer_done = false;  // the uploader's end message has been taken: nothing more will come
   size_t n_scans = 0;
   double wait_ms = 0, upload_ms = 0;
   std::vector<double> level_ms(level.size(), 0.0);
@@ -191,6 +192,7 @@ int main(int argc, char** argv) {
       u = ready.take();
     }
     if (u.end) {
+      producer_done = true;
       if (!u.error.empty()) {
         std::fprintf(stderr, "upload failed: %s\n", u.error.c_str());
         rc = 1;
@@ -225,11 +227,11 @@ int main(int argc, char** argv) {
   }
   const double total_ms = ms_since(t_begin);
   if (uploader.joinable()) {
-    if (rc) {  // let the uploader run dry
+    if (rc && !producer_done) {  // let the uploader run dry: every donor it uploads into comes straight back to it
       for (;;) {
-        free_donors.put(donors[0]);
         Upload u = ready.take();
         if (u.end) break;
+        free_donors.put(u.donor);
       }
     }
     uploader.join();

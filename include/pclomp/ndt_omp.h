@@ -58,7 +58,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
 #endif
 
   /** ctor defaults of ndt_omp_impl.hpp:47-76 live in ndt_create(). */
-  NormalDistributionsTransform() : handle_(nullptr), trans_probability_(0), search_method(DIRECT7) {
+  NormalDistributionsTransform() : handle_(nullptr), source_dirty_(false), trans_probability_(0), search_method(DIRECT7) {
     reg_name_ = "NormalDistributionsTransform";
     check(ndt_create(default_device(), &handle_), "ndt_create");
     transformation_epsilon_ = 0.1;  // :71
@@ -69,7 +69,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
    *  grid and source cloud, and carries the parameters and the last result. */
   NormalDistributionsTransform(const NormalDistributionsTransform& o)
       : pcl::Registration<PointSource, PointTarget>(o), handle_(nullptr), uploaded_source_(o.uploaded_source_),
-        trans_probability_(o.trans_probability_), search_method(o.search_method) {
+        source_dirty_(o.source_dirty_), trans_probability_(o.trans_probability_), search_method(o.search_method) {
     check(ndt_clone(o.handle_, &handle_), "ndt_clone");
   }
   NormalDistributionsTransform& operator=(const NormalDistributionsTransform& o) {
@@ -80,6 +80,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
       ndt_destroy(handle_);
       handle_ = h;
       uploaded_source_ = o.uploaded_source_;
+      source_dirty_ = o.source_dirty_;
       trans_probability_ = o.trans_probability_;
       search_method = o.search_method;
     }
@@ -98,6 +99,16 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
       PCL_WARN("[pclomp::NormalDistributionsTransform] %s\n", ndt_last_error());  // _impl.hpp:79-84 warns, keeps going
     else
       check(s, "ndt_set_input_target");
+  }
+
+  /** pcl::Registration::setInputSource is virtual; the reference does not override it and reads
+   *  *input_ at every align (ndt_omp_impl.hpp:833).  Here the points live on the GPU, so every call
+   *  marks the source for upload at the next align -- also when the pointer is the one already
+   *  uploaded (a caller may have refilled the cloud in place).  Between two align calls with no
+   *  setInputSource in between the upload is reused, as PCL reuses its own KD-tree. */
+  inline void setInputSource(const PointCloudSourceConstPtr& cloud) {
+    pcl::Registration<PointSource, PointTarget>::setInputSource(cloud);
+    source_dirty_ = true;
   }
 
   inline void setResolution(float resolution) {  // :132-142 (rebuild rule is inside the library)
@@ -196,15 +207,17 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     if (s != NDT_OK) throw std::runtime_error(std::string(what) + ": " + ndt_last_error());
   }
   void sync_source() {
-    if (input_ && input_ != uploaded_source_) {
+    if (input_ && (source_dirty_ || input_ != uploaded_source_)) {
       check(ndt_set_input_source(handle_, input_->points.data(), input_->points.size(), sizeof(PointSource)),
             "ndt_set_input_source");
       uploaded_source_ = input_;
+      source_dirty_ = false;
     }
   }
 
   ndt_handle handle_;
   PointCloudSourceConstPtr uploaded_source_;
+  bool source_dirty_;  // setInputSource since the last upload
   double trans_probability_;
 
  public:

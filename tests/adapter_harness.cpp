@@ -79,6 +79,28 @@ int main(int argc, char** argv) {
   // ndt_rosbag_mapping_node.cpp:133 prints the fitness of the derived object
   std::printf("fitness %.12g\n", copy.getFitnessScore());
 
+  // A caller that refills its cloud object in place and hands the SAME pointer over again (legal PCL usage; the
+  // reference reads *input_ at every align, ndt_omp_impl.hpp:833): the new points must be registered, not the old upload.
+  {
+    pcl::PointCloud<PointT>::Ptr reused(new pcl::PointCloud<PointT>(*source));
+    NDT refill;
+    refill.setResolution(1.0);
+    refill.setInputTarget(target);
+    refill.setInputSource(reused);
+    pcl::PointCloud<PointT>::Ptr a(new pcl::PointCloud<PointT>());
+    refill.align(*a);
+    for (auto& p : reused->points) {  // same object, other points: shifted by (0.4, -0.3, 0.05)
+      p.x += 0.4f;
+      p.y -= 0.3f;
+      p.z += 0.05f;
+    }
+    refill.setInputSource(reused);
+    refill.align(*a);
+    print("refill_same_ptr", refill.getFinalTransformation(), refill.hasConverged(), refill.getFinalNumIteration());
+    refill.align(*a);  // no set call in between: the upload is reused, the answer is the same
+    print("refill_again", refill.getFinalTransformation(), refill.hasConverged(), refill.getFinalNumIteration());
+  }
+
   // apps/align.cpp:84-86 -- pclomp::GICP through the pcl::Registration base pointer
   typedef pclomp::GeneralizedIterativeClosestPoint<PointT, PointT> GICP;
   GICP::Ptr gicp_omp(new GICP());

@@ -87,6 +87,18 @@ def test_adapter_harness_matches_oracle(built_lib, pair, tmp_path):
     d, _ = cKDTree(t.astype(np.float64)).query(moved.astype(np.float64))
     assert float(rows["fitness"]) == pytest.approx(float(np.mean(d ** 2)), rel=1e-5)
 
+    # setInputSource(same pointer) after the cloud was refilled in place: the NEW points are registered
+    o2 = po.OracleNDT(resolution=1.0, num_threads=8)
+    o2.set_target(t)
+    s_shift = (s.astype(np.float32) + np.array([0.4, -0.3, 0.05], np.float32)).astype(np.float32)
+    o2.set_source(s_shift)
+    rr = o2.align()
+    conv, iters, Tr = parse("refill_same_ptr")
+    assert conv == int(rr["converged"]) and iters == rr["iterations"]
+    assert rot_err(Tr, rr["T"]) < 1e-4 and trans_err(Tr, rr["T"]) < 1e-3
+    assert trans_err(Tr, r["T"]) > 0.1   # (not the stale upload's answer)
+    assert np.array_equal(parse("refill_again")[2], Tr)
+
     # pclomp::GICP through the pcl::Registration pointer (apps/align.cpp:84-86)
     og = po.OracleGICP()
     og.setInputTarget(t)

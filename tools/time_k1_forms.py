@@ -6,8 +6,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toyslam_amd import clouds, ndt
 import torch
-cases = [("pair-like 16k/40m", 16000, 40.0, 1.0), ("60k/40m", 60000, 40.0, 1.0), ("300k/60m", 300000, 60.0, 1.0), ("1M/60m", 1000000, 60.0, 1.0),
+cases = [("pair-like 16k/40m", 16000, 40.0, 1.0), ("30k/40m", 30000, 40.0, 1.0), ("45k/40m", 45000, 40.0, 1.0), ("60k/40m", 60000, 40.0, 1.0), ("300k/60m", 300000, 60.0, 1.0), ("1M/60m", 1000000, 60.0, 1.0),
          ("1M/100m surfaces", 1000000, 100.0, 1.0), ("1M uniform", 1000000, None, 1.0), ("2M/150m 0.5", 2000000, 150.0, 0.5), ("10M/400m 0.5", 10000000, 400.0, 0.5)]
+cases = cases[:int(os.environ.get("K1_CASES", len(cases)))]  # K1_CASES=3: the small clouds only
 for name, n, ext, res in cases:
     tgt = clouds.target_uniform(n) if ext is None else clouds.target_surfaces(n, extent=ext, n_boxes=40)
     dev = torch.from_numpy(np.c_[tgt, np.ones(n, np.float32)]).cuda()

@@ -44,8 +44,10 @@ class StepPool {
 
  private:
   void post() {
-    gen_.fetch_add(1, std::memory_order_acq_rel);
-    if (sleepers_.load(std::memory_order_acquire) > 0) {
+    // post: gen_++ then read sleepers_; a worker: sleepers_++ then read gen_ -- a store-then-load handshake on two words,
+    // which only sequential consistency orders on every architecture
+    gen_.fetch_add(1, std::memory_order_seq_cst);
+    if (sleepers_.load(std::memory_order_seq_cst) > 0) {
       std::lock_guard<std::mutex> g(mu_);  // a sleeper re-checks gen_ under this lock before it waits: no lost wake-up
       cv_.notify_all();
     }
@@ -59,8 +61,8 @@ class StepPool {
         __builtin_ia32_pause();
         if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - idle_since > std::chrono::microseconds(50)) {
           std::unique_lock<std::mutex> lk(mu_);
-          sleepers_.fetch_add(1, std::memory_order_acq_rel);
-          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          sleepers_.fetch_add(1, std::memory_order_seq_cst);
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_seq_cst) != seen; });
           sleepers_.fetch_sub(1, std::memory_order_acq_rel);
         }
       }

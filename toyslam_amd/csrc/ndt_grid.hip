@@ -140,15 +140,19 @@ ndt_status upload_cloud(ndt_context* h, const void* pts, size_t n, size_t stride
           __builtin_ia32_pause();
           if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { polled = false; break; }
         }
-      if (polled) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        for (int i = 0; i < nb * 12; i++) {
-          const unsigned bits = static_cast<unsigned>(w[i] >> 32);
-          std::memcpy(&h->bbox_rows[i], &bits, sizeof(float));
-        }
-      } else {  // (a launch that failed, a device that hung: let the runtime say what happened)
+      if (!polled) {
+        // two seconds without the rows: a stream that is merely slow (a profiler serialising it, long work queued ahead)
+        // or a launch that failed / a device that hung.  Let the runtime say which: after a successful synchronisation the
+        // kernel HAS run and its rows are valid.
         HIP_TRY(hipStreamSynchronize(h->stream));
-        return fail(NDT_ERR_HIP, "bounding-box rows did not arrive");
+        polled = true;
+        for (int i = 0; i < nb * 12 && polled; i++) polled = static_cast<unsigned>(w[i]) == tag;
+        if (!polled) return fail(NDT_ERR_HIP, "bounding-box rows did not arrive");
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (int i = 0; i < nb * 12; i++) {
+        const unsigned bits = static_cast<unsigned>(w[i] >> 32);
+        std::memcpy(&h->bbox_rows[i], &bits, sizeof(float));
       }
     }
     if (!polled) {
@@ -537,8 +541,8 @@ ndt_status build_grid(ndt_context* h) {
     static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
     DevBuf<unsigned long long> stamps;
     if (want_stamps) {
-      HIP_TRY(stamps.reserve(8 * (K + static_cast<size_t>(plan.n_blocks))));
-      HIP_TRY(hipMemsetAsync(stamps.p, 0, 8 * (K + static_cast<size_t>(plan.n_blocks)) * sizeof(unsigned long long), st));
+      HIP_TRY(stamps.reserve(8 * (K + std::max(K, static_cast<size_t>(plan.n_blocks)))));
+      HIP_TRY(hipMemsetAsync(stamps.p, 0, 8 * (K + std::max(K, static_cast<size_t>(plan.n_blocks))) * sizeof(unsigned long long), st));
       S.stamps = stamps.p;
     }
     // Records dense and in ascending cell order (maybe_compact_records: two small launches, ~13 us) pay for themselves as
@@ -548,6 +552,12 @@ ndt_status build_grid(ndt_context* h) {
     // registration against it, or before the first lock-step batch (NDT_K1_COMPACT=eager: at once, as round 2 did; off: never).
     // The mapping nodes' 16 k-point clouds (records that fit L2 many times over) never compact.
     static const int compact_mode = [] { const char* v = getenv("NDT_K1_COMPACT"); return !v ? 1 : std::strcmp(v, "eager") == 0 ? 2 : std::strcmp(v, "off") == 0 ? 0 : 1; }();
+    static const bool small_on = [] { const char* v = getenv("NDT_K1_SMALL"); return !v || atoi(v) != 0; }();
+    const bool small_form = small_on && ndt::grid_build_small_applies(n, plan);
+    if (small_form)
+      HIP_TRY(ndt::launch_grid_build_small(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
+                                           g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
+    else
     HIP_TRY(ndt::launch_grid_build_buckets(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
                                            g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
     g->compact_pending = n > 65536 && compact_mode != 0;
@@ -566,10 +576,24 @@ ndt_status build_grid(ndt_context* h) {
         std::fprintf(stderr, "%s %llu/%llu  ", names[q], d[d.size() / 2], d.back());
       }
       std::fprintf(stderr, "\n");
-      const size_t B = static_cast<size_t>(plan.n_blocks);
-      std::vector<unsigned long long> hs(8 * B);
+      if (small_form) {  // k1_small: cycles from the block's start to the end of the scan / the publication / the end
+        std::vector<unsigned long long> hk(4 * K);
+        HIP_TRY(hipMemcpy(hk.data(), stamps.p + 8 * K, 4 * K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[k1_small clocks, %zu blocks, cycles since the block's start: scan / published / end] ", K);
+        for (int q = 1; q < 4; q++) {
+          std::vector<unsigned long long> d;
+          for (size_t b = 0; b < K; b++) d.push_back(hk[4 * b + q] - hk[4 * b]);
+          std::sort(d.begin(), d.end());
+          std::fprintf(stderr, "%llu/%llu  ", d[d.size() / 2], d.back());
+        }
+        unsigned long long t_lo = ~0ull, t_hi = 0;
+        for (size_t b = 0; b < K; b++) { t_lo = std::min(t_lo, hk[4 * b]); t_hi = std::max(t_hi, hk[4 * b + 3]); }
+        std::fprintf(stderr, " first start -> last end %llu\n", t_hi - t_lo);
+      }
+      const size_t B = small_form ? 0 : static_cast<size_t>(plan.n_blocks);
+      std::vector<unsigned long long> hs(8 * B + 1);
       HIP_TRY(hipMemcpy(hs.data(), stamps.p + 8 * K, 8 * B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      std::fprintf(stderr, "[k1_scatter clocks, %zu blocks, cycles since the block's start: tables / ranks / column scan / stores] ", B);
+      if (B) std::fprintf(stderr, "[k1_scatter clocks, %zu blocks, cycles since the block's start: tables / ranks / column scan / stores] ", B);
       for (int q = 1; q < 5; q++) {
         std::vector<unsigned long long> d;
         for (size_t bq = 0; bq < B; bq++)

@@ -1116,12 +1116,19 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
 }
 
 // per-bucket cell histogram in LDS (cnt[C], zeroed here)
-__device__ __forceinline__ void k1_cell_histogram(const float4* __restrict__ bpts, unsigned bb, unsigned be, const GridGeom& g,
+// Where a bucket's points come from: its slice of the bucketed cloud in global memory (k1_scatter wrote it), or the lists a
+// block of k1_small collected them in (LDS).  src(j) = point j of the bucket, j < nb, w = point index.
+struct K1GlobalSrc {
+  const float4* __restrict__ p;  // bpts + the bucket's base
+  __device__ __forceinline__ float4 operator()(unsigned j) const { return p[j]; }
+};
+template <class Src>
+__device__ __forceinline__ void k1_cell_histogram(const Src& src, unsigned nb, const GridGeom& g,
                                                   const K1Deal& deal, int C, unsigned* cnt) {
   for (int c = threadIdx.x; c < C; c += kBlock) cnt[c] = 0;
   __syncthreads();
-  for (unsigned j = bb + threadIdx.x; j < be; j += kBlock) {
-    const float4 p = bpts[j];
+  for (unsigned j = threadIdx.x; j < nb; j += kBlock) {
+    const float4 p = src(j);
     atomicAdd(&cnt[k1_local(build_cell(g, p.x, p.y, p.z), deal)], 1u);
   }
   __syncthreads();
@@ -1140,7 +1147,7 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   U3 t = {0, 0, 0};
   if (be > bb) {  // uniform
-    k1_cell_histogram(bpts, bb, be, g, deal, C, k1_lds);
+    k1_cell_histogram(K1GlobalSrc{bpts + bb}, be - bb, g, deal, C, k1_lds);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       const unsigned v = k1_lds[c];
       t.occ += (v > 0);
@@ -1231,15 +1238,18 @@ constexpr int kTeamCell = 32, kTeamLanes = 16;
 constexpr size_t kK1MaxDynamicLds = 136 * 1024;  // of the CU's 160 KB (the kernels also hold up to ~20 KB of static LDS)
 constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
-__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
-                                                      double eig_ratio, int lds_cap, int wmax /* cells one pass may span (power of two <= C) */,
-                                                      const unsigned* __restrict__ bucket_base, int* __restrict__ sorted_idx,
-                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
-                                                      unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
-                                                      unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
-                                                      unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
-  extern __shared__ unsigned k1_lds[];
-  const K1Deal deal(map & 255, map >> 8);
+// One bucket, finished by one block: bucket k holds nb points (src), the first of them is point bb of the bucket order.
+// k1_lds: the dynamic LDS described at the launch (3 C words of per-cell state, 3 words per point of a pass, 5 rows of wmax
+// u16 counters).
+template <class Src>
+__device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, const unsigned bb, const unsigned nb, unsigned* k1_lds,
+                                                   const GridGeom& g, const K1Deal& deal, int C, int min_pts,
+                                                   double eig_ratio, int lds_cap, int wmax /* cells one pass may span (power of two <= C) */,
+                                                   int* __restrict__ sorted_idx,
+                                                   VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                   unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
+                                                   unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
+                                                   unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
   __shared__ U3 s_u3[kBlock / kWave];
   __shared__ int s_hi;
   // phase clocks of thread 0 (NDT_K1_STAMPS): cycles spent in 0 loads + ranks (or the histogram pass), 1 column / cell scans
@@ -1260,13 +1270,10 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                               // (sx sy sz cxx cxy cxz cyy cyz czz) as 18 words at the head of the cell's x segment,
                                               // fx fy fz at the head of its y segment (a team cell has more than 32 points)
   __shared__ float s_one;
-  const int k = blockIdx.x;
-  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  if (be == bb) {  // empty bucket (uniform)
+  if (nb == 0) {  // empty bucket (uniform)
     if (threadIdx.x == 0) bucket_valid[k] = 0u;
     return;
   }
-  const unsigned nb = be - bb;
   if (threadIdx.x == 0) s_one = 1.0f;
   unsigned* cnt = k1_lds;          // [C] points per cell
   unsigned* cstart = k1_lds + C;   // [C] start of the cell's segment inside the bucket (exclusive prefix of cnt)
@@ -1297,7 +1304,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
 #pragma unroll
     for (int u = 0; u < kK1PerThread; u++) {
       const unsigned j = static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-      p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
+      p[u] = (u < per_wave && j < nb) ? src(j) : make_float4(NAN, NAN, NAN, 0.f);
     }
     __syncthreads();  // (the counter rows are cleared)
 #pragma unroll
@@ -1336,7 +1343,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
     __syncthreads();
     lap(2);
   } else {
-    k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
+    k1_cell_histogram(src, nb, g, deal, C, cnt);
     k1_scan_cells(cnt, cstart, C, s_u3);
     lap(0);
   }
@@ -1405,7 +1412,7 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
 #pragma unroll
         for (int u = 0; u < kK1PerThread; u++) {
           const unsigned j = j0 + static_cast<unsigned>((wave * per_wave + u) * kWave + lane);
-          p[u] = (u < per_wave && j < nb) ? bpts[bb + j] : make_float4(NAN, NAN, NAN, 0.f);
+          p[u] = (u < per_wave && j < nb) ? src(j) : make_float4(NAN, NAN, NAN, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < kK1PerThread; u++) {
@@ -1597,6 +1604,329 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int min_pts,
+                                                      double eig_ratio, int lds_cap, int wmax,
+                                                      const unsigned* __restrict__ bucket_base, int* __restrict__ sorted_idx,
+                                                      VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                      unsigned* __restrict__ bucket_valid, unsigned* __restrict__ scratch, unsigned n_total,
+                                                      unsigned long long* __restrict__ st) {
+  extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);
+  const int k = blockIdx.x;
+  const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
+  k1_finalize_bucket(K1GlobalSrc{bpts + bb}, k, bb, be - bb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
+                     bucket_valid, scratch, n_total, st);
+}
+
+// A bucket of at most kSmallFinish points, finished without any per-cell table: a thread per point, the point's place in
+// (cell, point index) order counted directly -- every thread reads all nb cells of the bucket out of LDS (broadcast
+// reads, four cells each) and counts the points of smaller cells, the points of its own cell, and those of them before
+// itself.  The first point of a cell owns the cell: it adds the cell's points up in order and finishes the voxel.  Four block
+// barriers in all; k1_finalize_bucket on the same bucket (tables to clear, four scans over the C cells, the passes' selection)
+// is ~14 k cycles of which 8 k are such overhead -- at the mapping nodes' size (16 k points over 256 buckets) every bucket is
+// this small.  Same outputs as k1_finalize_bucket, bit for bit.  LDS: 4 x nb words from k1_lds.
+constexpr int kSmallFinish = 128;
+template <class Src>
+__device__ __forceinline__ void k1_finish_small(const Src& src, const int k, const unsigned bb, const unsigned nb, unsigned* k1_lds,
+                                                const GridGeom& g, const K1Deal& deal, int min_pts, double eig_ratio,
+                                                int* __restrict__ sorted_idx, VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids,
+                                                int* __restrict__ lut, unsigned* __restrict__ bucket_valid) {
+  __shared__ unsigned s_valid[kBlock / kWave];
+  const unsigned nb4 = (nb + 3u) & ~3u;
+  unsigned* cellof = k1_lds;  // [nb4]
+  float* sx = reinterpret_cast<float*>(k1_lds + nb4);
+  float* sy = sx + nb4;
+  float* sz = sy + nb4;
+  const unsigned j = threadIdx.x;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned c = 0xffffffffu;
+  if (j < nb) {
+    p = src(j);
+    c = static_cast<unsigned>(k1_local(build_cell(g, p.x, p.y, p.z), deal));
+  }
+  if (j < nb4) cellof[j] = c;  // (the padding: larger than any cell)
+  __syncthreads();
+  unsigned lt = 0, eq = 0, eq_before = 0;
+  if (j < nb) {
+    for (unsigned i = 0; i < nb4; i += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(cellof + i);
+      lt += (v.x < c) + (v.y < c) + (v.z < c) + (v.w < c);
+      const unsigned e0 = v.x == c, e1 = v.y == c, e2 = v.z == c, e3 = v.w == c;
+      eq += e0 + e1 + e2 + e3;
+      eq_before += (e0 & (i < j)) + (e1 & (i + 1 < j)) + (e2 & (i + 2 < j)) + (e3 & (i + 3 < j));
+    }
+    const unsigned q = lt + eq_before;
+    sx[q] = p.x;
+    sy[q] = p.y;
+    sz[q] = p.z;
+    sorted_idx[bb + q] = __float_as_int(p.w);
+  }
+  __syncthreads();
+  unsigned ok = 0;
+  if (j < nb && eq_before == 0 && static_cast<int>(eq) >= min_pts) {
+    const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+    VoxelSums S;
+    for (unsigned i = 0; i < eq; i++) S.add(sx[lt + i], sy[lt + i], sz[lt + i]);
+    const int r = static_cast<int>((bb + lt) / static_cast<unsigned>(min_pts));
+    ok = finish_voxel(S, static_cast<int>(eq), 0, r, k1_cell(k, static_cast<int>(c), deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) ok += __shfl_xor(ok, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_valid[threadIdx.x / kWave] = ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < kBlock / kWave; w++) t += s_valid[w];
+    bucket_valid[k] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1 for small clouds (the mapping nodes' 16 k points): ONE launch.  The four-kernel chain above is, at that size, four launch
+// boundaries around ~3 us of work each.  Here every block reads the WHOLE cloud (256 KB out of L2), keeps the points of its
+// own bucket and only counts the others, and then finishes its bucket exactly as k1_finalize does:
+//   scan     eight waves (two per SIMD: one wave alone issues a dependent instruction every ~8 cycles, two share the SIMD
+//            without slowing each other); wave w walks the w-th eighth of the cloud in 64-point chunks: cell, bucket; ballot of "bucket below mine" ->
+//            running count (the bucket's base in the bucket order, without any histogram, scan or exchange between blocks),
+//            ballot of "mine" -> the point goes to the wave's list in LDS (x, y, z, index).  The lists of waves 0..7 one
+//            after the other hold the bucket's points in ascending point index -- the order k1_scatter produces.
+//   publish  bucket_base[k], the bucketed points (the leaf pass and grid_counts read both later on)
+//   table    the block owns the look-up table slots of its bucket's cells (all written: record or empty) and the border
+//            slots of the k-th slice of the padded table -- every slot has one writer, nothing is cleared beforehand
+//   finish   by the first four waves (the others have ended): k1_finish_small / k1_finalize_bucket on the lists
+// No block waits for another one: no grid barrier, no co-residency requirement, fine on a CU-masked stream or beside a
+// resident evaluation server.  The price is the redundant scan, n x K cell computations (~5 us per 16 k points on every
+// CU: issue-bound, not memory-bound -- the same loop over one L1-resident kilobyte is 8 % faster) -- hence small clouds
+// only.  A wave whose list overflows (a bucket with more than list_cap points from one eighth of the cloud) is detected by the whole block; the block then scans a second time and writes its points straight to their
+// final places in the bucketed cloud, and finishes from there.
+// ---------------------------------------------------------------------------
+constexpr int kSmallWaves = 8;                      // waves of the scan (two per SIMD); the first kBlock / kWave of them finish the bucket
+constexpr int kSmallThreads = kSmallWaves * kWave;  // 512
+struct K1ListSrc {
+  const float4* list;    // [kSmallWaves][cap]
+  const unsigned* seg;   // LDS [kSmallWaves + 1]: first bucket position of every wave's list, then nb
+  int cap;
+  const float4* spilled;  // after an overflow: the bucket's slice of the bucketed cloud instead (else null)
+  __device__ __forceinline__ float4 operator()(unsigned j) const {
+    if (spilled) return spilled[j];  // (uniform)
+    unsigned w = 0;
+#pragma unroll
+    for (int i = 1; i < kSmallWaves; i++) w += (j >= seg[i]) ? 1u : 0u;
+    return list[w * static_cast<unsigned>(cap) + (j - seg[w])];
+  }
+};
+constexpr int kSmallBatch = 8;               // 64-point chunks a wave has in flight
+// The bucket of a point for the redundant scan, in as few instructions as it takes (every block does this for EVERY point of
+// the cloud): the per-axis indices exactly as build_cell computes them, each tested against its axis (so that the 24-bit
+// multiply-adds below are exact and the cell needs no further range test: a small grid has fewer than 2^24 cells), the run's
+// bucket by a mask when K is a power of two.  -1: not a point of the grid (non-finite, or outside the box: garbage in a
+// cloud declared dense) -- such a point is dropped here, so the finish never sees it.
+template <bool DENSE, bool POW2>
+__device__ __forceinline__ int small_bucket(const GridGeom& g, const K1Deal& deal, float x, float y, float z) {
+#pragma clang fp contract(off)
+  const float fx = x * g.inv_leaf[0], fy = y * g.inv_leaf[1], fz = z * g.inv_leaf[2];
+  const int i0 = static_cast<int>(floorf(fx) - static_cast<float>(g.min_b[0]));
+  const int i1 = static_cast<int>(floorf(fy) - static_cast<float>(g.min_b[1]));
+  const int i2 = static_cast<int>(floorf(fz) - static_cast<float>(g.min_b[2]));
+  // The box is the box of these very points, so a finite point is inside it -- 0 <= i < div_b < 2^24 on every axis, the
+  // 24-bit multiply-adds are exact and equal build_cell's -- and needs no range test.  What is not finite: in a cloud
+  // declared dense nothing that gets here (an infinity makes the box overflow, the host stops before any kernel; a NaN
+  // converts to index 0 on every axis here as in build_cell); otherwise the point is dropped.
+  const unsigned cell = __umul24(static_cast<unsigned>(i2), static_cast<unsigned>(g.mul[2])) +
+                        (__umul24(static_cast<unsigned>(i1), static_cast<unsigned>(g.mul[1])) + static_cast<unsigned>(i0));
+  const unsigned run = cell >> deal.rb;
+  int b;
+  if (POW2) {
+    b = static_cast<int>(run & (deal.K - 1u));
+  } else {
+    unsigned q, r;
+    deal.divmod(run, q, r);
+    b = static_cast<int>(r);
+  }
+  if (!DENSE) {
+    const float t = (fx + fy) + fz;  // not finite as soon as one coordinate is not (inf - inf = NaN)
+    if (!(fabsf(t) < INFINITY)) b = -1;
+  }
+  return b;
+}
+
+// One scan of this wave's chunks [c_lo, c_hi).  PASS 0: count the points of the buckets below k (-> below), collect the
+// points of bucket k in the wave's list (own = how many there are, also beyond the list's capacity).  PASS 1: the points of
+// bucket k go to out[own++] (their final places in the bucketed cloud).
+template <bool DENSE, bool POW2, int PASS>
+__device__ __forceinline__ void small_scan(const float4* __restrict__ pts, int n, const GridGeom& g, const K1Deal& deal, int k, int c_lo, int c_hi,
+                                           float4* mylist, int list_cap, float4* __restrict__ out, unsigned& own_out, unsigned& below_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned own = 0, below = 0;  // wave-uniform
+  const int full_hi = min(c_hi, n / kWave);  // chunks below this one are whole: no bounds test per point
+  auto visit = [&](const float4& p, int i, bool in_range) {
+    int b = small_bucket<DENSE, POW2>(g, deal, p.x, p.y, p.z);
+    if (!in_range) b = -1;
+    if (PASS == 0) below += static_cast<unsigned>(__popcll(__ballot(static_cast<unsigned>(b) < static_cast<unsigned>(k))));
+    const unsigned long long mine = __ballot(b == k);
+    if (mine) {  // (uniform, and rare: one point in K)
+      const unsigned pos = own + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mine), 0u));
+      if (b == k) {
+        const float4 q = make_float4(p.x, p.y, p.z, __int_as_float(i));
+        if (PASS == 0) {
+          if (pos < static_cast<unsigned>(list_cap)) mylist[pos] = q;
+        } else {
+          out[pos] = q;
+        }
+      }
+      own += static_cast<unsigned>(__popcll(mine));
+    }
+  };
+  int c0 = c_lo;
+  if (c0 + kSmallBatch <= full_hi) {
+    // whole batches, two register sets: while one batch is looked at, the loads of the next one are in flight (a copy from a
+    // "next" into a "current" set made the compiler wait for the loads it had just issued)
+    const int nbat = (full_hi - c_lo) / kSmallBatch;
+    float4 pa[kSmallBatch], pb[kSmallBatch];
+    auto fetch = [&](float4* dst, int t) {
+      const int cb = c_lo + t * kSmallBatch;
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; u++) dst[u] = pts[(cb + u) * kWave + lane];
+    };
+    auto look = [&](const float4* src, int t) {
+      const int cb = c_lo + t * kSmallBatch;
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; u++) visit(src[u], (cb + u) * kWave + lane, true);
+    };
+    // (every fetch unconditional -- the last ones read a batch again -- so that the compiler knows how many loads are
+    // outstanding at every point and waits for exactly the set it is about to look at)
+    fetch(pa, 0);
+    for (int t = 0; t < nbat; t += 2) {
+      fetch(pb, min(t + 1, nbat - 1));
+      look(pa, t);
+      fetch(pa, min(t + 2, nbat - 1));
+      if (t + 1 < nbat) look(pb, t + 1);  // (uniform)
+    }
+    c0 = c_lo + nbat * kSmallBatch;
+  }
+  for (; c0 < c_hi; c0++) {  // the rest, chunk by chunk
+    const int i = c0 * kWave + lane;
+    const float4 p = pts[min(i, n - 1)];
+    visit(p, i, i < n);
+  }
+  own_out = own;
+  below_out = below;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k1_small(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K, int C, int min_pts,
+                                                   double eig_ratio, int lds_cap, int wmax, int list_cap, unsigned fin_words /* LDS words of the finish */,
+                                                   int small_finish /* buckets up to this size: k1_finish_small (0: never) */,
+                                                   unsigned* __restrict__ bucket_base, float4* __restrict__ bpts, int* __restrict__ sorted_idx,
+                                                   VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                   unsigned* __restrict__ bucket_valid, unsigned* __restrict__ scratch, unsigned* __restrict__ counts,
+                                                   unsigned long long* __restrict__ st /* development aid (NDT_K1_STAMPS), or null */) {
+  extern __shared__ unsigned k1_lds[];
+  auto mark = [&](int q) {  // thread 0's clock: 0 start, 1 scan done, 2 published + table slots cleared, 3 end
+    if (st && threadIdx.x == 0) st[8 * static_cast<size_t>(K) + 4 * blockIdx.x + q] = stamp();
+  };
+  mark(0);
+  const K1Deal deal(map & 255, map >> 8);
+  __shared__ unsigned s_own[kSmallWaves], s_below[kSmallWaves], s_seg[kSmallWaves + 1];
+  float4* list = reinterpret_cast<float4*>(k1_lds + fin_words);  // (fin_words is a multiple of 4)
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int chunks = (n + kWave - 1) / kWave, per = (chunks + kSmallWaves - 1) / kSmallWaves;  // chunks per wave
+  const int c_lo = min(chunks, wave * per), c_hi = min(chunks, c_lo + per);
+  float4* mylist = list + wave * list_cap;
+  const bool pow2 = (K & (K - 1)) == 0;
+  // ---- scan ----
+  unsigned own = 0, below = 0;
+  if (dense) {
+    if (pow2) small_scan<true, true, 0>(pts, n, g, deal, k, c_lo, c_hi, mylist, list_cap, nullptr, own, below);
+    else small_scan<true, false, 0>(pts, n, g, deal, k, c_lo, c_hi, mylist, list_cap, nullptr, own, below);
+  } else {
+    if (pow2) small_scan<false, true, 0>(pts, n, g, deal, k, c_lo, c_hi, mylist, list_cap, nullptr, own, below);
+    else small_scan<false, false, 0>(pts, n, g, deal, k, c_lo, c_hi, mylist, list_cap, nullptr, own, below);
+  }
+  if (lane == 0) {
+    s_own[wave] = own;
+    s_below[wave] = below;
+  }
+  __syncthreads();
+  mark(1);
+  unsigned base_w = 0, bb = 0, nb = 0;
+  bool overflow = false;
+  for (int w = 0; w < kSmallWaves; w++) {
+    bb += s_below[w];
+    if (w < wave) base_w += s_own[w];
+    nb += s_own[w];
+    overflow = overflow || s_own[w] > static_cast<unsigned>(list_cap);
+  }
+  if (overflow) {  // (uniform, rare) a list was too short: a second scan, the points straight to their final places
+    unsigned own2 = 0, dummy = 0;
+    if (dense) small_scan<true, false, 1>(pts, n, g, deal, k, c_lo, c_hi, nullptr, 0, bpts + bb + base_w, own2, dummy);
+    else small_scan<false, false, 1>(pts, n, g, deal, k, c_lo, c_hi, nullptr, 0, bpts + bb + base_w, own2, dummy);
+  }
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int w = 0; w < kSmallWaves; w++) {
+      s_seg[w] = run;
+      run += s_own[w];
+    }
+    s_seg[kSmallWaves] = run;
+    bucket_base[k] = bb;
+    if (k == K - 1) {
+      bucket_base[K] = bb + nb;
+      counts[0] = bb + nb;  // points binned
+    }
+  }
+  const K1ListSrc lsrc{list, s_seg, list_cap, overflow ? bpts + bb : nullptr};
+  if (!overflow) {  // (uniform)
+    __syncthreads();  // s_seg
+    for (unsigned j = threadIdx.x; j < nb; j += kSmallThreads) bpts[bb + j] = lsrc(j);
+  }
+  // ---- the look-up table: border slots of my slice, and every cell of my bucket starts out empty ----
+  {
+    const long long per_blk = (g.lut_cells + K - 1) / K;
+    const long long lo = static_cast<long long>(k) * per_blk, hi = min(g.lut_cells, lo + per_blk);
+    const int ex = g.div_b[0] + kLutBorder, ey = g.div_b[1] + kLutBorder, ez = g.div_b[2] + kLutBorder;
+    // (a / b for a < 2^31 and a quotient below 2^22 -- an axis of the grid: the product with the f32 reciprocal is within
+    // one of it; two 32-bit integer divisions per slot were a third of this phase)
+    auto divq = [](unsigned a, unsigned b, float rb) {
+      unsigned q = static_cast<unsigned>(__uint2float_rz(a) * rb);
+      int r = static_cast<int>(a - q * b);
+      if (r < 0) { q--; r += static_cast<int>(b); }
+      if (r >= static_cast<int>(b)) q++;
+      return q;
+    };
+    const float rp2 = 1.0f / static_cast<float>(g.pmul[2]), rp1 = 1.0f / static_cast<float>(g.pmul[1]);
+    const float rm2 = 1.0f / static_cast<float>(g.mul[2]), rm1 = 1.0f / static_cast<float>(g.mul[1]);
+    for (long long sl = lo + threadIdx.x; sl < hi; sl += kSmallThreads) {
+      const unsigned u = static_cast<unsigned>(sl);  // (a small grid's padded table has fewer than 2^31 slots)
+      const int pz = static_cast<int>(divq(u, static_cast<unsigned>(g.pmul[2]), rp2));
+      const unsigned rem = u - static_cast<unsigned>(pz) * static_cast<unsigned>(g.pmul[2]);
+      const int py = static_cast<int>(divq(rem, static_cast<unsigned>(g.pmul[1]), rp1)), px = static_cast<int>(rem) - py * g.pmul[1];
+      if (px < kLutBorder || px >= ex || py < kLutBorder || py >= ey || pz < kLutBorder || pz >= ez) lut[sl] = kLutEmpty;
+    }
+    for (int lc = threadIdx.x; lc < C; lc += kSmallThreads) {
+      const long long cell = static_cast<unsigned>(k1_cell(k, lc, deal));
+      if (cell < g.n_cells) {
+        const unsigned c = static_cast<unsigned>(cell);
+        const int cz = static_cast<int>(divq(c, static_cast<unsigned>(g.mul[2]), rm2));
+        const unsigned rem = c - static_cast<unsigned>(cz) * static_cast<unsigned>(g.mul[2]);
+        const int cy = static_cast<int>(divq(rem, static_cast<unsigned>(g.mul[1]), rm1)), cx = static_cast<int>(rem) - cy * g.mul[1];
+        lut[static_cast<long long>(cx + kLutBorder) + static_cast<long long>(cy + kLutBorder) * g.pmul[1] + static_cast<long long>(cz + kLutBorder) * g.pmul[2]] = kLutEmpty;
+      }
+    }
+  }
+  __syncthreads();  // the bucketed points and the empty slots are out before anything of the finish reads / overwrites them
+  mark(2);
+  // The finish is written for kBlock threads: the scan's other waves end here.  (A barrier waits for the waves of the
+  // workgroup that have not terminated -- s_barrier, CDNA3 ISA 4.4 -- so the barriers of the finish are the four waves' own.)
+  if (threadIdx.x >= kBlock) return;
+  if (nb <= static_cast<unsigned>(small_finish))  // (uniform)
+    k1_finish_small(lsrc, k, bb, nb, k1_lds, g, deal, min_pts, eig_ratio, sorted_idx, recs, centroids, lut, bucket_valid);
+  else
+    k1_finalize_bucket(lsrc, k, bb, nb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
+                       bucket_valid, scratch, static_cast<unsigned>(n), st);
+  mark(3);
+}
+
 // ---------------------------------------------------------------------------
 // Record compaction of a bucket-form build.  k1_finalize numbers a voxel's record by where its points sit in the bucket
 // order (unique without a scan over voxels) -- slots with gaps, bucket by bucket.  The evaluation kernels gather records
@@ -1716,7 +2046,7 @@ __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ b
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) return;
   unsigned* cnt = k1_lds;
-  k1_cell_histogram(bpts, bb, be, g, deal, C, cnt);
+  k1_cell_histogram(K1GlobalSrc{bpts + bb}, be - bb, g, deal, C, cnt);
   const int per = C / kBlock > 0 ? C / kBlock : 1;
   const int lo = threadIdx.x * per;
   U3 t = {0, 0, 0};
@@ -1941,6 +2271,40 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), fin_lds(lds_cap), stream,
                      S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, wmax, S.bucket_base, sorted_idx, recs, centroids, lut,
                      S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.stamps);
+  return hipGetLastError();
+}
+
+// K1 for small clouds in one launch (k1_small).  false: not for this cloud / plan (the caller takes the chain).
+bool grid_build_small_applies(int n, const GridBuildPlan& P) {
+  // every block scans the whole cloud: n x K cell computations.  Measured against the chain (tools/time_k1_forms.py): see NOTES.
+  static const int small_max = [] { const char* v = getenv("NDT_K1_SMALL_MAX"); return v ? atoi(v) : 49152; }();
+  return n > 0 && n <= small_max && P.n_buckets <= 512;
+}
+hipError_t launch_grid_build_small(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& P, int min_pts,
+                                   double eig_ratio, const GridBuildScratch& S, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
+                                   int* lut, unsigned* counts, hipStream_t stream) {
+  const int K = P.n_buckets, C = P.cells_per_bucket;
+  const int wmax = std::min(C, 1024);
+  // lists: eight waves x list_cap points of 16 bytes (NDT_K1_SMALL_LIST: tests force the overflow path with a tiny capacity)
+  static const int list_env = [] { const char* v = getenv("NDT_K1_SMALL_LIST"); return v ? std::max(1, atoi(v)) : 0; }();
+  const int list_cap = list_env > 0 ? list_env : 384;
+  const size_t list_bytes = static_cast<size_t>(kSmallWaves) * list_cap * sizeof(float4);
+  auto fin_lds = [&](int cap) { return ((static_cast<size_t>(3) * C + 3 * static_cast<size_t>(cap)) * sizeof(unsigned) + 5 * static_cast<size_t>(wmax) * 2 + 15) / 16 * 16; };
+  int lds_cap = kK1LdsCap;
+  while (lds_cap > 256 && fin_lds(lds_cap) + list_bytes > kK1MaxDynamicLds) lds_cap -= 256;
+  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? std::max(256, atoi(v)) / 256 * 256 : 0; }();
+  if (cap_env > 0) lds_cap = std::min(lds_cap, cap_env);
+  if (fin_lds(lds_cap) + list_bytes > kK1MaxDynamicLds) return hipErrorInvalidValue;
+  // (NDT_K1_SMALL_FINISH=0: every bucket through k1_finalize_bucket -- the cross-check of the two finishes)
+  static const int small_finish = [] { const char* v = getenv("NDT_K1_SMALL_FINISH"); return v ? std::max(0, std::min(kSmallFinish, atoi(v))) : kSmallFinish; }();
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_small), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(k1_small, dim3(K), dim3(kSmallThreads), fin_lds(lds_cap) + list_bytes, stream, pts, n, dense, g, P.shift, K, C, min_pts, eig_ratio,
+                     lds_cap, wmax, list_cap, static_cast<unsigned>(fin_lds(lds_cap) / sizeof(unsigned)), small_finish, S.bucket_base, S.bpts, sorted_idx, recs,
+                     centroids, lut, S.bucket_base + K + 1, S.order, counts, S.stamps);
   return hipGetLastError();
 }
 

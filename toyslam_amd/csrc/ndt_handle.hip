@@ -236,7 +236,15 @@ ndt_status ndt_set_cu_partition(ndt_handle h, int partition) {
   if (h->stream) {
     h->cu_count = h->stream_masked[partition] ? (partition == 1 ? total - side_cus() : side_cus()) : total;
   } else {
+    const int old_count = h->cu_count;
     s = create_stream(h);
+    if (s || !h->stream) {  // no stream for the new partition: the handle stays where it was
+      h->stream = h->partition_stream[old_partition];
+      h->cu_partition = old_partition;
+      h->cu_count = old_count;
+      tls_pool_stream = h->stream;
+      return s ? s : fail(NDT_ERR_HIP, "no stream for the CU partition");
+    }
     h->stream_masked[partition] = h->cu_count != total;
     h->partition_stream[partition] = h->stream;
   }

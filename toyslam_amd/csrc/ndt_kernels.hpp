@@ -155,6 +155,11 @@ struct GridBuildScratch {
 };
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
+// the same grid from ONE launch, for small clouds (every block scans the whole cloud and finishes its own bucket); scratch.cntmat unused
+bool grid_build_small_applies(int n_points, const GridBuildPlan& plan);
+hipError_t launch_grid_build_small(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
+                                   double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
+                                   int* lut, unsigned* counts, hipStream_t stream);
 hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
                                      double eig_ratio, const GridBuildScratch& scratch, int* sorted_idx, VoxelRec* recs, VoxelSide* centroids,
                                      int* lut, unsigned* counts, hipStream_t stream);
