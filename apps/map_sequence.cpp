@@ -22,7 +22,8 @@
 // after the other, 2.7 ms overlapped, 3.7 ms overlapped on CU partitions -- the steps are short host-paced sequences of
 // pageable copies and small launches, and two threads driving them get in each other's way; hence not the default.
 //
-//   map_sequence <pcd_directory> [voxel_leaf_size (0.5 | 0.3)] [global_map_out.pcd | -] [rosbag | node] [pipeline]
+//   map_sequence <pcd_directory> [voxel_leaf_size (0.5 | 0.3)] [global_map_out.pcd | -] [rosbag | node] [serial | pipeline] [host]
+// ("host": the serial loop with every cloud passing through host buffers, as in rounds 1-3; the default keeps them in HBM)
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -144,7 +145,86 @@ struct Node {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the node's loop as it stands: one handle, one step after the other
+// the node's loop as it stands, one handle, one step after the other -- with every cloud staying in HBM (the default):
+// the raw scan goes up once (from the reader's page-locked buffer), the prefilter leaves its result on the device as an
+// ndt_cloud, and that one object is the source of this registration, the target of the next one and what the map update
+// adds -- no download, no second or third upload / repack / bounding-box pass of the same points
+// ---------------------------------------------------------------------------------------------------------------------
+static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_leaf_size, ndt_handle h) {
+  ndt_cloud previous = nullptr;  // clouds_[current_index_ - 1]
+  int rc = 0;
+  for (; !rc;) {
+    size_t fresh = 0;
+    CHECK(ndt_pcd_sequence_poll(seq, node.loaded, &fresh));
+    if (fresh == 0) break;
+    for (; !rc;) {
+      const void* raw = nullptr;
+      size_t n = 0;
+      int dense = 1, number = -1;
+      const ndt_status s = ndt_pcd_sequence_next(seq, &raw, &n, &dense, &number);
+      if (s != NDT_OK) {
+        std::fprintf(stderr, "skipped: %s\n", ndt_last_error());
+        continue;
+      }
+      if (!raw) break;
+      auto t0 = clock_type::now();
+      ndt_cloud current = nullptr;  // load_and_filter_cloud, :142-148
+      int overflowed = 0;
+      size_t m = 0;
+      if (ndt_cloud_voxel_filter(h, raw, n, sizeof(Pt), dense, voxel_leaf_size, 0, &current, &overflowed) != NDT_OK || ndt_cloud_size(current, &m) != NDT_OK) {
+        std::fprintf(stderr, "voxel filter failed: %s\n", ndt_last_error());
+        rc = 1;
+        break;
+      }
+      node.t_filter += since(t0);
+      if (m == 0) {  // :128 -- empty clouds are not kept
+        ndt_cloud_release(current);
+        continue;
+      }
+      node.loaded++;
+      std::printf("Loaded cloud_%d.pcd (%zu points)\n", number, m);
+      auto step = [&]() -> int {
+        if (node.loaded == 1) {  // load_initial_clouds, :64-68
+          t0 = clock_type::now();
+          int ov = 0;
+          CHECK(ndt_map_update_cloud(h, current, 1, kIdentity, 0.5f, &ov));
+          node.t_map += since(t0);
+          return 0;
+        }
+        t0 = clock_type::now();  // process_available_clouds, :70-100
+        CHECK(ndt_set_input_target_cloud(h, previous, 1));
+        CHECK(ndt_set_input_source_cloud(h, current));
+        float T[16];
+        int converged = 0, iterations = 0;
+        double probability = 0;
+        CHECK(ndt_align(h, node.rosbag ? node.pres_transform.data() : nullptr, T, &converged, &iterations, &probability, nullptr, 0));
+        node.t_align += since(t0);
+        std::vector<float> map_pose;
+        std::string err;
+        const bool into_map = node.after_align(h, T, converged, iterations, map_pose, err);
+        if (!err.empty()) {
+          std::fprintf(stderr, "%s\n", err.c_str());
+          return 1;
+        }
+        if (into_map) {
+          t0 = clock_type::now();
+          int ov = 0;
+          CHECK(ndt_map_update_cloud(h, current, 1, map_pose.data(), 0.5f, &ov));  // :204 / map_voxel :88: leaf fixed at 0.5
+          node.t_map += since(t0);
+        }
+        return 0;
+      };
+      rc = step();
+      ndt_cloud_release(previous);
+      previous = current;
+    }
+  }
+  ndt_cloud_release(previous);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the same loop through host buffers, as a caller that holds its clouds in host memory (PCL) has to run it
 // ---------------------------------------------------------------------------------------------------------------------
 static int run_serial(Node& node, ndt_pcd_sequence_handle seq, float voxel_leaf_size, ndt_handle h) {
   std::vector<Pt> previous, current;  // clouds_[current_index_ - 1], clouds_[current_index_]
@@ -390,12 +470,13 @@ static int run_pipelined(Node& node, ndt_pcd_sequence_handle seq, float voxel_le
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::printf("usage: map_sequence <pcd_directory> [voxel_leaf_size] [global_map_out.pcd | -] [rosbag | node] [pipeline]\n");
+    std::printf("usage: map_sequence <pcd_directory> [voxel_leaf_size] [global_map_out.pcd | -] [rosbag | node] [serial | pipeline] [host]\n");
     return 0;
   }
   Node node;
   node.rosbag = argc > 4 && std::strcmp(argv[4], "rosbag") == 0;
   const bool serial = !(argc > 5 && std::strcmp(argv[5], "pipeline") == 0);
+  const bool host_clouds = argc > 6 && std::strcmp(argv[6], "host") == 0;  // serial only: every cloud through host buffers
   const float voxel_leaf_size = argc > 2 ? static_cast<float>(std::atof(argv[2])) : (node.rosbag ? 0.3f : 0.5f);  // :44 / rosbag :87
   ndt_handle h = nullptr, map_handle = nullptr;
   CHECK(ndt_create(0, &h));
@@ -408,8 +489,15 @@ int main(int argc, char** argv) {
 
   ndt_pcd_sequence_handle seq = nullptr;
   CHECK(ndt_pcd_sequence_open(argv[1], &seq));
+  // a node constructs its objects (and a GPU library loads its code, creates its streams, page-locks its slots) before the
+  // first scan arrives: not part of any scan's time
+  const auto t_warm = clock_type::now();
+  CHECK(ndt_warm_up(h));
+  if (map_handle) CHECK(ndt_warm_up(map_handle));
+  const double warm_ms = since(t_warm);
   const auto t_begin = clock_type::now();
-  const int rc = serial ? run_serial(node, seq, voxel_leaf_size, h) : run_pipelined(node, seq, voxel_leaf_size, h, map_handle);
+  const int rc = !serial ? run_pipelined(node, seq, voxel_leaf_size, h, map_handle)
+                         : host_clouds ? run_serial(node, seq, voxel_leaf_size, h) : run_resident(node, seq, voxel_leaf_size, h);
   if (rc) return rc;
 
   ndt_handle mh = serial ? h : map_handle;
@@ -421,9 +509,11 @@ int main(int argc, char** argv) {
     std::snprintf(title, sizeof(title), "trajectory[%zu]:", i);
     print_matrix(title, node.trajectory[i].data());
   }
+  std::printf("start-up (device, code object, page-locked slots; ndt_warm_up): %.1f ms, not in the times below\n", warm_ms);
   std::printf("time: total %.2f ms  (prefilter %.2f, %s %.2f, map update %.2f; %s)\n", since(t_begin), node.t_filter,
               serial ? "set inputs + align" : "take inputs over + align", node.t_align, node.t_map,
-              serial ? "file reading overlapped" : "file reading, prefilter + input preparation and map update overlapped with the registrations");
+              !serial ? "file reading, prefilter + input preparation and map update overlapped with the registrations"
+                      : host_clouds ? "file reading overlapped; clouds through host buffers" : "file reading overlapped; clouds resident in HBM");
   if (argc > 3 && std::strcmp(argv[3], "-") != 0 && map_points) {
     std::vector<Pt> map(map_points);
     CHECK(ndt_map_get(mh, map.data(), sizeof(Pt)));

@@ -189,6 +189,41 @@ ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride_bytes); /* x,y
 ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts_float4, size_t* n);
 void ndt_host_chain_pose(const float* pose /*16*/, const float* transform /*16*/, float* out /*16, may alias*/);
 
+/* What a node does once, at start-up, instead of inside its first scan: the device context, the library's code object (tens
+ * of milliseconds on first use), the handle's page-locked result / staging slots, and one tiny registration, voxel filter and
+ * map update on a scratch handle so that every kernel of the loop has been launched once.  Changes nothing observable on `h`. */
+ndt_status ndt_warm_up(ndt_handle h);
+
+/* ---- clouds that stay in HBM: the node loop without host round trips -----------------------------------------------
+ * In all three mapping nodes a filtered scan is used four times: as the output of the prefilter
+ * (ndt_omp_mapping_node.cpp:142-148), as the source of the registration against its predecessor (:151-169), as the target of
+ * the registration of its successor (cloud k is clouds_[current_index_] of one pair and clouds_[current_index_ - 1] of the
+ * next, :77-79), and as what update_global_map adds to the map (:195-211).  Through host buffers that is one download and
+ * three uploads, repacks and bounding-box passes of the same points.  An `ndt_cloud` is that scan as an object: dense
+ * 16-byte records in HBM together with their bounding boxes, reference-counted (a handle that takes it as an input holds a
+ * reference of its own, so releasing the caller's reference is always safe).
+ *   ndt_cloud_voxel_filter      N1 with the result left in HBM (pts: host memory, or device memory when on_device != 0)
+ *   ndt_cloud_upload            a host cloud as it is
+ *   ndt_set_input_source_cloud / ndt_set_input_target_cloud / ndt_map_update_cloud
+ *                               the three consumers, by reference: no copy, no repack, no bounding-box pass
+ *   ndt_promote_source_to_target  the handle's current input source becomes its input target (cloud k of the pair
+ *                               (k-1, k) is the target of the pair (k, k+1)); the voxel grid is built from the
+ *                               resident points -- for callers that kept no ndt_cloud, e.g. after ndt_set_input_source
+ * Results are bit-identical to the host-buffer entry points (same kernels on the same points).  A cloud belongs to the
+ * device of the handle that made it; handles on other streams of that device may use it (the library orders the streams). */
+typedef struct ndt_cloud_s* ndt_cloud;
+ndt_status ndt_cloud_voxel_filter(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, int is_dense, float leaf_size,
+                                  int on_device, ndt_cloud* out, int* overflowed);
+ndt_status ndt_cloud_upload(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, ndt_cloud* out);
+ndt_status ndt_cloud_size(ndt_cloud c, size_t* n);
+ndt_status ndt_cloud_data(ndt_cloud c, const void** d_pts_float4, size_t* n);               /* the records in HBM */
+ndt_status ndt_cloud_download(ndt_handle h, ndt_cloud c, void* out, size_t out_stride_bytes); /* x,y,z,1.0f per point */
+void ndt_cloud_release(ndt_cloud c);
+ndt_status ndt_set_input_source_cloud(ndt_handle h, ndt_cloud c);
+ndt_status ndt_set_input_target_cloud(ndt_handle h, ndt_cloud c, int is_dense);
+ndt_status ndt_map_update_cloud(ndt_handle h, ndt_cloud scan, int is_dense, const float* pose, float leaf_size, int* overflowed);
+ndt_status ndt_promote_source_to_target(ndt_handle h, int is_dense);
+
 /* ---- PCD files (row N3 of the scope table) -----------------------------------
  * What pcl::io::loadPCDFile<pcl::PointXYZ> hands the callers (ndt_omp/apps/align.cpp:48-55,
  * ndt_omp_mapping_node.cpp:140, ndt_omp_node.cpp:82) and what pcl::io::savePCDFileBinary writes

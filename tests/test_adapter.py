@@ -195,11 +195,14 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
     out = subprocess.check_output([exe, str(d), "0.5", map_out], text=True)
     # "pipeline": the steps of consecutive scans overlap (prep handles, inputs taken over by the registration handle with
     # ndt_share_input_target / _source; with NDT_PIPELINE_PARTITION=1 on CU partitions) -- the same lines, bit for bit
-    strip = lambda o: [ln for ln in o.splitlines() if not ln.startswith("time:") and not ln.startswith("global map written")]
+    strip = lambda o: [ln for ln in o.splitlines() if not ln.startswith("time:") and not ln.startswith("start-up") and not ln.startswith("global map written")]
     for env in ({}, {"NDT_PIPELINE_PARTITION": "1"}):
         out_pipe = subprocess.check_output([exe, str(d), "0.5", "-", "node", "pipeline"], text=True, env=dict(os.environ, **env))
         assert strip(out) == strip(out_pipe)
         assert "overlapped with the registrations" in out_pipe and "file reading overlapped" in out
+    # the default keeps every cloud in HBM (ndt_cloud); "host" sends them through host buffers as rounds 1-3 did: the same lines
+    out_host = subprocess.check_output([exe, str(d), "0.5", "-", "node", "serial", "host"], text=True)
+    assert strip(out) == strip(out_host) and "clouds resident in HBM" in out and "clouds through host buffers" in out_host
     lines = out.splitlines()
     traj = []
     for i, ln in enumerate(lines):
@@ -233,6 +236,7 @@ def test_map_sequence_app_follows_the_mapping_node(built_lib, tmp_path):
     from scipy.spatial import cKDTree
     out = subprocess.check_output([exe, str(d), "0.3", "-", "rosbag"], text=True)
     assert strip(out) == strip(subprocess.check_output([exe, str(d), "0.3", "-", "rosbag", "pipeline"], text=True))
+    assert strip(out) == strip(subprocess.check_output([exe, str(d), "0.3", "-", "rosbag", "serial", "host"], text=True))
     lines = out.splitlines()
     traj = [np.array([[float(x) for x in lines[i + 1 + r].split()] for r in range(4)]) for i, ln in enumerate(lines) if ln.startswith("trajectory[")]
     fit = [float(ln.split()[1]) for ln in lines if ln.startswith("fitness:")]

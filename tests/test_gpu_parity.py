@@ -937,6 +937,80 @@ def test_map_accumulation_matches_reference_loop(mods, pair):
     assert ov and n_map == 2 and np.array_equal(g.mapGet(), far)
 
 
+# ------------------------------------------------------------------ clouds that stay in HBM (ndt_cloud)
+def test_resident_clouds_equal_host_buffers(mods, pair):
+    """The node loop's steps with the filtered scan staying in HBM as an ndt_cloud -- prefilter, source of one registration,
+    target of the next, map update -- against the same steps through host buffers and against the oracle: the points, the
+    grid, the registration and the map are the same bits (the same kernels on the same points)."""
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(5)
+    raw_t = np.repeat(t, 3, axis=0) + rng.normal(0, 0.02, (3 * len(t), 3)).astype(np.float32)
+    raw_s = np.repeat(s, 3, axis=0) + rng.normal(0, 0.02, (3 * len(s), 3)).astype(np.float32)
+    g, href = ndt.NormalDistributionsTransform(), ndt.NormalDistributionsTransform()
+    ct, ov = g.voxelGridFilterCloud(raw_t.astype(np.float32), 0.5)
+    cs, _ = g.voxelGridFilterCloud(raw_s.astype(np.float32), 0.5)
+    ft, fs = po.voxel_grid_filter(raw_t.astype(np.float32), 0.5)[0], po.voxel_grid_filter(raw_s.astype(np.float32), 0.5)[0]
+    assert not ov and len(ct) == len(ft) and np.array_equal(ct.numpy(), ft) and np.array_equal(cs.numpy(), fs)
+    # registration from the resident clouds == from host copies of the same points == the oracle's
+    g.setInputTargetCloud(ct)
+    g.setInputSourceCloud(cs)
+    g.align()
+    href.setInputTarget(ft)
+    href.setInputSource(fs)
+    href.align()
+    assert np.array_equal(g.getFinalTransformation(), href.getFinalTransformation())
+    assert g.getFinalNumIteration() == href.getFinalNumIteration() and g.grid_counts() == href.grid_counts()
+    o = po.OracleNDT(resolution=1.0, num_threads=8)
+    o.set_target(ft)
+    o.set_source(fs)
+    r = o.align()
+    assert rot_err(g.getFinalTransformation(), r["T"]) < 1e-4 and trans_err(g.getFinalTransformation(), r["T"]) < 1e-3
+    d1 = g.grid()
+    d2 = href.grid()
+    for k in ("idx", "n", "mean", "cov", "icov"):
+        assert np.array_equal(d1[k], d2[k]), k
+    # cloud k of the pair (k-1, k) is the target of the pair (k, k+1): promote, no upload
+    g.promoteSourceToTarget()
+    g.setInputSourceCloud(ct)
+    g.align()
+    href.setInputTarget(fs)
+    href.setInputSource(ft)
+    href.align()
+    assert np.array_equal(g.getFinalTransformation(), href.getFinalTransformation())
+    # promote after a plain host upload of the source works the same way
+    h2 = ndt.NormalDistributionsTransform()
+    h2.setInputSource(fs)
+    h2.promoteSourceToTarget()
+    h2.setInputSource(ft)
+    h2.align()
+    assert np.array_equal(h2.getFinalTransformation(), href.getFinalTransformation())
+    # the map update from the resident cloud
+    pose = clouds.make_T([0.30, -0.20, 0.10], np.deg2rad([0.5, -0.3, 1.0])).astype(np.float32)
+    g.mapClear()
+    href.mapClear()
+    g.mapUpdateCloud(ct, None, 0.5)
+    n1, _ = g.mapUpdateCloud(cs, pose, 0.5)
+    href.mapUpdate(ft, None, 0.5)
+    n2, _ = href.mapUpdate(fs, pose, 0.5)
+    assert n1 == n2 and np.array_equal(g.mapGet(), href.mapGet())
+    # a cloud outlives the caller's reference while a handle uses it; another handle (another stream) may use it too
+    cu = g.uploadCloud(fs)
+    other = ndt.NormalDistributionsTransform()
+    other.setInputTargetCloud(ct)
+    other.setInputSourceCloud(cu)
+    cu.release()
+    ct.release()
+    other.align()
+    href.setInputTarget(ft)
+    href.setInputSource(fs)
+    href.align()
+    assert np.array_equal(other.getFinalTransformation(), href.getFinalTransformation())
+    # empty input -> an empty cloud
+    ce, _ = g.voxelGridFilterCloud(np.zeros((0, 3), np.float32), 0.5)
+    assert len(ce) == 0
+
+
 # ------------------------------------------------------------------ configs[4] shape: voxel pyramid
 def test_multiresolution_pyramid_matches_oracle(mods):
     """Coarse-to-fine NDT (2.0 -> 1.0 -> 0.5 m), each level's result the next level's guess

@@ -84,6 +84,17 @@ SIGNATURES = {
     "ndt_map_size": (C.c_int, [vp, szp]),
     "ndt_map_get": (C.c_int, [vp, vp, C.c_size_t]),
     "ndt_map_get_device": (C.c_int, [vp, C.POINTER(C.c_void_p), szp]),
+    "ndt_cloud_voxel_filter": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_int, C.POINTER(vp), ip]),
+    "ndt_warm_up": (C.c_int, [vp]),
+    "ndt_cloud_upload": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
+    "ndt_cloud_size": (C.c_int, [vp, szp]),
+    "ndt_cloud_data": (C.c_int, [vp, C.POINTER(C.c_void_p), szp]),
+    "ndt_cloud_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ndt_cloud_release": (None, [vp]),
+    "ndt_set_input_source_cloud": (C.c_int, [vp, vp]),
+    "ndt_set_input_target_cloud": (C.c_int, [vp, vp, C.c_int]),
+    "ndt_map_update_cloud": (C.c_int, [vp, vp, C.c_int, fp, C.c_float, ip]),
+    "ndt_promote_source_to_target": (C.c_int, [vp, C.c_int]),
     "ndt_host_chain_pose": (None, [fp, fp, fp]),
     "ndt_pcd_read_header": (C.c_int, [C.c_char_p, szp, ip, ip]),
     "ndt_pcd_read_xyz": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.c_size_t, szp, ip]),

@@ -777,8 +777,33 @@ ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float*
 // [PCL] VoxelGrid::applyFilter on a dense float4 device cloud: d_out (capacity n) receives one centroid
 // per occupied voxel in ascending voxel-index order; *overflow = the leaf is too small for the
 // bounding box and, as PCL does, the input was copied through.  Synchronises h->stream.
+// rows of the result's bounding boxes: queued behind the centroids, read by the host behind the synchronisation that brings
+// the count -- no second round trip (n_dev: the count where the filter left it)
+static constexpr int kOutBoxBlocks = 64;
+static ndt_status queue_out_boxes(ndt_handle h, const float4* d_out, size_t n_max, const unsigned* n_dev) {
+  if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
+  const int nb = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (n_max + 255) / 256));
+  HIP_TRY(ndt::launch_repack_bbox(d_out, n_max, sizeof(float4), nullptr, h->bbox_rows, nb, h->stream, 0, n_dev));
+  return NDT_OK;
+}
+static void read_out_boxes(ndt_handle h, size_t n_max, DeviceCloud* c) {
+  const int nb = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (n_max + 255) / 256));
+  for (int v = 0; v < 2; v++)
+    for (int k = 0; k < 3; k++) {
+      c->bb_min[v][k] = FLT_MAX;
+      c->bb_max[v][k] = -FLT_MAX;
+    }
+  const float* mm = h->bbox_rows;
+  for (int b = 0; b < nb; b++)
+    for (int v = 0; v < 2; v++)
+      for (int k = 0; k < 3; k++) {
+        c->bb_min[v][k] = std::min(c->bb_min[v][k], mm[b * 12 + v * 6 + k]);
+        c->bb_max[v][k] = std::max(c->bb_max[v][k], mm[b * 12 + v * 6 + 3 + k]);
+      }
+}
+
 ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
-                                      size_t* n_out, bool* overflow, const BBox* known_bbox) {
+                                      size_t* n_out, bool* overflow, const BBox* known_bbox, DeviceCloud* out_boxes) {
   *n_out = 0;
   *overflow = false;
   if (n == 0) return NDT_OK;
@@ -800,7 +825,9 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   }
   if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
     HIP_TRY(hipMemcpyAsync(d_out, d_in, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
+    if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, nullptr); if (sq) return sq; }
     HIP_TRY(hipStreamSynchronize(st));
+    if (out_boxes) read_out_boxes(h, n, out_boxes);
     *n_out = n;
     *overflow = true;
     return NDT_OK;
@@ -839,7 +866,9 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
     HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(max_l), sorted_idx.p, d_out, st, totals.p, big2.p));
     unsigned tot2[3];
     HIP_TRY(hipMemcpyAsync(tot2, totals.p, sizeof(tot2), hipMemcpyDeviceToHost, st));
+    if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, totals.p + 1); if (sq) return sq; }
     HIP_TRY(hipStreamSynchronize(st));
+    if (out_boxes) read_out_boxes(h, n, out_boxes);
     *n_out = tot2[1];
     return NDT_OK;
   }
@@ -867,7 +896,9 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p, big_pts.p));
   unsigned tot[3];
   HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+  if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, totals.p + 1); if (sq) return sq; }
   HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
+  if (out_boxes) read_out_boxes(h, n, out_boxes);
   *n_out = tot[1];
   return NDT_OK;
 }
@@ -1031,32 +1062,87 @@ ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t 
 // ndt_rosbag_mapping_node.cpp:146-161): transformPointCloud(scan, pose); global_map += it;
 // global_map = VoxelGrid(leaf).filter(global_map).  The map stays in HBM.
 static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, bool on_device,
-                                  const float* pose, float leaf, int* overflowed) {
+                                  const float* pose, float leaf, int* overflowed, const std::shared_ptr<DeviceCloud>* resident = nullptr) {
   if (!h || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
   if (overflowed) *overflowed = 0;
   std::shared_ptr<DeviceCloud> c;
-  ndt_status s = upload_cloud(h, scan, n, stride, on_device, c);
+  ndt_status s = NDT_OK;
+  if (resident) c = *resident;  // an ndt_cloud: read where it lies
+  else s = upload_cloud(h, scan, n, stride, on_device, c);
   if (s) return s;
   const size_t total = h->map_n + n;
   if (total > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "map too large");
   if (total == 0) return NDT_OK;
-  // concatenation [map | transformed scan] (operator+= keeps the map's points first)
-  DevBuf<float4> cat;
-  HIP_TRY(cat.reserve(total));
-  if (h->map_n) HIP_TRY(hipMemcpyAsync(cat.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
-  if (n) {
-    float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    float T12[12];
-    colmajor_to_T12(pose ? pose : I, T12);
-    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, cat.p + h->map_n, h->stream, is_dense));
+  // concatenation [map | transformed scan] (operator+= keeps the map's points first): the scan is transformed straight into
+  // the room behind the map -- the map is not copied
+  if (h->map_pts.cap < total) {
+    DevBuf<float4> bigger;
+    HIP_TRY(bigger.reserve(total + total / 2 + n));
+    if (h->map_n) HIP_TRY(hipMemcpyAsync(bigger.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    h->map_pts.swap(bigger);  // (the old block goes back to the pool behind the copy, stream order)
   }
-  HIP_TRY(h->map_pts.reserve(total));
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* P = pose ? pose : I;
+  if (n) {
+    float T12[12];
+    colmajor_to_T12(P, T12);
+    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, h->map_pts.p + h->map_n, h->stream, is_dense));
+  }
+  HIP_TRY(h->map_alt.reserve(total + total / 2 + n));
   size_t n_new = 0;
   bool overflow = false;
   // the accumulated map is dense only if every scan was; PCL carries is_dense through operator+=
   h->map_dense = (h->map_n == 0 ? 1 : h->map_dense) && is_dense;
-  s = voxel_filter_device(h, cat.p, total, h->map_dense, leaf, h->map_pts.p, &n_new, &overflow);
+  // A box for the filter without a pass over the points: the map's own box (the last pass left it) joined with the box of the
+  // scan's box under the pose, padded for the f32 rounding of the transform.  ANY box that holds the points gives the same
+  // voxels in the same order -- a voxel is floor(x / leaf) whatever min_b is, and the linear index orders the voxels by
+  // (z, y, x) for every box -- so the result is PCL's bit for bit; only the index-overflow test wants the exact box, and it
+  // is computed when the padded one overflows.
+  BBox guess{};
+  bool have_guess = (h->map_n == 0 || h->map_boxes_known);
+  const int v = h->map_dense ? 0 : 1;
+  if (have_guess) {
+    for (int k = 0; k < 3; k++) {
+      guess.mn[k] = h->map_n ? h->map_boxes.bb_min[v][k] : FLT_MAX;
+      guess.mx[k] = h->map_n ? h->map_boxes.bb_max[v][k] : -FLT_MAX;
+    }
+    if (n) {
+      const BBox sb = bbox_of(*c, is_dense);
+      if (sb.mn[0] <= sb.mx[0]) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0;
+        for (int corner = 0; corner < 8; corner++) {
+          const double q[3] = {(corner & 1) ? sb.mx[0] : sb.mn[0], (corner & 2) ? sb.mx[1] : sb.mn[1], (corner & 4) ? sb.mx[2] : sb.mn[2]};
+          for (int r = 0; r < 3; r++) {
+            double a = P[12 + r], m = std::fabs(a);
+            for (int k = 0; k < 3; k++) {
+              a += static_cast<double>(P[4 * k + r]) * q[k];
+              m += std::fabs(static_cast<double>(P[4 * k + r]) * q[k]);
+            }
+            lo[r] = std::min(lo[r], a);
+            hi[r] = std::max(hi[r], a);
+            mag = std::max(mag, m);
+          }
+        }
+        const double pad = 1e-5 * mag + 1e-6;  // (a transformed coordinate is three f32 multiply-adds: a few ulps of the terms)
+        for (int r = 0; r < 3; r++) {
+          guess.mn[r] = std::min(guess.mn[r], static_cast<float>(lo[r] - pad));
+          guess.mx[r] = std::max(guess.mx[r], static_cast<float>(hi[r] + pad));
+        }
+        for (int r = 0; r < 3; r++) have_guess = have_guess && std::isfinite(guess.mn[r]) && std::isfinite(guess.mx[r]);
+      }
+    }
+    if (have_guess && guess.mn[0] <= guess.mx[0]) {  // would the padded box overflow the index space?  then the exact one decides
+      long long d[3];
+      for (int k = 0; k < 3; k++) d[k] = static_cast<long long>((guess.mx[k] - guess.mn[k]) * (1.0f / leaf)) + 1;
+      if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max()) / 2) have_guess = false;
+    } else {
+      have_guess = false;
+    }
+  }
+  s = voxel_filter_device(h, h->map_pts.p, total, h->map_dense, leaf, h->map_alt.p, &n_new, &overflow, have_guess ? &guess : nullptr, &h->map_boxes);
   if (s) return s;
+  h->map_boxes_known = true;
+  h->map_pts.swap(h->map_alt);
   h->map_n = n_new;
   if (overflowed) *overflowed = overflow ? 1 : 0;
   return NDT_OK;
@@ -1066,8 +1152,166 @@ ndt_status ndt_map_clear(ndt_handle h) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   h->map_n = 0;
   h->map_dense = 1;
+  h->map_boxes_known = false;
   return NDT_OK;
 }
+// ---- ndt_cloud: clouds that stay in HBM between the steps of a node's loop ----------------------------------------------
+// the cloud is about to be read by work on h's stream: order that stream behind the cloud's making, remember it for the
+// cloud's release
+static ndt_status cloud_use_on(ndt_handle h, DeviceCloud* c) {
+  if (c->made_on && c->made_on != h->stream) {
+    if (c->device != h->device) return fail(NDT_ERR_INVALID, "the cloud lives on another device");
+    HIP_TRY(hipStreamSynchronize(c->made_on));
+    if (std::find(c->used_on.begin(), c->used_on.end(), h->stream) == c->used_on.end()) c->used_on.push_back(h->stream);
+  }
+  return NDT_OK;
+}
+
+ndt_status ndt_cloud_voxel_filter(ndt_handle h, const void* pts, size_t n, size_t stride, int is_dense, float leaf, int on_device,
+                                  ndt_cloud* out, int* overflowed) {
+  if (!h || !out || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  if (overflowed) *overflowed = 0;
+  std::shared_ptr<DeviceCloud> in;
+  // (a device cloud of 16-byte records is read where it lies; everything it is needed for is over when this returns)
+  const bool ref_ok = on_device && n > 0 && stride == sizeof(float4) && (reinterpret_cast<uintptr_t>(pts) & 15) == 0;
+  ndt_status s = upload_cloud(h, pts, n, stride, on_device != 0, in, ref_ok);
+  if (s) return s;
+  auto c = std::make_shared<DeviceCloud>();
+  c->device = h->device;
+  c->made_on = h->stream;
+  HIP_TRY(c->pts.reserve(std::max<size_t>(n, 1)));
+  size_t n_written = 0;
+  bool overflow = false;
+  if (n) {
+    const BBox bb = bbox_of(*in, is_dense);
+    s = voxel_filter_device(h, in->pts.p, n, is_dense, leaf, c->pts.p, &n_written, &overflow, &bb, c.get());
+    if (s) return s;
+  }
+  c->n = n_written;
+  if (overflowed) *overflowed = overflow ? 1 : 0;
+  *out = new ndt_cloud_s{c};
+  return NDT_OK;
+}
+
+ndt_status ndt_cloud_upload(ndt_handle h, const void* pts, size_t n, size_t stride, ndt_cloud* out) {
+  if (!h || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  std::shared_ptr<DeviceCloud> c;
+  ndt_status s = upload_cloud(h, pts, n, stride, false, c);
+  if (s) return s;
+  c->device = h->device;
+  c->made_on = h->stream;
+  *out = new ndt_cloud_s{c};
+  return NDT_OK;
+}
+
+ndt_status ndt_cloud_size(ndt_cloud c, size_t* n) {
+  if (!c || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *n = c->c->n;
+  return NDT_OK;
+}
+ndt_status ndt_cloud_data(ndt_cloud c, const void** d_pts, size_t* n) {
+  if (!c || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *d_pts = c->c->pts.p;
+  *n = c->c->n;
+  return NDT_OK;
+}
+ndt_status ndt_cloud_download(ndt_handle h, ndt_cloud c, void* out, size_t out_stride) {
+  if (!h || !c || (c->c->n && !out)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+  ndt_status s = ensure_device(h);
+  if (!s) s = cloud_use_on(h, c->c.get());
+  if (s) return s;
+  return download_records(h, c->c->pts.p, c->c->n, out, out_stride);
+}
+void ndt_cloud_release(ndt_cloud c) { delete c; }
+
+ndt_status ndt_set_input_source_cloud(ndt_handle h, ndt_cloud c) {
+  if (!h || !c) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = ensure_device(h);
+  if (!s) s = cloud_use_on(h, c->c.get());
+  if (s) return s;
+  // Big scans are registered from a copy in lattice order whose pitch is this handle's resolution (order_cloud): that copy
+  // belongs to the handle, not to the shared cloud -- a view of the cloud's points with an ordered copy of its own.
+  auto view = std::make_shared<DeviceCloud>();
+  view->pts.borrow(c->c->pts.p, c->c->n);
+  view->n = c->c->n;
+  std::memcpy(view->bb_min, c->c->bb_min, sizeof(view->bb_min));
+  std::memcpy(view->bb_max, c->c->bb_max, sizeof(view->bb_max));
+  s = order_cloud(h, view.get(), nullptr, 0);
+  if (s) return s;
+  if (view->n_sorted == 0) {  // (the usual case at the nodes' size: nothing to order, the cloud itself is the source)
+    h->source = c->c;
+    return NDT_OK;
+  }
+  view->parent = c->c;
+  h->source = view;
+  return NDT_OK;
+}
+ndt_status ndt_set_input_target_cloud(ndt_handle h, ndt_cloud c, int is_dense) {
+  if (!h || !c) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = ensure_device(h);
+  if (!s) s = cloud_use_on(h, c->c.get());
+  if (s) return s;
+  h->target = c->c;
+  h->target_dense = is_dense ? 1 : 0;
+  return build_grid(h);
+}
+ndt_status ndt_promote_source_to_target(ndt_handle h, int is_dense) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (!h->source) return fail(NDT_ERR_NO_INPUT, "no input source to promote");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  // the resident points and their boxes: no upload, no repack, no bounding-box pass (a view made for ordering: its parent)
+  h->target = h->source->parent ? h->source->parent : h->source;
+  h->target_dense = is_dense ? 1 : 0;
+  return build_grid(h);
+}
+
+ndt_status ndt_map_update_cloud(ndt_handle h, ndt_cloud scan, int is_dense, const float* pose, float leaf, int* overflowed) {
+  if (!h || !scan) return fail(NDT_ERR_INVALID, "bad arguments");
+  ndt_status s = ensure_device(h);
+  if (!s) s = cloud_use_on(h, scan->c.get());
+  if (s) return s;
+  return map_update_impl(h, nullptr, scan->c->n, sizeof(float4), is_dense, true, pose, leaf, overflowed, &scan->c);
+}
+
+ndt_status ndt_warm_up(ndt_handle h) {
+  if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  ndt_status s = ensure_device(h);
+  if (!s) s = ensure_host_rows(h, 1);
+  if (s) return s;
+  if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
+  // a scratch handle with the same parameters runs the loop's calls once on a few hundred points: code object, kernels, pool
+  ndt_handle t = nullptr;
+  s = ndt_clone(h, &t);
+  if (s) return s;
+  std::vector<float> pts;
+  for (int i = 0; i < 24; i++)
+    for (int j = 0; j < 24; j++)
+      for (int k = 0; k < 2; k++) {
+        const float u = 0.37f * i + 0.011f * j, v = 0.41f * j + 0.007f * i;
+        pts.insert(pts.end(), {u, v, 0.3f * k + 0.05f * std::sin(u + v), 1.0f});
+      }
+  const size_t n = pts.size() / 4;
+  ndt_cloud c = nullptr;
+  int ov = 0, conv = 0, it = 0;
+  float T[16];
+  double prob = 0;
+  s = ndt_cloud_voxel_filter(t, pts.data(), n, 16, 1, 0.2f, 0, &c, &ov);
+  if (!s) s = ndt_set_input_target_cloud(t, c, 1);
+  if (!s) s = ndt_set_input_source_cloud(t, c);
+  if (!s) s = ndt_align(t, nullptr, T, &conv, &it, &prob, nullptr, 0);
+  if (!s) s = ndt_map_update_cloud(t, c, 1, nullptr, 0.5f, &ov);
+  if (!s) s = ndt_set_input_target(t, pts.data(), n, 16, 1);
+  if (!s) s = ndt_set_input_source(t, pts.data(), n, 16);
+  ndt_cloud_release(c);
+  ndt_destroy(t);
+  tls_pool_stream = h->stream;
+  return s;
+}
+
 ndt_status ndt_map_update(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, const float* pose, float leaf,
                           int* overflowed) {
   return map_update_impl(h, scan, n, stride, is_dense, false, pose, leaf, overflowed);

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(kBlock) void k_repack_bbox(const unsigned char* __r
 // instead of synchronising the stream (a cloud handed over by reference has no copy the host would have to wait for anyway)
 template <bool COPY>
 __global__ __launch_bounds__(kBlock) void k_bbox16(const float4* __restrict__ src, size_t n, float4* __restrict__ dst,
-                                                  float* __restrict__ block_minmax, unsigned tag) {
+                                                  float* __restrict__ block_minmax, unsigned tag, const unsigned* __restrict__ n_dev) {
+  if (n_dev) n = *n_dev;  // (a count that is still on the device: the voxel filter's output)
   float mn[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
   float mx[6] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
@@ -2105,14 +2106,14 @@ hipError_t launch_repack(const void* d_src, size_t n, size_t stride_bytes, float
 }
 
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
-                              int n_blocks, hipStream_t stream, unsigned tag) {
+                              int n_blocks, hipStream_t stream, unsigned tag, const unsigned* n_dev) {
   if (n == 0) return hipSuccess;
   const bool rec16 = stride_bytes == 16 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0;
-  if (tag && !rec16) return hipErrorInvalidValue;  // tagged rows: the 16-byte-record forms only
+  if ((tag || n_dev) && !rec16) return hipErrorInvalidValue;  // tagged rows, device-side counts: the 16-byte-record forms only
   if (rec16 && !d_dst)
-    hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax, tag);
+    hipLaunchKernelGGL(k_bbox16<false>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, nullptr, d_block_minmax, tag, n_dev);
   else if (rec16)
-    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax, tag);
+    hipLaunchKernelGGL(k_bbox16<true>, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const float4*>(d_src), n, d_dst, d_block_minmax, tag, n_dev);
   else
     hipLaunchKernelGGL(k_repack_bbox, dim3(n_blocks), dim3(kBlock), 0, stream, static_cast<const unsigned char*>(d_src), n,
                        stride_bytes, d_dst, d_block_minmax);

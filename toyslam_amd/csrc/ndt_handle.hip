@@ -14,6 +14,7 @@ void ndt_context::release_buffers() {
   out_cloud.release();
   staging.release();
   map_pts.release();
+  map_alt.release();
   server_dev_mb.release();
   server_counter.release();
   server_dbg.release();

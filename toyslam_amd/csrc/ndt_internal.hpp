@@ -199,7 +199,26 @@ struct DeviceCloud {
   std::vector<size_t> scan_starts;  // ... and where its ordered segment starts in `sorted`
   const float4* k2_pts() const { return n_sorted ? sorted.p : pts.p; }
   int k2_n() const { return static_cast<int>(n_sorted ? n_sorted : n); }
+  // An ndt_cloud (a cloud the caller holds as an object and hands to several consumers): the stream it was made on -- its
+  // memory goes back to THAT stream's pool, whichever thread or handle drops the last reference -- and the other streams
+  // it has been read on (waited for before the memory is given back).  Null for the handles' own uploads.
+  int device = -1;
+  hipStream_t made_on = nullptr;
+  std::vector<hipStream_t> used_on;
+  std::shared_ptr<DeviceCloud> parent;  // a view of another cloud's points (pts borrowed) with an ordered copy of its own
+  ~DeviceCloud() {
+    if (!made_on) return;
+    (void)hipSetDevice(device);
+    for (hipStream_t s : used_on)
+      if (s != made_on) (void)hipStreamSynchronize(s);
+    const hipStream_t keep = tls_pool_stream;
+    tls_pool_stream = made_on;
+    pts.release();
+    sorted.release();
+    tls_pool_stream = keep;
+  }
 };
+
 
 // Immutable once built (shared between cloned handles).
 struct DeviceGrid {
@@ -246,6 +265,11 @@ struct DeviceGrid {
 
 }  // namespace ndtc
 using namespace ndtc;
+
+// the C-ABI's ndt_cloud
+struct ndt_cloud_s {
+  std::shared_ptr<DeviceCloud> c;
+};
 
 struct ndt_context;
 namespace ndtc {
@@ -306,9 +330,12 @@ struct ndt_context {
   bool server_running = false;
   int server_blocks = 0;  // grid of the running server: min(16, blocks) part rows come back per evaluation
   // N2: accumulated global map (dense float4, HBM resident)
-  DevBuf<float4> map_pts;
+  DevBuf<float4> map_pts;   // the map, with room behind it: the next scan is transformed straight into its tail
+  DevBuf<float4> map_alt;   // where the next filter pass writes (the two swap roles)
   size_t map_n = 0;
   int map_dense = 1;
+  DeviceCloud map_boxes;    // bounding boxes of the map as the last filter pass left it (bb_min / bb_max only)
+  bool map_boxes_known = false;
   int voxel_index = 0;              // ndt_set_voxel_index: 0 automatic, 1 dense table, 2 sparse (sorted build + hash look-up)
   bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
@@ -417,8 +444,9 @@ float index_slack(const DeviceGrid* g);
 ndt_status download_records(ndt_context* h, const float4* d_src, size_t n, void* out, size_t out_stride);
 void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix);
 ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness);
+// out_boxes: the result's bounding boxes as DeviceCloud keeps them ([2][3] min, [2][3] max), or null
 ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
-                               size_t* n_out, bool* overflow, const BBox* known_bbox = nullptr);
+                               size_t* n_out, bool* overflow, const BBox* known_bbox = nullptr, DeviceCloud* out_boxes = nullptr);
 // ---- ndt_eval.hip
 void colmajor_to_T12(const float* m, float* T12);
 float kd_radius2(float resolution);

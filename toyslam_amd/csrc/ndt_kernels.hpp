@@ -176,7 +176,7 @@ hipError_t launch_copy_records(const float4* src_host_pinned, float4* dst, int n
 // repack + bounding boxes (block rows of 12 floats: non-NaN min/max xyz, finite-only min/max xyz); 16-byte records on a
 // 16-byte boundary take a float4 path, and with d_dst == nullptr only the boxes are computed (cloud used where it lies)
 hipError_t launch_repack_bbox(const void* d_src, size_t n, size_t stride_bytes, float4* d_dst, float* d_block_minmax,
-                              int n_blocks, hipStream_t stream, unsigned tag = 0);
+                              int n_blocks, hipStream_t stream, unsigned tag = 0, const unsigned* n_dev = nullptr);  // n_dev: the count, still on the device
 hipError_t launch_bbox(const float4* pts, int n, int dense, float* d_block_minmax, int n_blocks, hipStream_t stream);
 hipError_t launch_count(const float4* pts, int n, int dense, const GridGeom& g, int* d_key, unsigned* d_rank,
                         unsigned* d_cell_count, hipStream_t stream);

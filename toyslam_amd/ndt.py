@@ -43,6 +43,40 @@ def _from_colmajor(v):
     return np.asarray(v, dtype=np.float32).reshape(4, 4).T.copy()
 
 
+class DeviceCloud:
+    """An ndt_cloud: a cloud resident in HBM with its bounding boxes (include/ndt_mi355.h, "clouds that stay in HBM")."""
+
+    def __init__(self, owner, c):
+        self._owner, self._c, self._L = owner, c, owner._L
+
+    def __len__(self):
+        n = C.c_size_t(0)
+        check(self._L.ndt_cloud_size(self._c, C.byref(n)))
+        return n.value
+
+    def data_ptr(self):
+        p, n = C.c_void_p(None), C.c_size_t(0)
+        check(self._L.ndt_cloud_data(self._c, C.byref(p), C.byref(n)))
+        return p.value or 0
+
+    def numpy(self):
+        n = len(self)
+        out = np.zeros((max(n, 1), 4), dtype=np.float32)
+        check(self._L.ndt_cloud_download(self._owner._h, self._c, out.ctypes.data, 16))
+        return out[:n, :3].copy()
+
+    def release(self):
+        if self._c:
+            self._L.ndt_cloud_release(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class NormalDistributionsTransform:
     """Drop-in shaped like pclomp::NormalDistributionsTransform<PointT, PointT>."""
 
@@ -227,6 +261,37 @@ class NormalDistributionsTransform:
         out = np.zeros((max(n, 1), 4), dtype=np.float32)
         check(self._L.ndt_map_get(self._h, out.ctypes.data, 16))
         return out[:n, :3].copy()
+
+    # ---- clouds that stay in HBM (ndt_cloud) ------------------------------------------
+    def voxelGridFilterCloud(self, cloud, leaf_size, is_dense=True):
+        """N1 with the result left in HBM: -> (DeviceCloud, overflowed)."""
+        a = _cloud(cloud)
+        c, ov = C.c_void_p(None), C.c_int(0)
+        check(self._L.ndt_cloud_voxel_filter(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, int(is_dense), float(leaf_size), 0,
+                                             C.byref(c), C.byref(ov)))
+        return DeviceCloud(self, c), bool(ov.value)
+
+    def uploadCloud(self, cloud):
+        a = _cloud(cloud)
+        c = C.c_void_p(None)
+        check(self._L.ndt_cloud_upload(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, C.byref(c)))
+        return DeviceCloud(self, c)
+
+    def setInputSourceCloud(self, dc):
+        check(self._L.ndt_set_input_source_cloud(self._h, dc._c))
+
+    def setInputTargetCloud(self, dc, is_dense=True):
+        check(self._L.ndt_set_input_target_cloud(self._h, dc._c, int(is_dense)))
+
+    def promoteSourceToTarget(self, is_dense=True):
+        """The current input source becomes the input target (cloud k of pair (k-1, k) is the target of pair (k, k+1))."""
+        check(self._L.ndt_promote_source_to_target(self._h, int(is_dense)))
+
+    def mapUpdateCloud(self, dc, pose=None, leaf_size=0.5, is_dense=True):
+        T = None if pose is None else _colmajor(pose)
+        ov = C.c_int(0)
+        check(self._L.ndt_map_update_cloud(self._h, dc._c, int(is_dense), _f(T) if T is not None else None, float(leaf_size), C.byref(ov)))
+        return self.mapSize(), bool(ov.value)
 
     # ---- batch (map-build) ---------------------------------------------------------
     def alignBatch(self, clouds=None, guesses=None, device_ptr=None, offsets=None, stride_bytes=16):
