@@ -177,6 +177,7 @@ static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_lea
         break;
       }
       node.t_filter += since(t0);
+      if (std::getenv("MAP_SEQUENCE_TRACE")) std::fprintf(stderr, "[scan %d] prefilter %.1f us\n", number, since(t0) * 1e3);
       if (m == 0) {  // :128 -- empty clouds are not kept
         ndt_cloud_release(current);
         continue;
@@ -492,8 +493,8 @@ int main(int argc, char** argv) {
   // a node constructs its objects (and a GPU library loads its code, creates its streams, page-locks its slots) before the
   // first scan arrives: not part of any scan's time
   const auto t_warm = clock_type::now();
-  CHECK(ndt_warm_up(h));
-  if (map_handle) CHECK(ndt_warm_up(map_handle));
+  CHECK(ndt_warm_up(h, 65536));  // (a node knows its sensor: the reference's scans are lidar sweeps of some ten thousand points)
+  if (map_handle) CHECK(ndt_warm_up(map_handle, 65536));
   const double warm_ms = since(t_warm);
   const auto t_begin = clock_type::now();
   const int rc = !serial ? run_pipelined(node, seq, voxel_leaf_size, h, map_handle)

@@ -189,10 +189,12 @@ ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride_bytes); /* x,y
 ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts_float4, size_t* n);
 void ndt_host_chain_pose(const float* pose /*16*/, const float* transform /*16*/, float* out /*16, may alias*/);
 
-/* What a node does once, at start-up, instead of inside its first scan: the device context, the library's code object (tens
- * of milliseconds on first use), the handle's page-locked result / staging slots, and one tiny registration, voxel filter and
- * map update on a scratch handle so that every kernel of the loop has been launched once.  Changes nothing observable on `h`. */
-ndt_status ndt_warm_up(ndt_handle h);
+/* What a node does once, at start-up, instead of inside its first scans: the device context, the library's code object (tens
+ * of milliseconds on first use), the handle's page-locked result / staging slots, and one pass through the loop's calls
+ * (voxel filter, target grid, registration, map update) on a synthetic scan of `expected_scan_points` points, so that every
+ * kernel has been launched once and the handle's memory pool holds blocks of the sizes the real scans will ask for.
+ * The handle's inputs, last result and map are left as they were. */
+ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points);
 
 /* ---- clouds that stay in HBM: the node loop without host round trips -----------------------------------------------
  * In all three mapping nodes a filtered scan is used four times: as the output of the prefilter

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from toyslam_amd import _lib, clouds, ndt
-n_scans, n_raw = 12, 60000
+n_scans, n_raw = 40, 60000
 rng = np.random.default_rng(3)
 world = clouds.target_surfaces(4 * n_raw, seed=77, extent=60.0)[:, :3].astype(np.float32)
 tmp = tempfile.mkdtemp(prefix="nodeloop_")
@@ -17,6 +17,6 @@ exe = os.path.join(tmp, "map_sequence")
 libdir = os.path.join(ROOT, "toyslam_amd")
 subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "map_sequence.cpp"),
                        "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
-r = subprocess.run([exe, tmp, "0.5", "-", "node"], text=True, capture_output=True, env=dict(os.environ, NDT_TRACE_N1="1"))
-print(r.stderr[-1500:])
+r = subprocess.run([exe, tmp, "0.5", "-", "node"], text=True, capture_output=True, env=dict(os.environ, MAP_SEQUENCE_TRACE="1"))
+print(r.stderr[:1200]); print(r.stderr[-600:])
 print([ln for ln in r.stdout.splitlines() if ln.startswith("time:") or ln.startswith("Loaded")][-3:])

@@ -85,7 +85,7 @@ SIGNATURES = {
     "ndt_map_get": (C.c_int, [vp, vp, C.c_size_t]),
     "ndt_map_get_device": (C.c_int, [vp, C.POINTER(C.c_void_p), szp]),
     "ndt_cloud_voxel_filter": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_int, C.POINTER(vp), ip]),
-    "ndt_warm_up": (C.c_int, [vp]),
+    "ndt_warm_up": (C.c_int, [vp, C.c_size_t]),
     "ndt_cloud_upload": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
     "ndt_cloud_size": (C.c_int, [vp, szp]),
     "ndt_cloud_data": (C.c_int, [vp, C.POINTER(C.c_void_p), szp]),

@@ -1277,38 +1277,83 @@ ndt_status ndt_map_update_cloud(ndt_handle h, ndt_cloud scan, int is_dense, cons
   return map_update_impl(h, nullptr, scan->c->n, sizeof(float4), is_dense, true, pose, leaf, overflowed, &scan->c);
 }
 
-ndt_status ndt_warm_up(ndt_handle h) {
+ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
   ndt_status s = ensure_device(h);
   if (!s) s = ensure_host_rows(h, 1);
   if (s) return s;
   if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
-  // a scratch handle with the same parameters runs the loop's calls once on a few hundred points: code object, kernels, pool
-  ndt_handle t = nullptr;
-  s = ndt_clone(h, &t);
-  if (s) return s;
-  std::vector<float> pts;
-  for (int i = 0; i < 24; i++)
-    for (int j = 0; j < 24; j++)
-      for (int k = 0; k < 2; k++) {
-        const float u = 0.37f * i + 0.011f * j, v = 0.41f * j + 0.007f * i;
-        pts.insert(pts.end(), {u, v, 0.3f * k + 0.05f * std::sin(u + v), 1.0f});
-      }
-  const size_t n = pts.size() / 4;
-  ndt_cloud c = nullptr;
+  // The loop's calls once on this handle's stream (its memory pool, its staging buffers), on a synthetic scan of the expected
+  // size -- a slab of 100 m x 100 m x 10 m, roughly a lidar sweep's extent: code object, kernels, page-locked slots, and pool
+  // blocks of the sizes the real scans will ask for.  The handle's inputs, results and map are put back afterwards.
+  const size_t n = std::max<size_t>(expected_scan_points, 1152);
+  std::vector<float> pts(4 * n);
+  unsigned long long z = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {  // splitmix64 -> [0, 1)
+    z += 0x9E3779B97F4A7C15ull;
+    unsigned long long x = z;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return static_cast<float>(x >> 40) * (1.0f / 16777216.0f);
+  };
+  for (size_t i = 0; i < n; i++) {
+    pts[4 * i] = 100.0f * rnd() - 50.0f;
+    pts[4 * i + 1] = 100.0f * rnd() - 50.0f;
+    pts[4 * i + 2] = (i & 3) ? 0.2f * rnd() : 10.0f * rnd() - 5.0f;  // mostly a ground sheet: voxels with enough points
+    pts[4 * i + 3] = 1.0f;
+  }
+  const auto keep_source = h->source;
+  const auto keep_target = h->target;
+  const auto keep_grid = h->grid;
+  const int keep_dense = h->target_dense, keep_iter = h->max_iter;
+  const int keep_conv = h->converged, keep_nr = h->nr_iterations, keep_evals = h->n_evals, keep_hess = h->n_hess;
+  const double keep_prob = h->trans_probability, keep_nn = h->mean_neighbors;
+  float keep_T[16];
+  std::memcpy(keep_T, h->final_T, sizeof(keep_T));
+  DevBuf<float4> keep_map, keep_alt;
+  keep_map.swap(h->map_pts);
+  keep_alt.swap(h->map_alt);
+  const size_t keep_map_n = h->map_n;
+  const int keep_map_dense = h->map_dense;
+  const bool keep_boxes_known = h->map_boxes_known;
+  h->map_n = 0;
+  h->map_boxes_known = false;
+  h->max_iter = 2;
+  ndt_cloud c = nullptr, d = nullptr;
   int ov = 0, conv = 0, it = 0;
   float T[16];
   double prob = 0;
-  s = ndt_cloud_voxel_filter(t, pts.data(), n, 16, 1, 0.2f, 0, &c, &ov);
-  if (!s) s = ndt_set_input_target_cloud(t, c, 1);
-  if (!s) s = ndt_set_input_source_cloud(t, c);
-  if (!s) s = ndt_align(t, nullptr, T, &conv, &it, &prob, nullptr, 0);
-  if (!s) s = ndt_map_update_cloud(t, c, 1, nullptr, 0.5f, &ov);
-  if (!s) s = ndt_set_input_target(t, pts.data(), n, 16, 1);
-  if (!s) s = ndt_set_input_source(t, pts.data(), n, 16);
-  ndt_cloud_release(c);
-  ndt_destroy(t);
-  tls_pool_stream = h->stream;
+  for (int round = 0; round < 2 && !s; round++) {  // (twice: the second round finds the pool's blocks and leaves them sized)
+    s = ndt_cloud_voxel_filter(h, pts.data(), n, 16, 1, 0.5f, 0, &c, &ov);
+    if (!s) s = ndt_cloud_voxel_filter(h, pts.data(), n, 16, 1, 0.3f, 0, &d, &ov);
+    if (!s) s = ndt_set_input_target_cloud(h, c, 1);
+    if (!s) s = ndt_set_input_source_cloud(h, d);
+    if (!s) s = ndt_align(h, nullptr, T, &conv, &it, &prob, nullptr, 0);
+    if (!s) s = ndt_map_update_cloud(h, c, 1, nullptr, 0.5f, &ov);
+    if (!s) s = ndt_map_update_cloud(h, d, 1, nullptr, 0.5f, &ov);
+    ndt_cloud_release(c);
+    ndt_cloud_release(d);
+    c = d = nullptr;
+  }
+  if (!s) HIP_TRY(hipStreamSynchronize(h->stream));
+  h->source = keep_source;
+  h->target = keep_target;
+  h->grid = keep_grid;
+  h->target_dense = keep_dense;
+  h->max_iter = keep_iter;
+  h->map_pts.swap(keep_map);
+  h->map_alt.swap(keep_alt);
+  h->map_n = keep_map_n;
+  h->map_dense = keep_map_dense;
+  h->map_boxes_known = keep_boxes_known && keep_map_n == 0 ? false : keep_boxes_known;
+  h->converged = keep_conv;
+  h->nr_iterations = keep_nr;
+  h->n_evals = keep_evals;
+  h->n_hess = keep_hess;
+  h->trans_probability = keep_prob;
+  h->mean_neighbors = keep_nn;
+  std::memcpy(h->final_T, keep_T, sizeof(keep_T));
   return s;
 }
 
