@@ -107,7 +107,7 @@ struct Node {
   std::vector<float> pose = std::vector<float>(kIdentity, kIdentity + 16);
   std::vector<float> pres_transform = std::vector<float>(kIdentity, kIdentity + 16);  // rosbag node :33,95
   size_t loaded = 0, registered = 0, not_converged = 0;
-  double t_filter = 0, t_align = 0, t_map = 0;
+  double t_filter = 0, t_align = 0, t_map = 0, t_wait = 0;  // t_wait: for the next file (the reader runs ahead in the background)
 
   // after align: -> whether the scan goes into the global map, and with which pose
   bool after_align(ndt_handle h, float* T, int converged, int iterations, std::vector<float>& map_pose, std::string& err) {
@@ -161,7 +161,9 @@ static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_lea
       const void* raw = nullptr;
       size_t n = 0;
       int dense = 1, number = -1;
+      const auto t_next = clock_type::now();
       const ndt_status s = ndt_pcd_sequence_next(seq, &raw, &n, &dense, &number);
+      node.t_wait += since(t_next);
       if (s != NDT_OK) {
         std::fprintf(stderr, "skipped: %s\n", ndt_last_error());
         continue;
@@ -511,8 +513,8 @@ int main(int argc, char** argv) {
     print_matrix(title, node.trajectory[i].data());
   }
   std::printf("start-up (device, code object, page-locked slots; ndt_warm_up): %.1f ms, not in the times below\n", warm_ms);
-  std::printf("time: total %.2f ms  (prefilter %.2f, %s %.2f, map update %.2f; %s)\n", since(t_begin), node.t_filter,
-              serial ? "set inputs + align" : "take inputs over + align", node.t_align, node.t_map,
+  std::printf("time: total %.2f ms  (prefilter %.2f, %s %.2f, map update %.2f, waiting for the next file %.2f; %s)\n", since(t_begin), node.t_filter,
+              serial ? "set inputs + align" : "take inputs over + align", node.t_align, node.t_map, node.t_wait,
               !serial ? "file reading, prefilter + input preparation and map update overlapped with the registrations"
                       : host_clouds ? "file reading overlapped; clouds through host buffers" : "file reading overlapped; clouds resident in HBM");
   if (argc > 3 && std::strcmp(argv[3], "-") != 0 && map_points) {

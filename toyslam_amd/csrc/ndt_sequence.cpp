@@ -28,9 +28,29 @@ int extract_file_number(const std::string& stem) {
 PcdSequence::PcdSequence(std::string directory, Alloc alloc, Release release)
     : dir_(std::move(directory)), alloc_(std::move(alloc)), release_(std::move(release)) {}
 
+void PcdSequence::worker() {
+  for (;;) {
+    std::packaged_task<void()> job;
+    {
+      std::unique_lock<std::mutex> lk(jobs_mu_);
+      jobs_cv_.wait(lk, [this] { return stop_ || !jobs_.empty(); });
+      if (jobs_.empty()) return;  // (stop_, and nothing left to read)
+      job = std::move(jobs_.front());
+      jobs_.pop_front();
+    }
+    job();
+  }
+}
+
 PcdSequence::~PcdSequence() {
   for (std::future<void>& f : inflight_)
     if (f.valid()) f.wait();
+  {
+    std::lock_guard<std::mutex> g(jobs_mu_);
+    stop_ = true;
+  }
+  jobs_cv_.notify_all();
+  for (std::thread& t : workers_) t.join();
   for (Slot& s : slots_)
     if (s.buf) release_(s.buf);
 }
@@ -56,6 +76,7 @@ int PcdSequence::poll(size_t loaded_clouds, std::string& err) {
   }
   std::stable_sort(fresh.begin(), fresh.end(), [](const Entry& a, const Entry& b) { return a.number < b.number; });
   for (Entry& e : fresh) queue_.push_back(std::move(e));
+  top_up(cursor_ + kSlots - 1);  // the first files are on their way before anybody asks for them (one slot stays with the scan handed out last)
   return static_cast<int>(fresh.size());
 }
 
@@ -64,7 +85,9 @@ void PcdSequence::start_read(size_t index) {
   Slot* slot = &slots_[index % kSlots];
   const std::string path = queue_[index].path;
   inflight_index_[index % kSlots] = index;
-  inflight_[index % kSlots] = std::async(std::launch::async, [this, slot, path] {
+  if (workers_.empty())
+    for (size_t w = 0; w + 1 < kSlots; w++) workers_.emplace_back([this] { worker(); });
+  std::packaged_task<void()> job([this, slot, path] {
     slot->status = 0;
     slot->err.clear();
     slot->n = 0;
@@ -92,6 +115,21 @@ void PcdSequence::start_read(size_t index) {
       slot->status = 2;
     }
   });
+  inflight_[index % kSlots] = job.get_future();
+  {
+    std::lock_guard<std::mutex> g(jobs_mu_);
+    jobs_.push_back(std::move(job));
+  }
+  jobs_cv_.notify_one();
+}
+
+void PcdSequence::top_up(size_t limit) {
+  if (read_ahead_ < cursor_) read_ahead_ = cursor_;
+  for (; read_ahead_ < queue_.size() && read_ahead_ < limit; read_ahead_++) {
+    std::future<void>& f = inflight_[read_ahead_ % kSlots];
+    if (f.valid()) f.wait();  // (an older read into this slot: long finished, its scan handed out)
+    start_read(read_ahead_);
+  }
 }
 
 int PcdSequence::next(Scan& out, std::string& err) {
@@ -99,14 +137,6 @@ int PcdSequence::next(Scan& out, std::string& err) {
   if (cursor_ >= queue_.size()) return 1;
   // The scan handed out by the previous call is released by this one, so every slot but the one handed out now may hold
   // a read in flight: entries cursor_ .. cursor_ + kSlots - 1 (the first of them is waited for below).
-  if (read_ahead_ < cursor_) read_ahead_ = cursor_;
-  auto top_up = [this](size_t limit) {
-    for (; read_ahead_ < queue_.size() && read_ahead_ < limit; read_ahead_++) {
-      std::future<void>& f = inflight_[read_ahead_ % kSlots];
-      if (f.valid()) f.wait();  // (an older read into this slot: long finished, its scan handed out)
-      start_read(read_ahead_);
-    }
-  };
   top_up(cursor_ + kSlots);
   const size_t mine = cursor_++;
   std::future<void>& fm = inflight_[mine % kSlots];
