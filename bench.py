@@ -78,11 +78,16 @@ def parse_args(argv=None):
                          "align(output, guess) path of ndt_rosbag_mapping_node.cpp:130 (tests/golden/large_golden.json: cfgB_near)")
     ap.add_argument("--lockstep-steps", type=int, default=3, help="N > 1 mapbuild: timed steps of the RCCL lock-step leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1 single: do not run the two rocprofv3 --pmc child passes that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) the short run a --pmc pass wraps: timed steps only, no legs")
     ap.add_argument("--no-bind", action="store_true", help="leave the CPU affinity of the rank alone (default: the cores of the GPU's NUMA node)")
     ap.add_argument("--no-mapbuild-leg", action="store_true", help="N = 1 single: skip the 512-scan map-build leg")
     ap.add_argument("--no-lockstep-leg", action="store_true", help="N > 1 mapbuild: skip the RCCL lock-step leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the selftest)")
     ap.add_argument("--dry-run", action="store_true", help="self-launch only: print the per-rank environment plan and exit")
+    ap.add_argument("--selftest-die-rank", type=int, default=-1,
+                    help="selftest: this rank exits with code 7 AFTER the rendezvous and the first collective (a rank lost in the middle of "
+                         "a run, e.g. after ndt_comm_init_rank): the launcher must stop the others and return non-zero")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks that all use GPU 0 and rendezvous over gloo: exercises the sharded workload, the launcher and the "
                          "JSON line on a one-GPU box (RCCL refuses two ranks on one device, so the lock-step leg reports an error)")
@@ -253,6 +258,46 @@ def committed_profile(name):
         return None, None
 
 
+def pmc_traffic_of_headline_kernel(set_name):
+    """HBM traffic of the headline kernel measured by THIS run: two fresh child processes -- started before this process touches the
+    GPU, the program directly behind `--` -- run a short pass of the same workload under `rocprofv3 --kernel-trace --pmc X`,
+    FETCH_SIZE and WRITE_SIZE in passes of their own (MI355X_MICROARCH.md: KB, 2 x FETCH_SIZE on gfx950).
+    -> (bytes per launch or None, dict of details)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, {"skipped": "rocprofv3 not found"}
+    vals, info = {}, {"passes": {}}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ndt_pmc_")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--set", set_name, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-mapbuild-leg", "--no-bind"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=170)
+        except Exception as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, {"skipped": "pass %s: %r" % (counter, e)}
+        per = []
+        for cf in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(cf)):
+                if "k_eval_server" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    per.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if not per:
+            return None, {"skipped": "pass %s: no k_eval_server rows (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:])}
+        per = per[2:] if len(per) > 4 else per  # (the first launches of a process fetch code and cold tables)
+        vals[counter] = sum(per) / len(per)
+        info["passes"][counter] = {"launches": len(per), "mean_kb": vals[counter]}
+    info["seconds"] = time.perf_counter() - t0
+    info["how"] = ("this run's own counters: two child processes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                   "mean over the warm k_eval_server launches, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes")
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, info
+
+
 def thread_cpu_times():
     """{tid: (comm, user+system seconds)} of this process's threads (/proc/self/task)."""
     out = {}
@@ -328,8 +373,17 @@ def main():
     workload = args.workload
     if workload == "auto":
         workload = "single" if world == 1 else "mapbuild"
-    steps = args.steps if args.steps is not None else {"single": 50, "large": 10, "mapbuild": 3, "batch": 5, "pyramid": 5, "selftest": 3}[workload]
-    warmup = args.warmup if args.warmup is not None else {"single": 5, "large": 2, "mapbuild": 1, "batch": 1, "pyramid": 2, "selftest": 0}[workload]
+    # (single: 200 steps = ~90 ms of timed region; round 3's 20-50 steps were 9-23 ms, thin for a +-3 % claim)
+    steps = args.steps if args.steps is not None else {"single": 200, "large": 10, "mapbuild": 3, "batch": 5, "pyramid": 5, "selftest": 3}[workload]
+    warmup = args.warmup if args.warmup is not None else {"single": 10, "large": 2, "mapbuild": 1, "batch": 1, "pyramid": 2, "selftest": 0}[workload]
+
+    # N = 1 headline: the counter passes run first, in child processes, while this process has not touched the GPU yet
+    pmc = None
+    if world == 1 and workload == "single" and not args.pmc_child and not args.no_pmc:
+        try:
+            pmc = pmc_traffic_of_headline_kernel(args.set)
+        except Exception as e:  # never lose the headline line to an auxiliary leg
+            pmc = (None, {"skipped": repr(e)})
 
     import numpy as np
     import torch
@@ -375,6 +429,8 @@ def main():
     if workload == "selftest":
         lo, hi = nd.shard_range(args.scans, rank, world)
         barrier()
+        if args.selftest_die_rank == rank:
+            os._exit(7)  # (the others are on their way into the next collective)
         t0 = time.perf_counter()
         for _ in range(steps):
             time.sleep(0.001 * (hi - lo) / max(1, args.scans) * world)
@@ -427,12 +483,25 @@ def main():
     t0 = time.perf_counter()
     reg.setInputTarget(tgt)
     t_build_first = time.perf_counter() - t0
-    t_build = median_time(lambda: reg.setInputTarget(tgt))                 # host buffer: H2D over PCIe + grid build
-    tgt_dev = torch.from_numpy(np.c_[tgt, np.ones(len(tgt), np.float32)]).cuda()
-    torch.cuda.synchronize()
-    t_build_dev = median_time(lambda: reg.setInputTargetDevice(tgt_dev.data_ptr(), len(tgt), 16))  # cloud already in HBM, copied
-    # ... and used where it lies (ndt_set_input_target_device_ref: pcl::Registration keeps a shared pointer, it never copies either)
-    t_build_ref = median_time(lambda: reg.setInputTargetDeviceRef(tgt_dev.data_ptr(), len(tgt)))
+    t_build = t_build_dev = t_build_ref = t_build_cloud = t_build_first
+    if not args.pmc_child:
+      t_build = median_time(lambda: reg.setInputTarget(tgt))                 # host buffer: H2D over PCIe + grid build
+      tgt_dev = torch.from_numpy(np.c_[tgt, np.ones(len(tgt), np.float32)]).cuda()
+      torch.cuda.synchronize()
+      t_build_dev = median_time(lambda: reg.setInputTargetDevice(tgt_dev.data_ptr(), len(tgt), 16))  # cloud already in HBM, copied
+      # ... and used where it lies (ndt_set_input_target_device_ref: pcl::Registration keeps a shared pointer, it never copies either)
+      t_build_ref = median_time(lambda: reg.setInputTargetDeviceRef(tgt_dev.data_ptr(), len(tgt)))
+      # ... and from an ndt_cloud (a cloud the library made or uploaded itself keeps its bounding boxes: no box pass, no host round trip)
+      tgt_cloud = reg.uploadCloud(tgt)
+      # (nothing in this call waits for the device -- no box to poll for -- so it is timed as eight builds back to back and one
+      # synchronisation, the way the by-reference builds above pace themselves through their polled boxes)
+      def cloud_builds():
+          for _ in range(8):
+              reg.setInputTargetCloud(tgt_cloud)
+          torch.cuda.synchronize()
+      t_build_cloud = median_time(cloud_builds) / 8
+      reg.setInputTargetDeviceRef(tgt_dev.data_ptr(), len(tgt))  # (the timed region runs against the by-reference grid, as in round 3)
+      tgt_cloud.release()
 
     T_gts = None
     if workload in ("single", "large"):
@@ -482,6 +551,9 @@ def main():
         used = sorted(((thr1[t][1] - thr0.get(t, (None, 0))[1], thr1[t][0], t) for t in thr1), reverse=True)
         sys.stderr.write("[bench threads] %d threads, timed region %.3f s; busiest (cpu-s, comm, tid): %s\n" % (len(thr1), dt_local, used[:12]))
     dt = max_over_ranks(dt_local)
+    if args.pmc_child:  # the profiler around this process has what it came for
+        print(json.dumps({"pmc_child": True, "steps": steps, "ms_per_step": dt / steps * 1e3}), flush=True)
+        return
 
     # every rank: did its registrations end at the known T_gt?  (summed over ranks; outside the timed region)
     recovered = None
@@ -521,8 +593,12 @@ def main():
             "per_rank_registrations_per_s": per_rank_regs,
             "cgroup_nr_throttled_in_timed_region_rank0": (cg1[0] - cg0[0]) if (cg0 and cg1) else None,
             "host_binding": binding, "target_build_ms": t_build * 1e3,
-            "target_build_roofline": None, "target_build_device_resident_ms": t_build_ref * 1e3,
+            # (key definitions as in rounds 1-2: device_resident = ndt_set_input_target_device, the library copies the cloud;
+            #  the by-reference build and the build from an ndt_cloud have keys of their own)
+            "target_build_roofline": None, "target_build_device_resident_ms": t_build_dev * 1e3,
             "target_build_device_resident_copied_ms": t_build_dev * 1e3,
+            "target_build_device_ref_ms": t_build_ref * 1e3,
+            "target_build_resident_cloud_ms": t_build_cloud * 1e3,
             "target_build_first_call_ms": t_build_first * 1e3,
         }
         if recovered is not None:
@@ -535,14 +611,21 @@ def main():
                                             "achieved": k1_bytes / t_build_ref / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": k1_bytes / t_build_ref / 1e9 / HBM_PEAK_GBS,
                                             "occupied_voxels": gi["n_leaves"], "valid_voxels": gi["n_valid"],
-                                            "note": "wall time of ndt_set_input_target_device_ref (cloud already in HBM and used where it lies), all of its kernels; "
-                                                    "target_build_device_resident_copied_ms: the same with the library's own copy of the cloud"}
+                                            "frac_resident_cloud": k1_bytes / t_build_cloud / 1e9 / HBM_PEAK_GBS,
+                                            "note": "wall time of ndt_set_input_target_device_ref (cloud already in HBM and used where it lies), all of its kernels "
+                                                    "(target_build_device_ref_ms); frac_resident_cloud: the same from an ndt_cloud, whose boxes are known "
+                                                    "(target_build_resident_cloud_ms); target_build_device_resident_ms: with the library's own copy of the cloud"}
         except Exception:
             pass
 
     if workload in ("single", "large"):
         if rank == 0:
             single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, dt, t_build, t_source, N_SOURCE, RESOLUTION, value, guess)
+            if pmc is not None and "roofline" in out:
+                out["roofline"]["traffic"] = pmc[0]
+                out["roofline"]["traffic_measured"] = pmc[1]
+                if pmc[0]:
+                    out["roofline"]["traffic_over_algorithmic"] = pmc[0] / out["roofline"]["algorithmic_bytes_per_launch"]
     else:
         batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps, dt, N_SOURCE, dev if n_local else None, offsets, lo, hi,
                    T_gts, torch)
@@ -551,6 +634,65 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# =====================================================================================================
+# N1 / N2 at the mapping nodes' size: a 60 k-point raw scan of a 60 m scene, 0.5 m leaf; clouds resident in HBM
+# =====================================================================================================
+def node_rows(reg, ndt, clouds, np):
+    """pcl::VoxelGrid prefilter (N1) and update_global_map (N2) against their own roof: M x 16 B read + V x 16 B written
+    (SURVEY 8(f)); wall time of the call (a chain of small kernels, the count and the result's boxes come back to the host)."""
+    import torch
+    n_raw, leaf = 60000, 0.5
+    rng = np.random.default_rng(3)
+    world_pts = clouds.target_surfaces(4 * n_raw, seed=77, extent=60.0)[:, :3].astype(np.float32)
+    h = ndt.NormalDistributionsTransform(device=getattr(reg, "_device", 0))
+    h.warmUp(65536)
+    raws = [np.ascontiguousarray(np.c_[world_pts[rng.choice(len(world_pts), n_raw, replace=False)] + [0.3 * k, 0.0, 0.0], np.ones(n_raw)].astype(np.float32)) for k in range(8)]
+    devs = [torch.from_numpy(r).cuda() for r in raws]
+    torch.cuda.synchronize()
+
+    def med(f, n):
+        ts = []
+        for i in range(n):
+            t0 = time.perf_counter()
+            f(i)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+    kept = {}
+
+    def n1(i):
+        c, _ = h.voxelGridFilterCloudDevice(devs[i % 8].data_ptr(), n_raw, 16, leaf)
+        kept["n"] = len(c)
+        kept["c"] = c
+    t_n1 = med(n1, 24)
+    t_n1_host = med(lambda i: h.voxelGridFilterCloud(raws[i % 8], leaf)[0].release(), 16)
+    v1 = kept["n"]
+    # N2: the map after 20 scans, then the update by one more filtered scan
+    h.mapClear()
+    filt = [h.voxelGridFilterCloud(r, leaf)[0] for r in raws]
+    for k in range(20):
+        h.mapUpdateCloud(filt[k % 8], clouds.make_T([0.3 * k, 0.02 * k, 0.0], [0.0, 0.0, 0.01 * k]), 0.5)
+    m_before = h.mapSize()
+    sizes = []
+
+    def n2(i):
+        sizes.append(h.mapSize())
+        h.mapUpdateCloud(filt[i % 8], clouds.make_T([0.3 * (20 + i), 0.02 * i, 0.0], [0.0, 0.0, 0.01 * i]), 0.5)
+    t_n2 = med(n2, 16)
+    m_in = float(np.median(sizes)) + v1
+    v2 = h.mapSize()
+    b1 = n_raw * 16 + v1 * 16
+    b2 = m_in * 16 + v2 * 16
+    return {"workload": "raw scan of %d points over a 60 m scene, %.1f m leaf; map of ~%d points" % (n_raw, leaf, m_before),
+            "n1_voxel_filter": {"us_per_call": t_n1 * 1e6, "points_in": n_raw, "voxels_out": v1, "algorithmic_bytes": b1,
+                                "roofline": {"bound": "hbm", "achieved": b1 / t_n1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b1 / t_n1 / 1e9 / HBM_PEAK_GBS},
+                                "from_host_buffer_us_per_call": t_n1_host * 1e6,
+                                "what": "ndt_cloud_voxel_filter, input in HBM (from_host_buffer: the same from pageable host memory, upload included)"},
+            "n2_map_update": {"us_per_call": t_n2 * 1e6, "points_in": m_in, "voxels_out": v2, "algorithmic_bytes": b2,
+                              "roofline": {"bound": "hbm", "achieved": b2 / t_n2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / t_n2 / 1e9 / HBM_PEAK_GBS},
+                              "what": "ndt_map_update_cloud: transform of the scan into the map's tail + voxel filter of map and scan"},
+            "note": "both are chains of ~10 small launches paced by launch and completion latencies, not by bytes: the fractions say so"}
 
 
 # =====================================================================================================
@@ -661,6 +803,28 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
             out["server_round_us"] = {"error": repr(e)}
     out["registration_algorithmic_GBs"] = (st["n_evals"] + st["n_hessian_recomputes"]) * bytes_per_eval / (dt / steps) / 1e9
 
+    # ---- the adapter's path: pcl::Registration::align fills the caller's output cloud (include/pclomp/ndt_omp.h passes a host
+    # buffer to ndt_align): the same registration plus the transformed scan's trip to host memory ----
+    if workload == "single":
+        try:
+            n_ad = max(5, min(steps, 50))
+            reg.align(guess, n_out=N_SOURCE)
+            ta = time.perf_counter()
+            for _ in range(n_ad):
+                reg.align(guess, n_out=N_SOURCE)
+            t_ad = (time.perf_counter() - ta) / n_ad
+            out["adapter_path"] = {"align_with_cloud_to_host_registrations_per_s": 1.0 / t_ad, "ms_per_registration": t_ad * 1e3, "steps": n_ad,
+                                   "what": "ndt_align with a host out_cloud (what pclomp::NormalDistributionsTransform::computeTransformation "
+                                           "calls): the headline's registration + fused transform of the scan + %d x 16 B to host memory" % N_SOURCE}
+        except Exception as e:
+            out["adapter_path"] = {"error": repr(e)}
+    # ---- the rows around the path at the mapping nodes' size, clouds resident in HBM ----
+    if world == 1 and workload == "single":
+        try:
+            out["node_rows"] = node_rows(reg, ndt, clouds, np)
+        except Exception as e:
+            out["node_rows"] = {"error": repr(e)}
+
     # ---- configs[3] on this one GPU: the denominator of the 8-GPU map-build comparison ----
     if world == 1 and workload == "single" and not args.no_mapbuild_leg:
         try:
@@ -710,6 +874,7 @@ def single_legs(out, args, reg, ndt, clouds, tgt, src, workload, world, steps, d
         best_cpu = 1.0 / med
         if phys > granted:  # for the record: every physical core of the host, most of them throttled
             medp, np_, _, _ = timed_oracle(po, tgt, src, RESOLUTION, phys, False, 6.0)
+            best_cpu = max(best_cpu, 1.0 / medp)  # (the ratio below is always against the fastest CPU variant measured)
             out["cpu_baseline_all_cores_throttled"] = {"value": 1.0 / medp, "unit": "registrations/s", "cores": phys, "threads": phys, "kind": "port",
                                                        "sample": "%d full registrations (median)" % np_, "ms_per_registration": medp * 1e3,
                                                        "note": "%d threads inside a cgroup that grants %s CPUs" % (phys, hi_["cgroup_cpu_quota"])}
@@ -805,7 +970,24 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
                 if flag.item() != 0:
                     raise RuntimeError("%s failed on %d of %d ranks%s" % (step, int(flag.item()), world, "" if err is None else " (this rank: %s)" % err))
 
-            all_ranks_ok("ndt_comm_init_rank", lambda: reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world))
+            # the transport of the one all-reduce per lock-step: RCCL from C++ on the library's stream (ndt_comm_*) -- or, in the
+            # one-GPU rehearsal (RCCL refuses two ranks on one device), the same exchange through ndt_set_allreduce over gloo, so
+            # that the rehearsal's line carries every key the real line does
+            hook_calls = [0]
+            if args.rehearse_one_gpu:
+                transport = "ndt_set_allreduce hook over gloo (one-GPU rehearsal; the real run: RCCL, ndt_comm_*)"
+                inner = nd.make_allreduce()
+
+                def counted(addr, n, on_device):
+                    hook_calls[0] += 1
+                    return inner(addr, n, on_device)
+                all_ranks_ok("ndt_set_allreduce", lambda: reg.setAllreduce(counted, on_device=False))
+            else:
+                transport = "RCCL (ncclAllReduce from C++ on the library's stream, ndt_comm_*)"
+                all_ranks_ok("ndt_comm_init_rank", lambda: reg.commInitRank(bytes(uid.cpu().numpy().tobytes()), rank, world))
+
+            def collectives_so_far():
+                return hook_calls[0] if args.rehearse_one_gpu else reg.commStats()["collectives"]
             kw = dict(device_ptr=dev.data_ptr() if dev is not None else 0, offsets=offsets, stride_bytes=16,
                       first_scan=lo, total_scans=args.scans)
             warm = {}
@@ -835,8 +1017,11 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
             reg.profile(1)
             for k in (0, 4, 5, 6):
                 reg.profile_read(k)
+            c_before = collectives_so_far()
             reg.alignBatchSharded(**kw)
             torch.cuda.synchronize()
+            c_batch = collectives_so_far() - c_before
+            cs = reg.commStats()
             split = {k: reg.profile_read(k) for k in (0, 4, 5, 6)}
             reg.profile(0)
             n_st = max(split[6][0], 1)
@@ -850,7 +1035,10 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
             per_rank = mine.cpu().numpy()
             result = {"value": args.scans / float(t.item()), "unit": "registrations/s", "ms_per_step": float(t.item()) * 1e3,
                       "steps": n_ls, "registrations_ending_at_T_gt": int(okt.item()), "lock_steps": cs["lock_steps"],
-                      "allreduce_doubles_per_lock_step": args.scans * 32, "rccl_world_size": cs["world"],
+                      "collectives": int(c_batch), "collectives_equal_lock_steps_plus_1": bool(c_batch == cs["lock_steps"] + 1),
+                      "transport": transport,
+                      "allreduce_doubles_per_lock_step": args.scans * 32,
+                      "rccl_world_size": (cs["world"] if not args.rehearse_one_gpu else None), "world_size": world,
                       "per_lock_step_us": {"lock_steps_profiled": int(n_st),
                                            "derivative_kernels": [float(x) for x in per_rank[:, 0]],
                                            "reduce_plus_ncclAllReduce": [float(x) for x in per_rank[:, 1]],
@@ -863,7 +1051,10 @@ def batch_legs(out, args, reg, nd, ndt, dist, rank, world, workload, step, steps
                       "what": "every rank steps all %d solvers; rows of the scans a rank does not own are zero; one in-place "
                               "ncclAllReduce(sum) of the [%d][32] f64 buffer per lock-step on the library stream (C++, ndt_comm_*)" % (args.scans, args.scans)}
             result["host_thread_plan"]["pool_threads"], result["host_thread_plan"]["max_batch_groups"] = ndt.host_thread_plan(*ndt.host_thread_budget())
-            reg.commDestroy()
+            if args.rehearse_one_gpu:
+                reg.setAllreduce(None)
+            else:
+                reg.commDestroy()
         except Exception as e:
             result = {"error": repr(e)}
         done.set()

@@ -102,3 +102,17 @@ def test_self_launch_stops_the_other_ranks_when_one_dies(tmp_path):
     # ... and the good case is left alone
     procs = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
     assert bench.supervise(procs, budget_s=60.0) == [0, 0, 0]
+
+
+def test_a_rank_lost_after_the_rendezvous_fails_the_launch_within_its_budget():
+    """A rank that dies in the MIDDLE of a run -- after the rendezvous and a first collective, the state a rank is in after
+    ndt_comm_init_rank -- leaves the others inside the next collective: the self-launcher must notice the exit code, stop the
+    survivors and return non-zero, well within its budget; no JSON line claims a result."""
+    import time
+    t0 = time.monotonic()
+    r = _run([sys.executable, BENCH, "--gpus", "3", "--steps", "2", "--warmup", "0", "--workload", "selftest", "--selftest-die-rank", "1"],
+             env={"NDT_BENCH_LAUNCH_BUDGET_S": "120"}, timeout=200)
+    assert r.returncode != 0
+    assert time.monotonic() - t0 < 90
+    assert "stopping the remaining ranks" in r.stderr or "rank exit codes" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{") and "scans_covered" in ln]

@@ -551,6 +551,8 @@ ndt_status build_grid(ndt_context* h) {
     S.cntmat = cntmat.p;
     S.bucket_base = g->bucket_base.p;
     S.bpts = g->bpts.p;
+    static const bool index_form_env = [] { const char* v = getenv("NDT_K1_INDEX"); return v && atoi(v) != 0; }();
+    S.index_form = index_form_env;
     S.order = order.p;
     static const bool want_stamps = [] { const char* v = getenv("NDT_K1_STAMPS"); return v && atoi(v) != 0; }();
     DevBuf<unsigned long long> stamps;
@@ -568,6 +570,8 @@ ndt_status build_grid(ndt_context* h) {
     static const int compact_mode = [] { const char* v = getenv("NDT_K1_COMPACT"); return !v ? 1 : std::strcmp(v, "eager") == 0 ? 2 : std::strcmp(v, "off") == 0 ? 0 : 1; }();
     static const bool small_on = [] { const char* v = getenv("NDT_K1_SMALL"); return !v || atoi(v) != 0; }();
     const bool small_form = small_on && ndt::grid_build_small_applies(n, plan);
+    if (small_form) S.index_form = false;
+    g->index_form = S.index_form;
     if (small_form)
       HIP_TRY(ndt::launch_grid_build_small(h->target->pts.p, n, h->target_dense, geo, plan, h->min_pts, h->eig_ratio, S, g->sorted_idx.p,
                                            g->recs.p, g->centroids.p, g->lut.p, g->counts.p, st));
@@ -707,7 +711,7 @@ ndt_status grid_counts(ndt_context* h, DeviceGrid* g) {
     DevBuf<unsigned> scratch;
     HIP_TRY(scratch.reserve(4 * K + 4));
     HIP_TRY(ndt::launch_grid_leaves(g->geom, g->plan, g->min_pts, g->bpts.p, g->bucket_base.p, scratch.p, g->leaf_cell.p, g->leaf_start.p,
-                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream));
+                                    g->leaf_count.p, g->leaf_rec.p, g->counts.p, g->lut.p, h->stream, g->index_form ? g->target->pts.p : nullptr));
     HIP_TRY(hipStreamSynchronize(h->stream));
     g->leaves_pending = false;
     g->bpts.release();

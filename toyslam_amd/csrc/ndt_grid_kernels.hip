@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(kK1Threads) void k1_colscan(unsigned* __restrict__ 
 __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                          int ppb, const unsigned* __restrict__ cntmat, const unsigned* __restrict__ total,
                                                          unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
-                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st) {
+                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st, int index_form) {
   extern __shared__ unsigned k1_lds[];
   const K1Deal deal(map & 255, map >> 8);
   __shared__ unsigned s_scan[kK1Waves];
@@ -1103,7 +1103,9 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
     for (int u = 0; u < 8; u++) {
       if (key[u] >= 0) {
         const int i = r0 + wave * (8 * kWave) + u * kWave + lane;
-        bpts[cursor[key[u]] + row[key[u]] + rk[u]] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
+        const unsigned pos = cursor[key[u]] + row[key[u]] + rk[u];
+        if (index_form) reinterpret_cast<int*>(bpts)[pos] = i;  // (uniform)
+        else bpts[pos] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(i));
       }
     }
     __syncthreads();
@@ -1120,9 +1122,22 @@ __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restric
 // Where a bucket's points come from: its slice of the bucketed cloud in global memory (k1_scatter wrote it), or the lists a
 // block of k1_small collected them in (LDS).  src(j) = point j of the bucket, j < nb, w = point index.
 struct K1GlobalSrc {
-  const float4* __restrict__ p;  // bpts + the bucket's base
-  __device__ __forceinline__ float4 operator()(unsigned j) const { return p[j]; }
+  const float4* __restrict__ p;  // bpts + the bucket's base -- or, index form, the cloud itself
+  const int* __restrict__ idx;   // index form (NDT_K1_INDEX=1): the bucket's slice of point indices; else null
+  __device__ __forceinline__ float4 operator()(unsigned j) const {
+    if (idx) {  // (uniform)
+      const int i = idx[j];
+      float4 q = p[i];
+      q.w = __int_as_float(i);
+      return q;
+    }
+    return p[j];
+  }
 };
+// the bucket's source from a kernel's (bpts, cloud) pair: cloud non-null = bpts holds 4-byte point indices
+__device__ __forceinline__ K1GlobalSrc k1_src(const float4* bpts, const float4* cloud, unsigned bb) {
+  return cloud ? K1GlobalSrc{cloud, reinterpret_cast<const int*>(bpts) + bb} : K1GlobalSrc{bpts + bb, nullptr};
+}
 template <class Src>
 __device__ __forceinline__ void k1_cell_histogram(const Src& src, unsigned nb, const GridGeom& g,
                                                   const K1Deal& deal, int C, unsigned* cnt) {
@@ -1138,7 +1153,7 @@ __device__ __forceinline__ void k1_cell_histogram(const Src& src, unsigned nb, c
 __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, unsigned min_pts,
                                                    const unsigned* __restrict__ bucket_base, unsigned* __restrict__ tot,
                                                    unsigned* __restrict__ ticket, unsigned* __restrict__ occ_base,
-                                                   unsigned* __restrict__ cand_base, unsigned* __restrict__ counts) {
+                                                   unsigned* __restrict__ cand_base, unsigned* __restrict__ counts, const float4* __restrict__ cloud) {
   extern __shared__ unsigned k1_lds[];
   const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
@@ -1148,7 +1163,7 @@ __global__ __launch_bounds__(kBlock) void k1_count(const float4* __restrict__ bp
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   U3 t = {0, 0, 0};
   if (be > bb) {  // uniform
-    k1_cell_histogram(K1GlobalSrc{bpts + bb}, be - bb, g, deal, C, k1_lds);
+    k1_cell_histogram(k1_src(bpts, cloud, bb), be - bb, g, deal, C, k1_lds);
     for (int c = threadIdx.x; c < C; c += kBlock) {
       const unsigned v = k1_lds[c];
       t.occ += (v > 0);
@@ -1610,12 +1625,12 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
                                                       const unsigned* __restrict__ bucket_base, int* __restrict__ sorted_idx,
                                                       VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
                                                       unsigned* __restrict__ bucket_valid, unsigned* __restrict__ scratch, unsigned n_total,
-                                                      unsigned long long* __restrict__ st) {
+                                                      unsigned long long* __restrict__ st, const float4* __restrict__ cloud) {
   extern __shared__ unsigned k1_lds[];
   const K1Deal deal(map & 255, map >> 8);
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  k1_finalize_bucket(K1GlobalSrc{bpts + bb}, k, bb, be - bb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
+  k1_finalize_bucket(k1_src(bpts, cloud, bb), k, bb, be - bb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
                      bucket_valid, scratch, n_total, st);
 }
 
@@ -2039,7 +2054,8 @@ __global__ __launch_bounds__(kBlock) void k_rc_apply(int* __restrict__ lut, long
 __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ bpts, GridGeom g, int map, int C, int min_pts,
                                                     const unsigned* __restrict__ bucket_base, const unsigned* __restrict__ occ_base,
                                                     int* __restrict__ leaf_cell, unsigned* __restrict__ leaf_start,
-                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec, const int* __restrict__ lut) {
+                                                    int* __restrict__ leaf_count, int* __restrict__ leaf_rec, const int* __restrict__ lut,
+                                                    const float4* __restrict__ cloud) {
   extern __shared__ unsigned k1_lds[];
   const K1Deal deal(map & 255, map >> 8);
   __shared__ U3 s_u3[kBlock / kWave];
@@ -2047,7 +2063,7 @@ __global__ __launch_bounds__(kBlock) void k1_leaves(const float4* __restrict__ b
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
   if (be == bb) return;
   unsigned* cnt = k1_lds;
-  k1_cell_histogram(K1GlobalSrc{bpts + bb}, be - bb, g, deal, C, cnt);
+  k1_cell_histogram(k1_src(bpts, cloud, bb), be - bb, g, deal, C, cnt);
   const int per = C / kBlock > 0 ? C / kBlock : 1;
   const int lo = threadIdx.x * per;
   U3 t = {0, 0, 0};
@@ -2245,7 +2261,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                      P.pts_per_block, S.cntmat, lut, g.lut_cells);
   hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
-                     total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr);
+                     total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr, S.index_form ? 1 : 0);
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
   // The kernel's registers allow three blocks per CU, so a pass gets what a third of the CU's LDS holds (the host does not
@@ -2271,7 +2287,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   (void)once_f;
   hipLaunchKernelGGL(k1_finalize, dim3(K), dim3(kBlock), fin_lds(lds_cap), stream,
                      S.bpts, g, P.shift, K, C, min_pts, eig_ratio, lds_cap, wmax, S.bucket_base, sorted_idx, recs, centroids, lut,
-                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.stamps);
+                     S.bucket_base + K + 1, S.order, static_cast<unsigned>(n), S.stamps, S.index_form ? pts : nullptr);
   return hipGetLastError();
 }
 
@@ -2346,7 +2362,7 @@ hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec*
 
 hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min_pts, const float4* bpts, const unsigned* bucket_base,
                               unsigned* scratch /* 4 K + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count, int* leaf_rec,
-                              unsigned* counts, const int* lut, hipStream_t stream) {
+                              unsigned* counts, const int* lut, hipStream_t stream, const float4* cloud) {
   const int K = P.n_buckets, C = P.cells_per_bucket;
   unsigned* ticket = scratch;
   unsigned* tot = scratch + 2;
@@ -2355,9 +2371,9 @@ hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& P, int min
   hipError_t e = hipMemsetAsync(ticket, 0, 2 * sizeof(unsigned), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k1_count, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, K, C,
-                     static_cast<unsigned>(min_pts), bucket_base, tot, ticket, occ_base, cand_base, counts);
+                     static_cast<unsigned>(min_pts), bucket_base, tot, ticket, occ_base, cand_base, counts, cloud);
   hipLaunchKernelGGL(k1_leaves, dim3(K), dim3(kBlock), static_cast<size_t>(C) * sizeof(unsigned), stream, bpts, g, P.shift, C, min_pts,
-                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec, lut);
+                     bucket_base, occ_base, leaf_cell, leaf_start, leaf_count, leaf_rec, lut, cloud);
   return hipGetLastError();
 }
 

@@ -251,6 +251,7 @@ struct DeviceGrid {
   bool leaves_pending = false;
   ndt::GridBuildPlan plan{};
   DevBuf<float4> bpts;
+  bool index_form = false;  // (NDT_K1_INDEX=1: bpts holds point indices)
   DevBuf<unsigned> bucket_base;
   ndt::GridView view() const {
     ndt::GridView v;

@@ -152,6 +152,7 @@ struct GridBuildScratch {
   float4* bpts;            // [n] points in bucket order, w = point index   (kept with the grid until the leaf pass)
   unsigned* order;         // [5 n] per-point scratch of voxels too crowded for LDS
   unsigned long long* stamps;  // development aid (NDT_K1_STAMPS): [n_buckets x 8] phase clocks of k1_finalize, or null
+  bool index_form;             // experiment (NDT_K1_INDEX=1): bpts holds 4-byte point indices, k1_finalize gathers from the cloud
 };
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
@@ -165,7 +166,7 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
                                      int* lut, unsigned* counts, hipStream_t stream);
 hipError_t launch_grid_leaves(const GridGeom& g, const GridBuildPlan& plan, int min_pts, const float4* bpts, const unsigned* bucket_base,
                               unsigned* scratch /* 4 n_buckets + 4 words */, int* leaf_cell, unsigned* leaf_start, int* leaf_count,
-                              int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream);
+                              int* leaf_rec, unsigned* counts, const int* lut, hipStream_t stream, const float4* cloud = nullptr);  // cloud: the index form's points
 // records of a bucket-form build -> dense, in ascending cell order (table entries rewritten); tile_sums: record_compaction_tiles words
 size_t record_compaction_tiles(long long lut_cells);
 hipError_t launch_compact_records(int* lut, long long lut_cells, const VoxelRec* recs_in, const VoxelSide* cent_in, VoxelRec* recs_out,

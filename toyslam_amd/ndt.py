@@ -82,6 +82,7 @@ class NormalDistributionsTransform:
 
     def __init__(self, device=0, _handle=None):
         self._L = _lib.lib()
+        self._device = device
         if _handle is None:
             h = C.c_void_p()
             check(self._L.ndt_create(device, C.byref(h)))
@@ -270,6 +271,16 @@ class NormalDistributionsTransform:
         check(self._L.ndt_cloud_voxel_filter(self._h, a.ctypes.data, a.shape[0], a.shape[1] * 4, int(is_dense), float(leaf_size), 0,
                                              C.byref(c), C.byref(ov)))
         return DeviceCloud(self, c), bool(ov.value)
+
+    def voxelGridFilterCloudDevice(self, dev_ptr, n, stride_bytes, leaf_size, is_dense=True):
+        """The same with the input already in HBM."""
+        c, ov = C.c_void_p(None), C.c_int(0)
+        check(self._L.ndt_cloud_voxel_filter(self._h, C.c_void_p(dev_ptr), n, stride_bytes, int(is_dense), float(leaf_size), 1,
+                                             C.byref(c), C.byref(ov)))
+        return DeviceCloud(self, c), bool(ov.value)
+
+    def warmUp(self, expected_scan_points=0):
+        check(self._L.ndt_warm_up(self._h, int(expected_scan_points)))
 
     def uploadCloud(self, cloud):
         a = _cloud(cloud)
