@@ -655,7 +655,12 @@ ndt_status ndt_diag_server_roundtrip(ndt_handle h, const double* p, int n_iter, 
   h->server_want_dbg = false;
   if (s) return s;
   const int kinds[3] = {3, 1, 0};
+  // NDT_DIAG_ONLY_KIND=3|1|0 (development aid, tools/pmc_valu_split.sh): only that kind of round in this launch, so that a
+  // counter pass around the process attributes the launch's instructions to one kind
+  static const int only_kind = [] { const char* e = getenv("NDT_DIAG_ONLY_KIND"); return e ? atoi(e) : -1; }();
+  us[0] = us[1] = us[2] = 0.0;
   for (int v = 0; v < 3; v++) {
+    if (only_kind >= 0 && kinds[v] != only_kind) continue;
     rq.kind = static_cast<ndt::EvalKind>(kinds[v]);
     double total = 0;
     for (int it = 0; it < n_iter + 5; it++) {
