@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_large; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --workload large --steps 2 --warmup 1 --no-cpu-baseline --no-mapbuild-leg > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- python3 $R/bench.py --workload large --steps 2 --warmup 1 --no-cpu-baseline --no-mapbuild-leg > $O/tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --workload large --steps 2 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- python3 $R/bench.py --workload large --steps 2 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/tcc.log 2>&1
 cd $R && python3 - <<'PY'
 import csv, glob, collections
 for name in ("fetch","tcc"):

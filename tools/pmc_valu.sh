@@ -7,14 +7,14 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_valu
 rm -rf $O
 mkdir -p $O
-B="--steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg"
+B="--steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $O/a --output-format csv -- python3 $R/bench.py $B > $O/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/b --output-format csv -- python3 $R/bench.py $B > $O/b.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $O/c --output-format csv -- python3 $R/bench.py $B > $O/c.log 2>&1
 cd $R && python3 - "$tag" <<'PY'
 import csv, glob, collections, json, sys
 tag = sys.argv[1]
-out = {"command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg (three separate --pmc passes)", "kernels": {}}
+out = {"command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc (three separate --pmc passes)", "kernels": {}}
 for name in ("a", "b", "c"):
     for f in glob.glob("gpurun_out/pmc_valu/%s/*/*counter_collection.csv" % name):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -7,15 +7,15 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 rm -rf $O
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-mapbuild-leg > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg > $O/write.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg > $O/tcc.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mapbuild-leg --no-pmc > $O/tcc.log 2>&1
 cd $R && python3 - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
 O = "gpurun_out/%s" % tag
-out = {"command": "python bench.py --steps K --warmup W --no-cpu-baseline --no-mapbuild-leg (stats: K=20; each --pmc pass on its own: K=5)", "kernels": {}, "pmc": {}}
+out = {"command": "python bench.py --steps K --warmup W --no-cpu-baseline --no-mapbuild-leg --no-pmc (stats: K=20; each --pmc pass on its own: K=5)", "kernels": {}, "pmc": {}}
 f = glob.glob(O + "/stats/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 open(O + "/kernel_stats.csv", "w").write(open(f).read())

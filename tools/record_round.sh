@@ -18,4 +18,9 @@ python3 bench.py --workload batch --batch 256 > gpurun_out/${tag}_bench_batch256
 python3 bench.py --workload mapbuild > gpurun_out/${tag}_bench_mapbuild_n1.json 2>/dev/null
 python3 bench.py --workload pyramid > gpurun_out/${tag}_bench_pyramid.json 2>/dev/null
 python3 tools/time_pair.py 2>/dev/null | tail -1 > gpurun_out/${tag}_pair_sequence.json
+python3 tools/node_loop_profile.py 40 60000 node gpurun_out/${tag}_node_loop.json > gpurun_out/${tag}_node_loop.log 2>&1
+python3 tools/node_loop_profile.py 40 60000 rosbag gpurun_out/${tag}_node_loop_rosbag.json > gpurun_out/${tag}_node_loop_rosbag.log 2>&1
+bash tools/pmc_valu_split.sh $tag > gpurun_out/${tag}_pmc_valu_split.log 2>&1
+python3 tools/time_k1_forms.py > gpurun_out/${tag}_k1_forms.jsonl 2>/dev/null
+python3 tools/time_prefilter.py 2>/dev/null | tail -1 > gpurun_out/${tag}_prefilter.json
 ls -la gpurun_out/${tag}_*.json
