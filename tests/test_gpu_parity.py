@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rot_err, trans_err
+from conftest import ROOT, rot_err, trans_err
 
 pytestmark = pytest.mark.gpu
 
@@ -935,6 +935,25 @@ def test_map_accumulation_matches_reference_loop(mods, pair):
     far = np.array([[0, 0, 0], [1e6, 1e6, 1e6]], np.float32)
     n_map, ov = g.mapUpdate(far, None, 0.01)
     assert ov and n_map == 2 and np.array_equal(g.mapGet(), far)
+
+
+# ------------------------------------------------------------------ K1 for small clouds: every regime of the one-launch form
+@pytest.mark.parametrize("env", [{}, {"NDT_K1_SMALL_LIST": "8"}, {"NDT_K1_LDS_CAP": "512"}, {"NDT_K1_SMALL_FINISH": "0"},
+                                 {"NDT_K1_SMALL": "0"}, {"NDT_K1_SMALL": "0", "NDT_K1_INDEX": "1"}],
+                         ids=["default", "lists_overflow_second_scan", "small_passes", "general_finish_only", "chain", "chain_index_form"])
+def test_small_cloud_grid_regimes_against_the_oracle(env):
+    """tools/fuzz_grid.py (random shapes up to 60 k points: uniform, clusters of thousands of points per voxel, sheets, lines, km
+    offsets, NaN, strides, resolutions, grid parameters -- voxel indices / counts / means / covariances bit for bit against the
+    oracle, dense == sparse records, N1 and N2 bit-exact) with the one-launch build of small clouds forced through each of its
+    paths: wave lists that overflow (the second scan writes straight to the bucketed cloud), LDS passes of 512 points (multi-pass
+    and crowded-cell paths of the finish), every bucket through the chain's finish instead of k1_finish_small -- and the chain
+    itself, in its point and its 4-byte-index scatter forms, as the cross-check."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_grid.py"), "77", "14"], env=dict(os.environ, FUZZ_GRID_INDEX="1", **env),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "grid fuzz done, mismatches: 0" in r.stdout, r.stdout[-1500:]
 
 
 # ------------------------------------------------------------------ clouds that stay in HBM (ndt_cloud)

@@ -792,48 +792,34 @@ ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float*
 }
 
 // ---- N1: voxel-grid centroid down-sample -----------------------------------
-// [PCL] VoxelGrid::applyFilter on a dense float4 device cloud: d_out (capacity n) receives one centroid
-// per occupied voxel in ascending voxel-index order; *overflow = the leaf is too small for the
-// bounding box and, as PCL does, the input was copied through.  Synchronises h->stream.
-// rows of the result's bounding boxes: queued behind the centroids, read by the host behind the synchronisation that brings
-// the count -- no second round trip (n_dev: the count where the filter left it)
+// [PCL] VoxelGrid::applyFilter on a dense float4 device cloud: d_out (capacity n) receives one centroid per occupied voxel
+// in ascending voxel-index order.  Two halves: voxel_filter_enqueue queues the whole chain on a stream and returns -- the
+// count and the per-block rows of the result's bounding boxes travel to page-locked memory behind the last kernel --
+// voxel_filter_finish reads them once that stream has been waited for.  voxel_filter_device is the two with a
+// synchronisation in between (N1); the map update (N2) leaves the wait to whoever next needs the map.
 static constexpr int kOutBoxBlocks = 64;
-static ndt_status queue_out_boxes(ndt_handle h, const float4* d_out, size_t n_max, const unsigned* n_dev) {
-  if (!h->bbox_rows) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->bbox_rows), 1024 * 12 * sizeof(float), hipHostMallocDefault));
-  const int nb = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (n_max + 255) / 256));
-  HIP_TRY(ndt::launch_repack_bbox(d_out, n_max, sizeof(float4), nullptr, h->bbox_rows, nb, h->stream, 0, n_dev));
-  return NDT_OK;
-}
-static void read_out_boxes(ndt_handle h, size_t n_max, DeviceCloud* c) {
-  const int nb = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (n_max + 255) / 256));
-  for (int v = 0; v < 2; v++)
-    for (int k = 0; k < 3; k++) {
-      c->bb_min[v][k] = FLT_MAX;
-      c->bb_max[v][k] = -FLT_MAX;
-    }
-  const float* mm = h->bbox_rows;
-  for (int b = 0; b < nb; b++)
-    for (int v = 0; v < 2; v++)
-      for (int k = 0; k < 3; k++) {
-        c->bb_min[v][k] = std::min(c->bb_min[v][k], mm[b * 12 + v * 6 + k]);
-        c->bb_max[v][k] = std::max(c->bb_max[v][k], mm[b * 12 + v * 6 + 3 + k]);
-      }
-}
+struct PoolStreamGuard {  // temporaries allocated (and given back) inside the scope belong to `s`'s pool
+  hipStream_t keep;
+  explicit PoolStreamGuard(hipStream_t s) : keep(tls_pool_stream) { tls_pool_stream = s; }
+  ~PoolStreamGuard() { tls_pool_stream = keep; }
+};
 
-ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
-                                      size_t* n_out, bool* overflow, const BBox* known_bbox, DeviceCloud* out_boxes) {
-  *n_out = 0;
-  *overflow = false;
+ndt_status voxel_filter_enqueue(ndt_handle h, hipStream_t st, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
+                                const BBox& bb, FilterPending& P) {
+  P.n_max = n;
+  P.fixed_n = 0;
+  P.from_device = false;
+  P.overflow = false;
   if (n == 0) return NDT_OK;
-  hipStream_t st = h->stream;
+  const PoolStreamGuard guard(st);
   const int ni = static_cast<int>(n);
-  // bbox -> geometry, exactly as VoxelGrid::applyFilter
-  BBox bb;
-  if (known_bbox) bb = *known_bbox;
-  else { ndt_status sb = bbox_compute(h, d_in, ni, is_dense, bb); if (sb) return sb; }
   const float* min_p = bb.mn;
   const float* max_p = bb.mx;
-  if (!(min_p[0] <= max_p[0])) return NDT_OK;  // no finite point: empty output
+  if (!(min_p[0] <= max_p[0])) {  // no finite point: empty output
+    for (int i = 0; i < kOutBoxBlocks * 12; i++) P.rows[i] = (i % 6) < 3 ? FLT_MAX : -FLT_MAX;
+    return NDT_OK;
+  }
+  const int nb_rows = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (n + 255) / 256));
   ndt::GridGeom geo{};
   long long d[3];
   for (int k = 0; k < 3; k++) {
@@ -843,11 +829,9 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   }
   if (d[0] * d[1] * d[2] > static_cast<long long>(std::numeric_limits<int32_t>::max())) {
     HIP_TRY(hipMemcpyAsync(d_out, d_in, n * sizeof(float4), hipMemcpyDeviceToDevice, st));  // output = *input_
-    if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, nullptr); if (sq) return sq; }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (out_boxes) read_out_boxes(h, n, out_boxes);
-    *n_out = n;
-    *overflow = true;
+    HIP_TRY(ndt::launch_repack_bbox(d_out, n, sizeof(float4), nullptr, P.rows, nb_rows, st, 0, nullptr));
+    P.fixed_n = n;
+    P.overflow = true;
     return NDT_OK;
   }
   for (int k = 0; k < 3; k++) {
@@ -861,6 +845,7 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
   DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
+  P.from_device = true;
   if (h->voxel_index == 2 || (h->voxel_index == 0 && geo.n_cells > 16ll * static_cast<long long>(n) + (1ll << 22))) {
     // a fine leaf over a wide box (apps/align.cpp: 0.1 m over a whole scan): per-point work only (ndt_sparse.hip)
     const size_t max_l = std::min<size_t>(n, static_cast<size_t>(geo.n_cells));
@@ -882,13 +867,9 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
     HIP_TRY(ndt::launch_sparse_index(d_in, ni, is_dense, geo, 1, temp.p, tb, w.p, w.p + n, vals.p, w.p + 2 * n, w.p + 3 * n, leaf_cell.p, leaf_start.p,
                                      leaf_count.p, leaf_rec.p, sorted_idx.p, totals.p, st));
     HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(max_l), sorted_idx.p, d_out, st, totals.p, big2.p));
-    unsigned tot2[3];
-    HIP_TRY(hipMemcpyAsync(tot2, totals.p, sizeof(tot2), hipMemcpyDeviceToHost, st));
-    if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, totals.p + 1); if (sq) return sq; }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (out_boxes) read_out_boxes(h, n, out_boxes);
-    *n_out = tot2[1];
-    return NDT_OK;
+    HIP_TRY(hipMemcpyAsync(P.tot, totals.p, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ndt::launch_repack_bbox(d_out, n, sizeof(float4), nullptr, P.rows, nb_rows, st, 0, totals.p + 1));
+    return NDT_OK;  // (the temporaries go back to the stream's pool: reused only behind these launches)
   }
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
@@ -912,12 +893,57 @@ ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int i
   DevBuf<float4> big_pts;  // scratch of the crowded-voxel path (k_presort_large)
   HIP_TRY(big_pts.reserve(n));
   HIP_TRY(ndt::launch_voxel_centroids(d_in, leaf_start.p, leaf_count.p, static_cast<int>(n_leaves), sorted_idx.p, d_out, st, totals.p, big_pts.p));
-  unsigned tot[3];
-  HIP_TRY(hipMemcpyAsync(tot, totals.p, sizeof(tot), hipMemcpyDeviceToHost, st));
-  if (out_boxes) { ndt_status sq = queue_out_boxes(h, d_out, n, totals.p + 1); if (sq) return sq; }
-  HIP_TRY(hipStreamSynchronize(st));  // the temporaries above return to the pool at scope exit
-  if (out_boxes) read_out_boxes(h, n, out_boxes);
-  *n_out = tot[1];
+  HIP_TRY(hipMemcpyAsync(P.tot, totals.p, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ndt::launch_repack_bbox(d_out, n, sizeof(float4), nullptr, P.rows, nb_rows, st, 0, totals.p + 1));
+  return NDT_OK;
+}
+
+// after the stream of voxel_filter_enqueue has been waited for: the count, and the boxes of the result
+void voxel_filter_finish(const FilterPending& P, size_t* n_out, DeviceCloud* boxes) {
+  *n_out = P.from_device ? P.tot[1] : P.fixed_n;
+  if (!boxes) return;
+  for (int v = 0; v < 2; v++)
+    for (int k = 0; k < 3; k++) {
+      boxes->bb_min[v][k] = FLT_MAX;
+      boxes->bb_max[v][k] = -FLT_MAX;
+    }
+  if (*n_out == 0) return;
+  const int nb = static_cast<int>(std::min<size_t>(kOutBoxBlocks, (P.n_max + 255) / 256));
+  for (int b = 0; b < nb; b++)
+    for (int v = 0; v < 2; v++)
+      for (int k = 0; k < 3; k++) {
+        boxes->bb_min[v][k] = std::min(boxes->bb_min[v][k], P.rows[b * 12 + v * 6 + k]);
+        boxes->bb_max[v][k] = std::max(boxes->bb_max[v][k], P.rows[b * 12 + v * 6 + 3 + k]);
+      }
+}
+
+ndt_status filter_slots(ndt_handle h, int which, FilterPending& P) {
+  if (!h->filter_slots) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->filter_slots), 2 * (kOutBoxBlocks * 12 + 4) * sizeof(float), hipHostMallocDefault));
+  }
+  float* base = h->filter_slots + which * (kOutBoxBlocks * 12 + 4);
+  P.rows = base;
+  P.tot = reinterpret_cast<unsigned*>(base + kOutBoxBlocks * 12);
+  return NDT_OK;
+}
+
+// the synchronous form (N1): *overflow = the leaf is too small for the bounding box and, as PCL does, the input was copied
+// through.  Synchronises h->stream.
+ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
+                                      size_t* n_out, bool* overflow, const BBox* known_bbox, DeviceCloud* out_boxes) {
+  *n_out = 0;
+  *overflow = false;
+  if (n == 0) return NDT_OK;
+  BBox bb;
+  if (known_bbox) bb = *known_bbox;
+  else { ndt_status sb = bbox_compute(h, d_in, static_cast<int>(n), is_dense, bb); if (sb) return sb; }
+  FilterPending P;
+  ndt_status s = filter_slots(h, 0, P);
+  if (!s) s = voxel_filter_enqueue(h, h->stream, d_in, n, is_dense, leaf, d_out, bb, P);
+  if (s) return s;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  voxel_filter_finish(P, n_out, out_boxes);
+  *overflow = P.overflow;
   return NDT_OK;
 }
 
@@ -1094,6 +1120,27 @@ ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t 
 // update_global_map of the mapping nodes (ndt_omp_mapping_node.cpp:195-211,
 // ndt_rosbag_mapping_node.cpp:146-161): transformPointCloud(scan, pose); global_map += it;
 // global_map = VoxelGrid(leaf).filter(global_map).  The map stays in HBM.
+// the map's stream (created on first use) and the completion of a queued update
+static ndt_status map_stream_of(ndt_handle h) {
+  if (!h->map_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
+  }
+  return NDT_OK;
+}
+// waits for a queued map update: the map's size and boxes are current afterwards
+static ndt_status map_complete(ndt_handle h) {
+  if (!h->map_pending) return NDT_OK;
+  h->map_pending = false;
+  HIP_TRY(hipStreamSynchronize(h->map_stream));
+  h->map_scan.reset();
+  size_t n_new = 0;
+  voxel_filter_finish(h->map_filter, &n_new, &h->map_boxes);
+  h->map_boxes_known = true;
+  h->map_n = n_new;
+  return NDT_OK;
+}
+
 static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size_t stride, int is_dense, bool on_device,
                                   const float* pose, float leaf, int* overflowed, const std::shared_ptr<DeviceCloud>* resident = nullptr) {
   if (!h || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
@@ -1103,15 +1150,25 @@ static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size
   if (resident) c = *resident;  // an ndt_cloud: read where it lies
   else s = upload_cloud(h, scan, n, stride, on_device, c);
   if (s) return s;
+  s = map_stream_of(h);
+  if (!s) s = map_complete(h);  // the map as the previous update left it: its size and its boxes
+  if (s) return s;
   const size_t total = h->map_n + n;
   if (total > static_cast<size_t>(std::numeric_limits<int>::max())) return fail(NDT_ERR_INVALID, "map too large");
   if (total == 0) return NDT_OK;
+  hipStream_t ms = h->map_stream;
+  // the scan was made on the handle's stream (an upload, a filter): the map's stream starts behind it; a resident cloud is
+  // read by the map's stream from now on (its memory is not recycled before that stream has been waited for)
+  HIP_TRY(hipEventRecord(h->map_ready, h->stream));
+  HIP_TRY(hipStreamWaitEvent(ms, h->map_ready, 0));
+  if (resident && c->made_on && c->made_on != ms && std::find(c->used_on.begin(), c->used_on.end(), ms) == c->used_on.end()) c->used_on.push_back(ms);
+  const PoolStreamGuard guard(ms);  // the map's buffers come from (and go back to) the map stream's pool
   // concatenation [map | transformed scan] (operator+= keeps the map's points first): the scan is transformed straight into
   // the room behind the map -- the map is not copied
   if (h->map_pts.cap < total) {
     DevBuf<float4> bigger;
     HIP_TRY(bigger.reserve(total + total / 2 + n));
-    if (h->map_n) HIP_TRY(hipMemcpyAsync(bigger.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+    if (h->map_n) HIP_TRY(hipMemcpyAsync(bigger.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, ms));
     h->map_pts.swap(bigger);  // (the old block goes back to the pool behind the copy, stream order)
   }
   float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -1119,18 +1176,16 @@ static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size
   if (n) {
     float T12[12];
     colmajor_to_T12(P, T12);
-    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, h->map_pts.p + h->map_n, h->stream, is_dense));
+    HIP_TRY(ndt::launch_transform(c->pts.p, static_cast<int>(n), T12, h->map_pts.p + h->map_n, ms, is_dense));
   }
   HIP_TRY(h->map_alt.reserve(total + total / 2 + n));
-  size_t n_new = 0;
-  bool overflow = false;
   // the accumulated map is dense only if every scan was; PCL carries is_dense through operator+=
   h->map_dense = (h->map_n == 0 ? 1 : h->map_dense) && is_dense;
   // A box for the filter without a pass over the points: the map's own box (the last pass left it) joined with the box of the
   // scan's box under the pose, padded for the f32 rounding of the transform.  ANY box that holds the points gives the same
   // voxels in the same order -- a voxel is floor(x / leaf) whatever min_b is, and the linear index orders the voxels by
   // (z, y, x) for every box -- so the result is PCL's bit for bit; only the index-overflow test wants the exact box, and it
-  // is computed when the padded one overflows.
+  // is computed (one pass, one wait) when the padded one comes near overflowing.
   BBox guess{};
   bool have_guess = (h->map_n == 0 || h->map_boxes_known);
   const int v = h->map_dense ? 0 : 1;
@@ -1172,17 +1227,33 @@ static ndt_status map_update_impl(ndt_handle h, const void* scan, size_t n, size
       have_guess = false;
     }
   }
-  s = voxel_filter_device(h, h->map_pts.p, total, h->map_dense, leaf, h->map_alt.p, &n_new, &overflow, have_guess ? &guess : nullptr, &h->map_boxes);
+  if (!have_guess) {  // the exact box: one pass over [map | scan] and a wait for it
+    BBox exact;
+    HIP_TRY(hipStreamSynchronize(ms));
+    const hipStream_t keep_stream = h->stream;
+    h->stream = ms;  // (bbox_compute launches on and waits for the handle's stream)
+    s = bbox_compute(h, h->map_pts.p, static_cast<int>(total), h->map_dense, exact);
+    h->stream = keep_stream;
+    if (s) return s;
+    guess = exact;
+  }
+  s = filter_slots(h, 1, h->map_filter);
+  if (!s) s = voxel_filter_enqueue(h, ms, h->map_pts.p, total, h->map_dense, leaf, h->map_alt.p, guess, h->map_filter);
   if (s) return s;
-  h->map_boxes_known = true;
   h->map_pts.swap(h->map_alt);
-  h->map_n = n_new;
-  if (overflowed) *overflowed = overflow ? 1 : 0;
+  h->map_scan = c;
+  h->map_pending = true;  // (its size and boxes: map_complete, when somebody needs them)
+  if (overflowed) *overflowed = h->map_filter.overflow ? 1 : 0;
   return NDT_OK;
 }
 
 ndt_status ndt_map_clear(ndt_handle h) {
   if (!h) return fail(NDT_ERR_INVALID, "null handle");
+  if (h->map_pending) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = map_complete(h);
+    if (s) return s;
+  }
   h->map_n = 0;
   h->map_dense = 1;
   h->map_boxes_known = false;
@@ -1344,6 +1415,8 @@ ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points) {
   const double keep_prob = h->trans_probability, keep_nn = h->mean_neighbors;
   float keep_T[16];
   std::memcpy(keep_T, h->final_T, sizeof(keep_T));
+  s = map_complete(h);
+  if (s) return s;
   DevBuf<float4> keep_map, keep_alt;
   keep_map.swap(h->map_pts);
   keep_alt.swap(h->map_alt);
@@ -1369,7 +1442,13 @@ ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points) {
     ndt_cloud_release(d);
     c = d = nullptr;
   }
+  if (!s) s = map_complete(h);
   if (!s) HIP_TRY(hipStreamSynchronize(h->stream));
+  {  // the scratch map's buffers go back to the map stream's pool, the handle's own map comes back
+    const PoolStreamGuard guard(h->map_stream ? h->map_stream : h->stream);
+    h->map_pts.release();
+    h->map_alt.release();
+  }
   h->source = keep_source;
   h->target = keep_target;
   h->grid = keep_grid;
@@ -1400,18 +1479,36 @@ ndt_status ndt_map_update_device(ndt_handle h, const void* d_scan, size_t n, siz
 }
 ndt_status ndt_map_size(ndt_handle h, size_t* n) {
   if (!h || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->map_pending) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = map_complete(h);
+    if (s) return s;
+  }
   *n = h->map_n;
   return NDT_OK;
 }
 ndt_status ndt_map_get(ndt_handle h, void* out, size_t out_stride) {
-  if (!h || (h->map_n && !out)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (!h) return fail(NDT_ERR_INVALID, "bad arguments");
   if (out_stride < 16) return fail(NDT_ERR_INVALID, "out_stride_bytes must be >= 16");
+  if (h->map_pending || h->map_stream) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = map_complete(h);
+    if (s) return s;
+    HIP_TRY(hipStreamSynchronize(h->map_stream));  // (the download runs on the handle's stream)
+  }
+  if (h->map_n && !out) return fail(NDT_ERR_INVALID, "bad arguments");
   if (h->map_n == 0) return NDT_OK;
   return download_records(h, h->map_pts.p, h->map_n, out, out_stride);
 }
 ndt_status ndt_map_get_device(ndt_handle h, const void** d_pts, size_t* n) {
   if (!h || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
   if (h->device_ready) HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->map_stream) {
+    ndt_status s = ensure_device(h);
+    if (!s) s = map_complete(h);
+    if (s) return s;
+    HIP_TRY(hipStreamSynchronize(h->map_stream));
+  }
   *d_pts = h->map_pts.p;
   *n = h->map_n;
   return NDT_OK;

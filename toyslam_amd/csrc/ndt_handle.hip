@@ -6,6 +6,7 @@
 void ndt_context::release_buffers() {
   target.reset();
   source.reset();
+  map_scan.reset();
   grid.reset();
   partials.release();
   ticket.release();

@@ -220,6 +220,15 @@ struct DeviceCloud {
 };
 
 
+// An enqueued voxel filter: where its count and the rows of its result's boxes arrive (page-locked), what the host decided
+struct FilterPending {
+  float* rows = nullptr;     // [64][12] per-block rows of the result's bounding boxes
+  unsigned* tot = nullptr;   // [3]: points binned, voxels, -
+  size_t n_max = 0, fixed_n = 0;
+  bool from_device = false;  // the count is tot[1] (else fixed_n: empty input, or the input copied through)
+  bool overflow = false;
+};
+
 // Immutable once built (shared between cloned handles).
 struct DeviceGrid {
   ndt::GridGeom geom{};
@@ -337,6 +346,14 @@ struct ndt_context {
   int map_dense = 1;
   DeviceCloud map_boxes;    // bounding boxes of the map as the last filter pass left it (bb_min / bb_max only)
   bool map_boxes_known = false;
+  // The map lives on a stream of its own: an update is queued there and NOT waited for -- the next registration does not
+  // read the map -- until somebody needs the map or its size (map_complete): the next update, ndt_map_size / _get.
+  hipStream_t map_stream = nullptr;
+  hipEvent_t map_ready = nullptr;       // recorded on the handle's stream: the scan the update reads is complete
+  bool map_pending = false;
+  FilterPending map_filter;
+  std::shared_ptr<DeviceCloud> map_scan;  // the scan a queued update reads (kept until the update has been waited for)
+  float* filter_slots = nullptr;        // page-locked: [2] x (64 x 12 rows + count words): slot 0 N1, slot 1 the map
   int voxel_index = 0;              // ndt_set_voxel_index: 0 automatic, 1 dense table, 2 sparse (sorted build + hash look-up)
   bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
@@ -386,6 +403,18 @@ struct ndt_context {
       (void)hipStreamSynchronize(stream);
       tls_pool_stream = stream;
     }
+    if (map_stream) {  // the map's buffers belong to the map stream's pool
+      (void)hipStreamSynchronize(map_stream);
+      const hipStream_t keep = tls_pool_stream;
+      tls_pool_stream = map_stream;
+      map_pts.release();
+      map_alt.release();
+      tls_pool_stream = keep;
+      DevPool::instance().forget_stream(map_stream);
+      (void)hipStreamDestroy(map_stream);
+      if (map_ready) (void)hipEventDestroy(map_ready);
+    }
+    if (filter_slots) (void)hipHostFree(filter_slots);
     release_buffers();
     if (host_result) (void)hipHostFree(host_result);
     if (host_pub) (void)hipHostFree(host_pub);
@@ -445,6 +474,10 @@ float index_slack(const DeviceGrid* g);
 ndt_status download_records(ndt_context* h, const float4* d_src, size_t n, void* out, size_t out_stride);
 void fill_point_index(const DeviceGrid* g, ndt::PointIndex& ix);
 ndt_status fitness_impl(ndt_context* h, const float4* d_src, int n, const float* T_colmajor, double max_range, double* fitness);
+ndt_status filter_slots(ndt_handle h, int which, FilterPending& P);
+ndt_status voxel_filter_enqueue(ndt_handle h, hipStream_t st, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
+                                const BBox& bb, FilterPending& P);
+void voxel_filter_finish(const FilterPending& P, size_t* n_out, DeviceCloud* boxes);
 // out_boxes: the result's bounding boxes as DeviceCloud keeps them ([2][3] min, [2][3] max), or null
 ndt_status voxel_filter_device(ndt_handle h, const float4* d_in, size_t n, int is_dense, float leaf, float4* d_out,
                                size_t* n_out, bool* overflow, const BBox* known_bbox = nullptr, DeviceCloud* out_boxes = nullptr);
