@@ -251,6 +251,13 @@ typedef struct ndt_pcd_sequence* ndt_pcd_sequence_handle;
 ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out);
 ndt_status ndt_pcd_sequence_poll(ndt_pcd_sequence_handle s, size_t loaded_clouds, size_t* n_new_files);
 ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, size_t* n, int* is_dense, int* file_number);
+/* Scans staged into HBM by the reader: after ndt_pcd_sequence_stage(s, device) every scan is copied to the device as soon as
+ * its file has been read (by the reading thread, on a copy stream of the sequence's own), and ndt_pcd_sequence_next_device
+ * hands out the device records (16 bytes each, valid until the next call) together with the host ones -- the upload of scan
+ * k + 1 runs while the caller registers scan k.  *d_pts == NULL with NDT_OK: nothing queued, as _next. */
+ndt_status ndt_pcd_sequence_stage(ndt_pcd_sequence_handle s, int device);
+ndt_status ndt_pcd_sequence_next_device(ndt_pcd_sequence_handle s, const void** d_pts, const void** host_pts, size_t* n, int* is_dense,
+                                        int* file_number);
 void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s);
 /* extract_file_number (:231-239) */
 int ndt_host_extract_file_number(const char* file_stem);

@@ -136,6 +136,8 @@ SIGNATURES = {
     "ndt_pcd_sequence_poll": (C.c_int, [vp, C.c_size_t, szp]),
     "ndt_pcd_sequence_next": (C.c_int, [vp, C.POINTER(vp), szp, ip, ip]),
     "ndt_pcd_sequence_close": (None, [vp]),
+    "ndt_pcd_sequence_stage": (C.c_int, [vp, C.c_int]),
+    "ndt_pcd_sequence_next_device": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), szp, ip, ip]),
     "ndt_host_extract_file_number": (C.c_int, [C.c_char_p]),
     "ndt_host_repack_fields": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, ip]),
     # GICP row (include/gicp_mi355.h)

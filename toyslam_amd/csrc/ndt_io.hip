@@ -2,6 +2,8 @@
 // (split out of the former single C-ABI unit; shared state in ndt_internal.hpp)
 #include "ndt_internal.hpp"
 
+#include <mutex>
+
 extern "C" {
 
 // ---- N3: PCD files -------------------------------------------------------------
@@ -40,6 +42,27 @@ ndt_status ndt_pcd_write_xyz(const char* path, const void* pts, size_t n, size_t
 // ---- N3: numbered scans of a directory, read ahead into page-locked buffers -------------------
 struct ndt_pcd_sequence {
   std::unique_ptr<ndt::PcdSequence> seq;
+  // ndt_pcd_sequence_stage: every scan also goes up to HBM as soon as it has been read -- by the reading thread, on a copy
+  // stream of the sequence's own -- so that the caller finds it there (ndt_pcd_sequence_next_device)
+  int stage_device = -1;
+  hipStream_t copy_stream = nullptr;
+  void* dev[ndt::PcdSequence::kSlots] = {};
+  size_t dev_cap[ndt::PcdSequence::kSlots] = {};
+  hipEvent_t ready[ndt::PcdSequence::kSlots] = {};
+  bool staged[ndt::PcdSequence::kSlots] = {};
+  std::mutex mu;  // the copy stream's queue and the slots' device buffers (several reading threads)
+  ~ndt_pcd_sequence() {
+    seq.reset();  // (joins the reading threads: nothing stages any more)
+    if (stage_device >= 0) {
+      (void)hipSetDevice(stage_device);
+      if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+      for (size_t k = 0; k < ndt::PcdSequence::kSlots; k++) {
+        if (dev[k]) (void)hipFree(dev[k]);
+        if (ready[k]) (void)hipEventDestroy(ready[k]);
+      }
+      if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+  }
 };
 
 ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out) {
@@ -84,6 +107,61 @@ ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, si
   if (is_dense) *is_dense = scan.is_dense;
   if (file_number) *file_number = scan.file_number;
   if (rc == 2) return fail(NDT_ERR_INVALID, err);
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_stage(ndt_pcd_sequence_handle s, int device) {
+  if (!s || device < 0) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (device >= usable_devices()) return fail(NDT_ERR_NO_DEVICE, "no such device");
+  if (s->stage_device >= 0) return s->stage_device == device ? NDT_OK : fail(NDT_ERR_INVALID, "the sequence already stages to another device");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  for (size_t k = 0; k < ndt::PcdSequence::kSlots; k++) HIP_TRY(hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming));
+  s->stage_device = device;
+  ndt_pcd_sequence* self = s;
+  s->seq->set_on_read([self](int slot, const void* buf, size_t n) {
+    std::lock_guard<std::mutex> g(self->mu);
+    self->staged[slot] = false;
+    if (hipSetDevice(self->stage_device) != hipSuccess) return;
+    const size_t bytes = std::max<size_t>(n, 1) * 16;
+    if (self->dev_cap[slot] < bytes) {
+      if (self->dev[slot]) (void)hipFree(self->dev[slot]);  // (synchronises: rare, the buffers grow to the scans' size once)
+      self->dev[slot] = nullptr;
+      self->dev_cap[slot] = 0;
+      if (hipMalloc(&self->dev[slot], bytes + bytes / 4) != hipSuccess) return;
+      self->dev_cap[slot] = bytes + bytes / 4;
+    }
+    if (n && hipMemcpyAsync(self->dev[slot], buf, n * 16, hipMemcpyHostToDevice, self->copy_stream) != hipSuccess) return;
+    if (hipEventRecord(self->ready[slot], self->copy_stream) != hipSuccess) return;
+    self->staged[slot] = true;
+  });
+  return NDT_OK;
+}
+
+ndt_status ndt_pcd_sequence_next_device(ndt_pcd_sequence_handle s, const void** d_pts, const void** host_pts, size_t* n, int* is_dense,
+                                        int* file_number) {
+  if (!s || !d_pts || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (s->stage_device < 0) return fail(NDT_ERR_INVALID, "ndt_pcd_sequence_stage has not been called");
+  ndt::PcdSequence::Scan scan;
+  std::string err;
+  const int rc = s->seq->next(scan, err);
+  *d_pts = nullptr;
+  if (host_pts) *host_pts = scan.pts;
+  *n = scan.n;
+  if (is_dense) *is_dense = scan.is_dense;
+  if (file_number) *file_number = scan.file_number;
+  if (rc == 2) return fail(NDT_ERR_INVALID, err);
+  if (rc == 0 && scan.pts) {
+    bool ok;
+    {
+      std::lock_guard<std::mutex> g(s->mu);
+      ok = s->staged[scan.slot];
+    }
+    if (!ok) return fail(NDT_ERR_HIP, "staging the scan to the device failed");
+    HIP_TRY(hipSetDevice(s->stage_device));
+    HIP_TRY(hipEventSynchronize(s->ready[scan.slot]));
+    *d_pts = s->dev[scan.slot];
+  }
   return NDT_OK;
 }
 

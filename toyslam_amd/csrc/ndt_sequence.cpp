@@ -110,6 +110,7 @@ void PcdSequence::start_read(size_t index) {
         }
       }
       if (pcd_read_xyz(path.c_str(), slot->buf, slot->cap_points, 16, &slot->n, &slot->dense, slot->err)) slot->status = 2;
+      else if (on_read_) on_read_(static_cast<int>(slot - slots_), slot->buf, slot->n);
     } catch (const std::exception& e) {
       slot->err = std::string("PCD: ") + e.what();
       slot->status = 2;
@@ -149,6 +150,7 @@ int PcdSequence::next(Scan& out, std::string& err) {
     return 2;
   }
   out.pts = slot.buf;
+  out.slot = static_cast<int>(mine % kSlots);
   out.n = slot.n;
   out.is_dense = slot.dense;
   return 0;

@@ -39,7 +39,12 @@ class PcdSequence {
     int is_dense = 1;
     int file_number = -1;
     const char* path = nullptr;
+    int slot = -1;  // which of the kSlots buffers holds it (on_read's first argument)
   };
+  // called by the reading thread when a file has been read and parsed into slot `slot` (n records at buf): the C-ABI's
+  // staging of scans into HBM hangs on it
+  using OnRead = std::function<void(int slot, const void* buf, size_t n)>;
+  void set_on_read(OnRead f) { on_read_ = std::move(f); }
   // The next queued file (0), nothing queued (1), or a file that cannot be read (2: err set, the file is skipped,
   // as load_and_filter_cloud's nullptr is).  While the caller works on a scan the following kSlots - 1 files are being
   // read and parsed by a pool of kSlots - 1 background threads that live as long as the sequence (a 2M-point scan takes
@@ -69,6 +74,7 @@ class PcdSequence {
   std::mutex jobs_mu_;
   std::condition_variable jobs_cv_;
   bool stop_ = false;
+  OnRead on_read_;
   std::string dir_;
   Alloc alloc_;
   Release release_;
