@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <map>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -208,6 +209,44 @@ class VoxelGridCovariance : public pcl::VoxelGrid<PointT> {
   /** .h:391-405 */
   inline const Map& getLeaves() { return leaves_; }
   inline PointCloudPtr getCentroids() { return voxel_centroids_; }
+
+  /** .h:407-412, _impl.hpp:449-490: a cloud for display -- 1000 points per voxel with enough points, drawn from the voxel's
+   *  normal distribution (mean + L r, L the Cholesky factor of the covariance, r three draws from N(0, |leaf_size|)).  Host
+   *  code over the dumped leaves.  The reference draws with boost::mt19937 + boost::normal_distribution; here std::mt19937
+   *  (the same engine and seed) + std::normal_distribution: the same distribution, not the same sample. */
+  void getDisplayCloud(pcl::PointCloud<pcl::PointXYZ>& cell_cloud) {
+    cell_cloud.points.clear();
+    const int pnt_per_cell = 1000;
+    std::mt19937 rng;
+    const double lx = leaf_size_[0], ly = leaf_size_[1], lz = leaf_size_[2];
+    std::normal_distribution<double> nd(0.0, std::sqrt(lx * lx + ly * ly + lz * lz));
+    for (typename Map::const_iterator it = leaves_.begin(); it != leaves_.end(); ++it) {
+      const Leaf& leaf = it->second;
+      if (leaf.nr_points < min_points_per_voxel_) continue;
+      // lower Cholesky factor of the (inflated) covariance, as Eigen::LLT computes it column by column
+      double L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int j = 0; j < 3; j++) {
+        double d = leaf.cov_(j, j);
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        L[j][j] = std::sqrt(d);
+        for (int i = j + 1; i < 3; i++) {
+          double v = leaf.cov_(i, j);
+          for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+          L[i][j] = v / L[j][j];
+        }
+      }
+      for (int i = 0; i < pnt_per_cell; i++) {
+        const double r0 = nd(rng), r1 = nd(rng), r2 = nd(rng);
+        pcl::PointXYZ p;
+        p.x = static_cast<float>(leaf.mean_(0) + L[0][0] * r0);
+        p.y = static_cast<float>(leaf.mean_(1) + L[1][0] * r0 + L[1][1] * r1);
+        p.z = static_cast<float>(leaf.mean_(2) + L[2][0] * r0 + L[2][1] * r1 + L[2][2] * r2);
+        cell_cloud.points.push_back(p);
+      }
+    }
+    cell_cloud.width = static_cast<unsigned>(cell_cloud.points.size());
+    cell_cloud.height = 1;
+  }
 
   /** .h:423-465: the k voxels (of those in the centroid cloud) whose centroids are nearest to the point, ascending. */
   int nearestKSearch(const PointT& point, int k, std::vector<LeafConstPtr>& k_leaves, std::vector<float>& k_sqr_distances) {

@@ -267,7 +267,7 @@ def test_voxel_grid_covariance_adapter_compiles_and_declares_reference_surface()
                  "filter(PointCloud& output, bool searchable = false)", "filter(bool searchable = false)", "getLeaf(int index)",
                  "getLeaf(PointT& p)", "getLeaf(Eigen::Vector3f& p)", "getNeighborhoodAtPoint7", "getNeighborhoodAtPoint1",
                  "getLeaves()", "getCentroids()", "nearestKSearch", "radiusSearch", "getEvecs", "getEvals", "getInverseCov",
-                 "getPointCount", "voxel_centroids_leaf_indices_"]:
+                 "getPointCount", "voxel_centroids_leaf_indices_", "getDisplayCloud(pcl::PointCloud<pcl::PointXYZ>& cell_cloud)"]:
         assert name in hdr, name
 
 
@@ -351,4 +351,8 @@ def test_voxel_grid_covariance_adapter_matches_oracle(built_lib, pair, tmp_path)
         assert int(f[7]) == len(inside) and float(f[8]) == pytest.approx(float(inside[0]) if len(inside) else -1.0, rel=1e-6)
         srt = np.sort(d2)
         assert int(f[9]) == 3 and float(f[10]) == pytest.approx(float(srt[0]), rel=1e-6) and float(f[11]) == pytest.approx(float(srt[2]), rel=1e-6)
-    assert lines[-1] == "copy %d %d" % (len(G["idx"]), len(neighbours(t[0].astype(np.float32), off7)))
+    assert lines[-2] == "copy %d %d" % (len(G["idx"]), len(neighbours(t[0].astype(np.float32), off7)))
+    # getDisplayCloud: 1000 draws per voxel with enough points; the first voxel's sample mean within 5 standard errors of its mean
+    disp = lines[-1].split()
+    n_valid = int((G["n"] >= 6).sum())
+    assert disp[0] == "display" and int(disp[1]) == 1000 * n_valid and int(disp[2]) == n_valid and float(disp[3]) < 5.0

@@ -3,6 +3,7 @@
 //   vgc_harness cloud.f32 n_points leaf n_queries
 #include <pclomp/voxel_grid_covariance_omp.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -88,5 +89,24 @@ int main(int argc, char** argv) {
   Grid copy(g);
   std::vector<Grid::LeafConstPtr> nb;
   std::printf("copy %zu %d\n", copy.getLeaves().size(), copy.getNeighborhoodAtPoint7(cloud->points[0], nb));
+  // getDisplayCloud (.h:407-412): 1000 draws from every valid voxel's normal distribution -- their sample mean and the spread
+  // along the axes must be the voxel's own (checked for the first valid voxel: mean within 5 standard errors)
+  {
+    pcl::PointCloud<pcl::PointXYZ> disp;
+    g.getDisplayCloud(disp);
+    size_t n_valid = 0;
+    const Grid::Leaf* first = nullptr;
+    for (const auto& kv : g.getLeaves())
+      if (kv.second.nr_points >= g.getMinPointPerVoxel()) {
+        if (!first) first = &kv.second;
+        n_valid++;
+      }
+    double m[3] = {0, 0, 0};
+    for (int i = 0; i < 1000 && first; i++) { m[0] += disp.points[i].x; m[1] += disp.points[i].y; m[2] += disp.points[i].z; }
+    const double scale = std::sqrt(3.0) * leaf;  // |leaf_size| multiplies the unit draws (the reference's quirk)
+    double worst = 0;
+    for (int k = 0; k < 3 && first; k++) worst = std::max(worst, std::fabs(m[k] / 1000 - first->mean_(k)) / (scale * std::sqrt(first->cov_(k, k) / 1000.0)));
+    std::printf("display %zu %zu %.3f\n", disp.points.size(), n_valid, worst);
+  }
   return 0;
 }
