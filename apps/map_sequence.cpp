@@ -151,77 +151,117 @@ struct Node {
 // adds -- no download, no second or third upload / repack / bounding-box pass of the same points
 // ---------------------------------------------------------------------------------------------------------------------
 static int run_resident(Node& node, ndt_pcd_sequence_handle seq, float voxel_leaf_size, ndt_handle h, size_t first_poll) {
+  // The prefilter of scan k + 1 is BEGUN (queued on the handle's filter stream: ndt_cloud_voxel_filter_begin -- its input's
+  // boxes were computed by the reader, so nothing has to come back from the device first) before scan k is registered,
+  // and ended when scan k + 1's turn comes: the node's steps in the node's order, the GPU working on two of them at once.
+  struct Raw {
+    ndt_cloud view = nullptr;  // the staged scan (the sequence's memory)
+    size_t n = 0;
+    int dense = 1, number = -1;
+  };
+  const char* ov_env = std::getenv("MAP_SEQUENCE_OVERLAP");
+  const bool overlap = ov_env && std::atoi(ov_env) != 0;  // (measured: no gain, the loop is bound by the GPU's time; off)
   ndt_cloud previous = nullptr;  // clouds_[current_index_ - 1]
+  Raw begun;                     // the scan whose prefilter is under way
+  bool have_begun = false, queue_dry = first_poll == 0;
   int rc = 0;
-  for (bool first = true; !rc; first = false) {
-    size_t fresh = first ? first_poll : 0;  // (the first poll ran before the device's start-up: its files are being read already)
-    if (!first) CHECK(ndt_pcd_sequence_poll(seq, node.loaded, &fresh));
-    if (fresh == 0) break;
-    for (; !rc;) {
-      const void* raw = nullptr;
-      size_t n = 0;
-      int dense = 1, number = -1;
-      const void* d_raw = nullptr;  // the same scan in HBM: the reader put it there as soon as the file was parsed
+  // the next queued scan -> its prefilter begun; false: nothing queued right now
+  auto begin_next = [&]() -> int {
+    for (;;) {
+      Raw r;
+      const void* host = nullptr;
       const auto t_next = clock_type::now();
-      const ndt_status s = ndt_pcd_sequence_next_device(seq, &d_raw, &raw, &n, &dense, &number);
+      const ndt_status s = ndt_pcd_sequence_next_cloud(seq, &r.view, &host, &r.n, &r.dense, &r.number);
       node.t_wait += since(t_next);
-      if (s != NDT_OK) {
+      if (s != NDT_OK) {  // loadPCDFile == -1 -> nullptr -> skipped (:140, :128)
         std::fprintf(stderr, "skipped: %s\n", ndt_last_error());
         continue;
       }
-      if (!raw) break;
-      auto t0 = clock_type::now();
-      ndt_cloud current = nullptr;  // load_and_filter_cloud, :142-148
-      int overflowed = 0;
-      size_t m = 0;
-      if (ndt_cloud_voxel_filter(h, d_raw, n, sizeof(Pt), dense, voxel_leaf_size, 1, &current, &overflowed) != NDT_OK || ndt_cloud_size(current, &m) != NDT_OK) {
-        std::fprintf(stderr, "voxel filter failed: %s\n", ndt_last_error());
-        rc = 1;
-        break;
-      }
-      node.t_filter += since(t0);
-      if (std::getenv("MAP_SEQUENCE_TRACE")) std::fprintf(stderr, "[scan %d] prefilter %.1f us\n", number, since(t0) * 1e3);
-      if (m == 0) {  // :128 -- empty clouds are not kept
-        ndt_cloud_release(current);
-        continue;
-      }
-      node.loaded++;
-      std::printf("Loaded cloud_%d.pcd (%zu points)\n", number, m);
-      auto step = [&]() -> int {
-        if (node.loaded == 1) {  // load_initial_clouds, :64-68
-          t0 = clock_type::now();
-          int ov = 0;
-          CHECK(ndt_map_update_cloud(h, current, 1, kIdentity, 0.5f, &ov));
-          node.t_map += since(t0);
-          return 0;
-        }
-        t0 = clock_type::now();  // process_available_clouds, :70-100
-        CHECK(ndt_set_input_target_cloud(h, previous, 1));
-        CHECK(ndt_set_input_source_cloud(h, current));
-        float T[16];
-        int converged = 0, iterations = 0;
-        double probability = 0;
-        CHECK(ndt_align(h, node.rosbag ? node.pres_transform.data() : nullptr, T, &converged, &iterations, &probability, nullptr, 0));
-        node.t_align += since(t0);
-        std::vector<float> map_pose;
-        std::string err;
-        const bool into_map = node.after_align(h, T, converged, iterations, map_pose, err);
-        if (!err.empty()) {
-          std::fprintf(stderr, "%s\n", err.c_str());
-          return 1;
-        }
-        if (into_map) {
-          t0 = clock_type::now();
-          int ov = 0;
-          CHECK(ndt_map_update_cloud(h, current, 1, map_pose.data(), 0.5f, &ov));  // :204 / map_voxel :88: leaf fixed at 0.5
-          node.t_map += since(t0);
-        }
+      if (!r.view) {
+        queue_dry = true;
         return 0;
-      };
-      rc = step();
-      ndt_cloud_release(previous);
-      previous = current;
+      }
+      const auto t0 = clock_type::now();
+      CHECK(ndt_cloud_voxel_filter_begin(h, r.view, r.dense, voxel_leaf_size));
+      node.t_filter += since(t0);
+      begun = r;
+      have_begun = true;
+      return 0;
     }
+  };
+  for (; !rc;) {
+    if (!have_begun) {
+      if (queue_dry) {  // process_new_clouds looks at the directory (the first look ran before the device's start-up)
+        size_t fresh = 0;
+        CHECK(ndt_pcd_sequence_poll(seq, node.loaded, &fresh));
+        if (fresh == 0) break;
+        queue_dry = false;
+      }
+      if (begin_next()) return 1;
+      if (!have_begun) continue;  // (every queued file was unreadable: look again)
+    }
+    // ---- load_and_filter_cloud of this scan ends (:142-148) ...
+    auto t0 = clock_type::now();
+    ndt_cloud current = nullptr;
+    int overflowed = 0;
+    size_t m = 0;
+    if (ndt_cloud_voxel_filter_end(h, &current, &overflowed) != NDT_OK || ndt_cloud_size(current, &m) != NDT_OK) {
+      std::fprintf(stderr, "voxel filter failed: %s\n", ndt_last_error());
+      return 1;
+    }
+    node.t_filter += since(t0);
+    const int number = begun.number;
+    ndt_cloud_release(begun.view);
+    have_begun = false;
+    // ... and the next scan's begins.  Not across a look at the directory: process_new_clouds counts the clouds KEPT so far,
+    // and whether the scan in flight is kept (not empty) is known only when its filter has ended.
+    if (overlap && !queue_dry && begin_next()) return 1;
+    if (m == 0) {  // :128 -- empty clouds are not kept
+      ndt_cloud_release(current);
+      continue;
+    }
+    node.loaded++;
+    std::printf("Loaded cloud_%d.pcd (%zu points)\n", number, m);
+    auto step = [&]() -> int {
+      if (node.loaded == 1) {  // load_initial_clouds, :64-68
+        t0 = clock_type::now();
+        int ov = 0;
+        CHECK(ndt_map_update_cloud(h, current, 1, kIdentity, 0.5f, &ov));
+        node.t_map += since(t0);
+        return 0;
+      }
+      t0 = clock_type::now();  // process_available_clouds, :70-100
+      CHECK(ndt_set_input_target_cloud(h, previous, 1));
+      CHECK(ndt_set_input_source_cloud(h, current));
+      float T[16];
+      int converged = 0, iterations = 0;
+      double probability = 0;
+      CHECK(ndt_align(h, node.rosbag ? node.pres_transform.data() : nullptr, T, &converged, &iterations, &probability, nullptr, 0));
+      node.t_align += since(t0);
+      std::vector<float> map_pose;
+      std::string err;
+      const bool into_map = node.after_align(h, T, converged, iterations, map_pose, err);
+      if (!err.empty()) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        return 1;
+      }
+      if (into_map) {
+        t0 = clock_type::now();
+        int ov = 0;
+        CHECK(ndt_map_update_cloud(h, current, 1, map_pose.data(), 0.5f, &ov));  // :204 / map_voxel :88: leaf fixed at 0.5
+        node.t_map += since(t0);
+      }
+      return 0;
+    };
+    rc = step();
+    ndt_cloud_release(previous);
+    previous = current;
+  }
+  if (have_begun) {  // (left over after an error)
+    ndt_cloud c = nullptr;
+    (void)ndt_cloud_voxel_filter_end(h, &c, nullptr);
+    ndt_cloud_release(c);
+    ndt_cloud_release(begun.view);
   }
   ndt_cloud_release(previous);
   return rc;

@@ -216,6 +216,11 @@ ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points);
 typedef struct ndt_cloud_s* ndt_cloud;
 ndt_status ndt_cloud_voxel_filter(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, int is_dense, float leaf_size,
                                   int on_device, ndt_cloud* out, int* overflowed);
+/* N1 of an ndt_cloud in two halves: _begin queues the whole filter on a stream of the handle's own and returns at once,
+ * _end waits for it and hands out the result -- in between the caller registers the PREVIOUS scan (the prefilter of scan
+ * k + 1 runs beside the registration of scan k).  One prefilter at a time per handle.  Same result as ndt_cloud_voxel_filter. */
+ndt_status ndt_cloud_voxel_filter_begin(ndt_handle h, ndt_cloud in, int is_dense, float leaf_size);
+ndt_status ndt_cloud_voxel_filter_end(ndt_handle h, ndt_cloud* out, int* overflowed);
 ndt_status ndt_cloud_upload(ndt_handle h, const void* pts, size_t n, size_t stride_bytes, ndt_cloud* out);
 ndt_status ndt_cloud_size(ndt_cloud c, size_t* n);
 ndt_status ndt_cloud_data(ndt_cloud c, const void** d_pts_float4, size_t* n);               /* the records in HBM */
@@ -258,6 +263,12 @@ ndt_status ndt_pcd_sequence_next(ndt_pcd_sequence_handle s, const void** pts, si
 ndt_status ndt_pcd_sequence_stage(ndt_pcd_sequence_handle s, int device);
 ndt_status ndt_pcd_sequence_next_device(ndt_pcd_sequence_handle s, const void** d_pts, const void** host_pts, size_t* n, int* is_dense,
                                         int* file_number);
+/* The same scan as an ndt_cloud: a VIEW of the staged records (the sequence owns the memory: valid until the next call of
+ * a _next* function) that carries the bounding boxes the reading thread computed on the host while the copy ran -- a
+ * prefilter of it needs nothing from the device before its kernels can be queued.  *cloud == NULL with NDT_OK: nothing
+ * queued.  Release the view with ndt_cloud_release. */
+ndt_status ndt_pcd_sequence_next_cloud(ndt_pcd_sequence_handle s, ndt_cloud* cloud, const void** host_pts, size_t* n, int* is_dense,
+                                       int* file_number);
 void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s);
 /* extract_file_number (:231-239) */
 int ndt_host_extract_file_number(const char* file_stem);

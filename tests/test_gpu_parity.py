@@ -1028,6 +1028,24 @@ def test_resident_clouds_equal_host_buffers(mods, pair):
     # empty input -> an empty cloud
     ce, _ = g.voxelGridFilterCloud(np.zeros((0, 3), np.float32), 0.5)
     assert len(ce) == 0
+    # the prefilter in two halves (queued on the filter stream beside a registration on the handle's): the same cloud, and the
+    # registration that ran in between is the same registration
+    craw = g.uploadCloud(raw_s.astype(np.float32))
+    g.voxelGridFilterBegin(craw, 0.5)
+    g.setInputTarget(ft)
+    g.setInputSource(fs)
+    g.align()
+    cb, ovb = g.voxelGridFilterEnd()
+    assert not ovb and np.array_equal(cb.numpy(), fs) and np.array_equal(g.getFinalTransformation(), href.getFinalTransformation())
+    with pytest.raises(ndt.NdtError):
+        g.voxelGridFilterEnd()   # nothing begun
+    g.setInputTargetCloud(cb)    # ... and its boxes came with it: usable as a target at once
+    g.setInputSource(ft)
+    g.align()
+    href.setInputTarget(fs)
+    href.setInputSource(ft)
+    href.align()
+    assert np.array_equal(g.getFinalTransformation(), href.getFinalTransformation())
 
 
 # ------------------------------------------------------------------ configs[4] shape: voxel pyramid

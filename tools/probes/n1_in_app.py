@@ -17,6 +17,6 @@ exe = os.path.join(tmp, "map_sequence")
 libdir = os.path.join(ROOT, "toyslam_amd")
 subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "apps", "map_sequence.cpp"),
                        "-o", exe, "-L" + libdir, "-lndt_mi355", "-Wl,-rpath," + libdir])
-for zc in ("1", "0", "1", "0"):
-    r = subprocess.run([exe, tmp, "0.5", "-", "node"], text=True, capture_output=True, env=dict(os.environ, NDT_ZERO_COPY=zc))
-    print("NDT_ZERO_COPY=" + zc, [ln for ln in r.stdout.splitlines() if ln.startswith("time:")][-1])
+for zc in ("1", "0", "1", "0", "1", "0"):
+    r = subprocess.run([exe, tmp, "0.5", "-", "node"], text=True, capture_output=True, env=dict(os.environ, MAP_SEQUENCE_OVERLAP=zc))
+    print("MAP_SEQUENCE_OVERLAP=" + zc, [ln for ln in r.stdout.splitlines() if ln.startswith("time:")][-1])

@@ -137,6 +137,9 @@ SIGNATURES = {
     "ndt_pcd_sequence_next": (C.c_int, [vp, C.POINTER(vp), szp, ip, ip]),
     "ndt_pcd_sequence_close": (None, [vp]),
     "ndt_pcd_sequence_stage": (C.c_int, [vp, C.c_int]),
+    "ndt_pcd_sequence_next_cloud": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_void_p), szp, ip, ip]),
+    "ndt_cloud_voxel_filter_begin": (C.c_int, [vp, vp, C.c_int, C.c_float]),
+    "ndt_cloud_voxel_filter_end": (C.c_int, [vp, C.POINTER(vp), ip]),
     "ndt_pcd_sequence_next_device": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), szp, ip, ip]),
     "ndt_host_extract_file_number": (C.c_int, [C.c_char_p]),
     "ndt_host_repack_fields": (C.c_int, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, ip]),

@@ -919,7 +919,7 @@ void voxel_filter_finish(const FilterPending& P, size_t* n_out, DeviceCloud* box
 
 ndt_status filter_slots(ndt_handle h, int which, FilterPending& P) {
   if (!h->filter_slots) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->filter_slots), 2 * (kOutBoxBlocks * 12 + 4) * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->filter_slots), 3 * (kOutBoxBlocks * 12 + 4) * sizeof(float), hipHostMallocDefault));
   }
   float* base = h->filter_slots + which * (kOutBoxBlocks * 12 + 4);
   P.rows = base;
@@ -1298,6 +1298,54 @@ ndt_status ndt_cloud_voxel_filter(ndt_handle h, const void* pts, size_t n, size_
   return NDT_OK;
 }
 
+// N1 of an ndt_cloud, in two halves: begin queues the whole chain on the handle's FILTER stream and returns (the input's boxes
+// are known: nothing has to come back from the device before the chain can be queued); end waits for it.  Between the two the
+// caller registers the previous scan on the handle's own stream.
+ndt_status ndt_cloud_voxel_filter_begin(ndt_handle h, ndt_cloud in, int is_dense, float leaf) {
+  if (!h || !in || !(leaf > 0)) return fail(NDT_ERR_INVALID, "bad arguments");
+  if (h->n1_pending) return fail(NDT_ERR_INVALID, "a prefilter has been begun and not ended");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  if (!h->filter_stream) HIP_TRY(hipStreamCreateWithFlags(&h->filter_stream, hipStreamNonBlocking));
+  DeviceCloud* ic = in->c.get();
+  if (ic->made_on && ic->made_on != h->filter_stream) {  // made elsewhere: complete before the filter stream reads it
+    if (ic->device != h->device) return fail(NDT_ERR_INVALID, "the cloud lives on another device");
+    HIP_TRY(hipStreamSynchronize(ic->made_on));
+    if (std::find(ic->used_on.begin(), ic->used_on.end(), h->filter_stream) == ic->used_on.end()) ic->used_on.push_back(h->filter_stream);
+  }
+  auto c = std::make_shared<DeviceCloud>();
+  c->device = h->device;
+  c->made_on = h->filter_stream;
+  {
+    const PoolStreamGuard guard(h->filter_stream);
+    HIP_TRY(c->pts.reserve(std::max<size_t>(ic->n, 1)));
+  }
+  s = filter_slots(h, 2, h->n1_filter);
+  if (!s) s = voxel_filter_enqueue(h, h->filter_stream, ic->pts.p, ic->n, is_dense, leaf, c->pts.p, bbox_of(*ic, is_dense), h->n1_filter);
+  if (s) return s;
+  h->n1_in = in->c;
+  h->n1_out = c;
+  h->n1_pending = true;
+  return NDT_OK;
+}
+ndt_status ndt_cloud_voxel_filter_end(ndt_handle h, ndt_cloud* out, int* overflowed) {
+  if (!h || !out) return fail(NDT_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  if (!h->n1_pending) return fail(NDT_ERR_INVALID, "no prefilter has been begun");
+  ndt_status s = ensure_device(h);
+  if (s) return s;
+  h->n1_pending = false;
+  HIP_TRY(hipStreamSynchronize(h->filter_stream));
+  size_t n_written = 0;
+  voxel_filter_finish(h->n1_filter, &n_written, h->n1_out.get());
+  h->n1_out->n = n_written;
+  if (overflowed) *overflowed = h->n1_filter.overflow ? 1 : 0;
+  *out = new ndt_cloud_s{h->n1_out};
+  h->n1_in.reset();
+  h->n1_out.reset();
+  return NDT_OK;
+}
+
 ndt_status ndt_cloud_upload(ndt_handle h, const void* pts, size_t n, size_t stride, ndt_cloud* out) {
   if (!h || !out) return fail(NDT_ERR_INVALID, "bad arguments");
   *out = nullptr;
@@ -1441,6 +1489,15 @@ ndt_status ndt_warm_up(ndt_handle h, size_t expected_scan_points) {
     ndt_cloud_release(c);
     ndt_cloud_release(d);
     c = d = nullptr;
+    if (!s) {  // the two-halves prefilter: its stream, and that stream's pool
+      ndt_cloud raw = nullptr;
+      s = ndt_cloud_upload(h, pts.data(), n, 16, &raw);
+      if (!s) s = ndt_cloud_voxel_filter_begin(h, raw, 1, 0.5f);
+      if (!s) s = ndt_cloud_voxel_filter_end(h, &c, &ov);
+      ndt_cloud_release(raw);
+      ndt_cloud_release(c);
+      c = nullptr;
+    }
   }
   if (!s) s = map_complete(h);
   if (!s) HIP_TRY(hipStreamSynchronize(h->stream));

@@ -353,7 +353,12 @@ struct ndt_context {
   bool map_pending = false;
   FilterPending map_filter;
   std::shared_ptr<DeviceCloud> map_scan;  // the scan a queued update reads (kept until the update has been waited for)
-  float* filter_slots = nullptr;        // page-locked: [2] x (64 x 12 rows + count words): slot 0 N1, slot 1 the map
+  float* filter_slots = nullptr;        // page-locked: [3] x (64 x 12 rows + count words): slot 0 N1, slot 1 the map, slot 2 a begun N1
+  // ndt_cloud_voxel_filter_begin / _end: one prefilter queued on a stream of its own (beside a registration on the handle's)
+  hipStream_t filter_stream = nullptr;
+  bool n1_pending = false;
+  FilterPending n1_filter;
+  std::shared_ptr<DeviceCloud> n1_in, n1_out;
   int voxel_index = 0;              // ndt_set_voxel_index: 0 automatic, 1 dense table, 2 sparse (sorted build + hash look-up)
   bool index_only = false;  // GICP's point index: cells and their point lists only, no per-voxel statistics
   int persistent = -1;  // -1 = default (NDT_PERSISTENT / on), 0 = launch per evaluation, 1 = server
@@ -413,6 +418,13 @@ struct ndt_context {
       DevPool::instance().forget_stream(map_stream);
       (void)hipStreamDestroy(map_stream);
       if (map_ready) (void)hipEventDestroy(map_ready);
+    }
+    if (filter_stream) {
+      (void)hipStreamSynchronize(filter_stream);
+      n1_in.reset();
+      n1_out.reset();
+      DevPool::instance().forget_stream(filter_stream);
+      (void)hipStreamDestroy(filter_stream);
     }
     if (filter_slots) (void)hipHostFree(filter_slots);
     release_buffers();

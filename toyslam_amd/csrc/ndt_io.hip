@@ -165,6 +165,41 @@ ndt_status ndt_pcd_sequence_next_device(ndt_pcd_sequence_handle s, const void** 
   return NDT_OK;
 }
 
+ndt_status ndt_pcd_sequence_next_cloud(ndt_pcd_sequence_handle s, ndt_cloud* cloud, const void** host_pts, size_t* n, int* is_dense,
+                                       int* file_number) {
+  if (!s || !cloud || !n) return fail(NDT_ERR_INVALID, "bad arguments");
+  *cloud = nullptr;
+  if (s->stage_device < 0) return fail(NDT_ERR_INVALID, "ndt_pcd_sequence_stage has not been called");
+  ndt::PcdSequence::Scan scan;
+  std::string err;
+  const int rc = s->seq->next(scan, err);
+  if (host_pts) *host_pts = scan.pts;
+  *n = scan.n;
+  if (is_dense) *is_dense = scan.is_dense;
+  if (file_number) *file_number = scan.file_number;
+  if (rc == 2) return fail(NDT_ERR_INVALID, err);
+  if (rc == 0 && scan.pts) {
+    bool ok;
+    {
+      std::lock_guard<std::mutex> g(s->mu);
+      ok = s->staged[scan.slot];
+    }
+    if (!ok) return fail(NDT_ERR_HIP, "staging the scan to the device failed");
+    HIP_TRY(hipSetDevice(s->stage_device));
+    HIP_TRY(hipEventSynchronize(s->ready[scan.slot]));
+    // a view of the staged records with the boxes the reading thread computed (the sequence owns the memory: valid until
+    // the next call, like the host records)
+    auto c = std::make_shared<DeviceCloud>();
+    c->pts.borrow(static_cast<float4*>(s->dev[scan.slot]), scan.n);
+    c->n = scan.n;
+    c->device = s->stage_device;
+    std::memcpy(c->bb_min, scan.bb_min, sizeof(c->bb_min));
+    std::memcpy(c->bb_max, scan.bb_max, sizeof(c->bb_max));
+    *cloud = new ndt_cloud_s{c};
+  }
+  return NDT_OK;
+}
+
 void ndt_pcd_sequence_close(ndt_pcd_sequence_handle s) { delete s; }
 
 int ndt_host_extract_file_number(const char* file_stem) { return file_stem ? ndt::extract_file_number(file_stem) : -1; }

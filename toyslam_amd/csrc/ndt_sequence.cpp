@@ -1,8 +1,13 @@
 // ndt_sequence.cpp -- see ndt_sequence.hpp.
 #include "ndt_sequence.hpp"
 
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <cerrno>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
 #include <cstdint>
 #include <cstdlib>
 #include <filesystem>
@@ -11,6 +16,28 @@
 #include "ndt_pcd.hpp"
 
 namespace ndt {
+
+// both bounding boxes of n (x, y, z, .) records: min / max are exact and order-free, so these are the boxes the device's
+// box kernel reduces to (ndt_grid_kernels.hip k_bbox16)
+static void host_boxes16(const float* p, size_t n, float bb_min[2][3], float bb_max[2][3]) {
+  __m128 mn0 = _mm_set1_ps(FLT_MAX), mx0 = _mm_set1_ps(-FLT_MAX), mn1 = mn0, mx1 = mx0;
+  const __m128 abs_mask = _mm_castsi128_ps(_mm_set1_epi32(0x7fffffff)), inf = _mm_set1_ps(INFINITY);
+  for (size_t i = 0; i < n; i++) {
+    const __m128 v = _mm_loadu_ps(p + 4 * i);
+    mn0 = _mm_min_ps(v, mn0);  // (min / max hand back their SECOND operand when the first is NaN)
+    mx0 = _mm_max_ps(v, mx0);
+    if ((_mm_movemask_ps(_mm_cmplt_ps(_mm_and_ps(v, abs_mask), inf)) & 7) == 7) {
+      mn1 = _mm_min_ps(v, mn1);
+      mx1 = _mm_max_ps(v, mx1);
+    }
+  }
+  alignas(16) float a[4], b[4], c[4], d[4];
+  _mm_store_ps(a, mn0); _mm_store_ps(b, mx0); _mm_store_ps(c, mn1); _mm_store_ps(d, mx1);
+  for (int k = 0; k < 3; k++) {
+    bb_min[0][k] = a[k]; bb_max[0][k] = b[k];
+    bb_min[1][k] = c[k]; bb_max[1][k] = d[k];
+  }
+}
 
 int extract_file_number(const std::string& stem) {
   const size_t underscore = stem.find_last_of('_');
@@ -109,8 +136,12 @@ void PcdSequence::start_read(size_t index) {
           return;
         }
       }
-      if (pcd_read_xyz(path.c_str(), slot->buf, slot->cap_points, 16, &slot->n, &slot->dense, slot->err)) slot->status = 2;
-      else if (on_read_) on_read_(static_cast<int>(slot - slots_), slot->buf, slot->n);
+      if (pcd_read_xyz(path.c_str(), slot->buf, slot->cap_points, 16, &slot->n, &slot->dense, slot->err)) {
+        slot->status = 2;
+      } else {
+        if (on_read_) on_read_(static_cast<int>(slot - slots_), slot->buf, slot->n);  // (the copy to the device runs beside the pass below)
+        host_boxes16(static_cast<const float*>(slot->buf), slot->n, slot->bb_min, slot->bb_max);
+      }
     } catch (const std::exception& e) {
       slot->err = std::string("PCD: ") + e.what();
       slot->status = 2;
@@ -151,6 +182,8 @@ int PcdSequence::next(Scan& out, std::string& err) {
   }
   out.pts = slot.buf;
   out.slot = static_cast<int>(mine % kSlots);
+  std::memcpy(out.bb_min, slot.bb_min, sizeof(out.bb_min));
+  std::memcpy(out.bb_max, slot.bb_max, sizeof(out.bb_max));
   out.n = slot.n;
   out.is_dense = slot.dense;
   return 0;

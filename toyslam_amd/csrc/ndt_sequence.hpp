@@ -40,6 +40,9 @@ class PcdSequence {
     int file_number = -1;
     const char* path = nullptr;
     int slot = -1;  // which of the kSlots buffers holds it (on_read's first argument)
+    // bounding boxes of the scan, computed by the reading thread: [0] NaN coordinates dropped (pcl::getMinMax3D of a dense
+    // cloud), [1] over the finite points only; min > max = no such point
+    float bb_min[2][3], bb_max[2][3];
   };
   // called by the reading thread when a file has been read and parsed into slot `slot` (n records at buf): the C-ABI's
   // staging of scans into HBM hangs on it
@@ -65,6 +68,7 @@ class PcdSequence {
     int dense = 1;
     int status = 0;
     std::string err;
+    float bb_min[2][3], bb_max[2][3];
   };
   void start_read(size_t index);
   void top_up(size_t limit);

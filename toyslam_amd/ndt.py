@@ -279,6 +279,15 @@ class NormalDistributionsTransform:
                                              C.byref(c), C.byref(ov)))
         return DeviceCloud(self, c), bool(ov.value)
 
+    def voxelGridFilterBegin(self, dc, leaf_size, is_dense=True):
+        """N1 of an ndt_cloud, first half: queued on the handle's filter stream, not waited for."""
+        check(self._L.ndt_cloud_voxel_filter_begin(self._h, dc._c, int(is_dense), float(leaf_size)))
+
+    def voxelGridFilterEnd(self):
+        c, ov = C.c_void_p(None), C.c_int(0)
+        check(self._L.ndt_cloud_voxel_filter_end(self._h, C.byref(c), C.byref(ov)))
+        return DeviceCloud(self, c), bool(ov.value)
+
     def warmUp(self, expected_scan_points=0):
         check(self._L.ndt_warm_up(self._h, int(expected_scan_points)))
 
