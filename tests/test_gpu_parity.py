@@ -1025,6 +1025,24 @@ def test_resident_clouds_equal_host_buffers(mods, pair):
     href.setInputSource(fs)
     href.align()
     assert np.array_equal(other.getFinalTransformation(), href.getFinalTransformation())
+    # a cloud outlives the handle that made it (and a handle that read it)
+    maker = ndt.NormalDistributionsTransform()
+    cm, _ = maker.voxelGridFilterCloud(raw_t.astype(np.float32), 0.5)
+    reader = ndt.NormalDistributionsTransform()
+    reader.setInputTargetCloud(cm)
+    del reader, maker
+    import gc
+    gc.collect()
+    g.setInputTargetCloud(cm)
+    g.setInputSource(fs)
+    g.align()
+    href.setInputTarget(ft)
+    href.setInputSource(fs)
+    href.align()
+    assert np.array_equal(g.getFinalTransformation(), href.getFinalTransformation())
+    cm._owner = g   # (the wrapper downloads through a live handle)
+    assert np.array_equal(cm.numpy(), ft)
+    cm.release()
     # empty input -> an empty cloud
     ce, _ = g.voxelGridFilterCloud(np.zeros((0, 3), np.float32), 0.5)
     assert len(ce) == 0

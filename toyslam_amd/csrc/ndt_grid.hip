@@ -1124,6 +1124,7 @@ ndt_status ndt_voxel_grid_filter_device(ndt_handle h, const void* d_pts, size_t 
 static ndt_status map_stream_of(ndt_handle h) {
   if (!h->map_stream) {
     HIP_TRY(hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
+    DevPool::instance().adopt_stream(h->map_stream);
     HIP_TRY(hipEventCreateWithFlags(&h->map_ready, hipEventDisableTiming));
   }
   return NDT_OK;
@@ -1306,7 +1307,10 @@ ndt_status ndt_cloud_voxel_filter_begin(ndt_handle h, ndt_cloud in, int is_dense
   if (h->n1_pending) return fail(NDT_ERR_INVALID, "a prefilter has been begun and not ended");
   ndt_status s = ensure_device(h);
   if (s) return s;
-  if (!h->filter_stream) HIP_TRY(hipStreamCreateWithFlags(&h->filter_stream, hipStreamNonBlocking));
+  if (!h->filter_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->filter_stream, hipStreamNonBlocking));
+    DevPool::instance().adopt_stream(h->filter_stream);
+  }
   DeviceCloud* ic = in->c.get();
   if (ic->made_on && ic->made_on != h->filter_stream) {  // made elsewhere: complete before the filter stream reads it
     if (ic->device != h->device) return fail(NDT_ERR_INVALID, "the cloud lives on another device");

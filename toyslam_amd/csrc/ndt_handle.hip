@@ -53,12 +53,14 @@ static ndt_status create_stream(ndt_context* h) {
     for (int c = lo; c < hi; c++) mask[c / 32] |= 1u << (c % 32);
     if (hipExtStreamCreateWithCUMask(&h->stream, static_cast<uint32_t>(mask.size()), mask.data()) == hipSuccess) {
       h->cu_count = hi - lo;
+      DevPool::instance().adopt_stream(h->stream);
       return NDT_OK;
     }
     (void)hipGetLastError();
     h->stream = nullptr;
   }
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  DevPool::instance().adopt_stream(h->stream);
   return NDT_OK;
 }
 

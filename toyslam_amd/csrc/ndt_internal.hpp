@@ -24,6 +24,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <set>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -114,9 +115,21 @@ class DevPool {
     }
     if (over) trim(kPoolTrimBytes / 2);
   }
+  // Streams that have been destroyed (forget_stream) and not created again since (adopt_stream: a new stream may get an old
+  // one's handle value): an ndt_cloud that outlives a handle it was made or read on must neither wait for such a stream nor
+  // give its memory to that stream's pool.
+  void adopt_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> g(m_);
+    retired_.erase(st);
+  }
+  bool retired(hipStream_t st) {
+    std::lock_guard<std::mutex> g(m_);
+    return retired_.count(st) != 0;
+  }
   // blocks cached for a stream that is about to be destroyed: give them back
   void forget_stream(hipStream_t st) {
     std::lock_guard<std::mutex> g(m_);
+    retired_.insert(st);
     for (auto it = free_.begin(); it != free_.end();) {
       if (std::get<1>(it->first) == st) {
         (void)hipFree(it->second);
@@ -140,6 +153,7 @@ class DevPool {
   static constexpr size_t kPoolTrimBytes = size_t(16) << 30;
   std::mutex m_;
   std::multimap<Key, void*> free_;
+  std::set<hipStream_t> retired_;
   size_t cached_ = 0;
 };
 
@@ -209,10 +223,16 @@ struct DeviceCloud {
   ~DeviceCloud() {
     if (!made_on) return;
     (void)hipSetDevice(device);
+    DevPool& pool = DevPool::instance();
     for (hipStream_t s : used_on)
-      if (s != made_on) (void)hipStreamSynchronize(s);
+      if (s != made_on && !pool.retired(s)) (void)hipStreamSynchronize(s);  // (a destroyed stream's work is over: its handle waited)
     const hipStream_t keep = tls_pool_stream;
-    tls_pool_stream = made_on;
+    if (pool.retired(made_on)) {  // the handle that made it is gone: to the default pool, behind a device-wide wait
+      (void)hipDeviceSynchronize();
+      tls_pool_stream = nullptr;
+    } else {
+      tls_pool_stream = made_on;
+    }
     pts.release();
     sorted.release();
     tls_pool_stream = keep;
