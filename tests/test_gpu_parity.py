@@ -939,15 +939,18 @@ def test_map_accumulation_matches_reference_loop(mods, pair):
 
 # ------------------------------------------------------------------ K1 for small clouds: every regime of the one-launch form
 @pytest.mark.parametrize("env", [{}, {"NDT_K1_SMALL_LIST": "8"}, {"NDT_K1_LDS_CAP": "512"}, {"NDT_K1_SMALL_FINISH": "0"},
-                                 {"NDT_K1_SMALL": "0"}, {"NDT_K1_SMALL": "0", "NDT_K1_INDEX": "1"}],
-                         ids=["default", "lists_overflow_second_scan", "small_passes", "general_finish_only", "chain", "chain_index_form"])
+                                 {"NDT_K1_SMALL": "0"}, {"NDT_K1_SMALL": "0", "NDT_K1_INDEX": "1"}, {"NDT_VF_FROM": "0"},
+                                 {"NDT_VF_FROM": "0", "NDT_K1_LDS_CAP": "512"}, {"NDT_VF": "chain"}],
+                         ids=["default", "lists_overflow_second_scan", "small_passes", "general_finish_only", "chain", "chain_index_form",
+                              "voxel_filter_buckets_at_every_size", "voxel_filter_buckets_small_passes", "voxel_filter_general_chain"])
 def test_small_cloud_grid_regimes_against_the_oracle(env):
     """tools/fuzz_grid.py (random shapes up to 60 k points: uniform, clusters of thousands of points per voxel, sheets, lines, km
     offsets, NaN, strides, resolutions, grid parameters -- voxel indices / counts / means / covariances bit for bit against the
     oracle, dense == sparse records, N1 and N2 bit-exact) with the one-launch build of small clouds forced through each of its
     paths: wave lists that overflow (the second scan writes straight to the bucketed cloud), LDS passes of 512 points (multi-pass
     and crowded-cell paths of the finish), every bucket through the chain's finish instead of k1_finish_small -- and the chain
-    itself, in its point and its 4-byte-index scatter forms, as the cross-check."""
+    itself, in its point and its 4-byte-index scatter forms, as the cross-check.  The voxel filter (N1, and N2's) likewise: on
+    the bucket front end at every size (by default from 128 k points), with small passes, and on the general chain."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_grid.py"), "77", "14"], env=dict(os.environ, FUZZ_GRID_INDEX="1", **env),

@@ -917,6 +917,41 @@ ndt_status voxel_filter_enqueue(ndt_handle h, hipStream_t st, const float4* d_in
     HIP_TRY(ndt::launch_repack_bbox(d_out, n, sizeof(float4), nullptr, P.rows, nb_rows, st, 0, totals.p + 1));
     return NDT_OK;  // (the temporaries go back to the stream's pool: reused only behind these launches)
   }
+  // Dense grids within the bucket plan's range: the order-preserving bucket front end of K1 + vf_finalize / vf_bitmap_prefix /
+  // vf_place (ndt_grid_kernels.hip): the cell space is never walked, no point is gathered through an index.
+  // NDT_VF=chain: the general chain below for every grid (the cross-check).
+  static const bool vf_buckets = [] { const char* v = getenv("NDT_VF"); return !(v && std::strcmp(v, "chain") == 0); }();
+  ndt::GridBuildPlan plan{};
+  // (from 128 k points and for boxes with at most four cells per point: below / beyond, a bucket's share of the cell space --
+  // thousands of cells for a hundred points -- makes vf_finalize cost what the chain's scans cost: 60 k points 81 against 76 us,
+  // a 250 k-point map 29 us for that kernel alone; 300 k-point scan 81 against 111, 1 M 106 against 228.  NDT_VF_FROM=0: always.)
+  static const long long vf_from = [] { const char* v = getenv("NDT_VF_FROM"); return v ? static_cast<long long>(std::max(0, atoi(v))) : 131072ll; }();
+  const bool vf_dense = vf_from == 0 || (static_cast<long long>(n) >= vf_from && geo.n_cells <= 4ll * static_cast<long long>(n));
+  if (vf_buckets && vf_dense && ndt::filter_buckets_plan(geo.n_cells, ni, plan)) {
+    const size_t K = static_cast<size_t>(plan.n_buckets);
+    const size_t bw = ndt::filter_buckets_bitmap_words(geo.n_cells);
+    DevBuf<unsigned> cntmat, order, bucket_base, bitmap, wprefix;
+    DevBuf<float4> bpts, st_cent;
+    DevBuf<int> st_cell;
+    HIP_TRY(cntmat.reserve((static_cast<size_t>(plan.n_blocks) + 1) * K));
+    HIP_TRY(order.reserve(5 * n));
+    HIP_TRY(bucket_base.reserve(2 * K + 1));
+    HIP_TRY(bpts.reserve(n));
+    HIP_TRY(st_cell.reserve(n));
+    HIP_TRY(st_cent.reserve(n));
+    HIP_TRY(bitmap.reserve(bw));
+    HIP_TRY(wprefix.reserve(bw));
+    HIP_TRY(totals.reserve(4));
+    ndt::GridBuildScratch S{};
+    S.cntmat = cntmat.p;
+    S.bucket_base = bucket_base.p;
+    S.bpts = bpts.p;
+    S.order = order.p;
+    HIP_TRY(ndt::launch_filter_buckets(d_in, ni, is_dense, geo, plan, S, st_cell.p, st_cent.p, bitmap.p, wprefix.p, totals.p, d_out, st));
+    HIP_TRY(hipMemcpyAsync(P.tot, totals.p, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ndt::launch_repack_bbox(d_out, n, sizeof(float4), nullptr, P.rows, nb_rows, st, 0, totals.p + 1));
+    return NDT_OK;  // (the temporaries go back to the stream's pool: reused only behind these launches)
+  }
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));
   HIP_TRY(key.reserve(n));
   HIP_TRY(rank.reserve(n));

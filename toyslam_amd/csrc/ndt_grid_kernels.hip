@@ -1254,15 +1254,29 @@ constexpr int kTeamCell = 32, kTeamLanes = 16;
 constexpr size_t kK1MaxDynamicLds = 136 * 1024;  // of the CU's 160 KB (the kernels also hold up to ~20 KB of static LDS)
 constexpr int kMaxTeamCells = kK1LdsCap / (kTeamCell + 1) + 1;  // team cells one LDS pass can hold
 
+// What happens with a cell's sums once its points have been added up in order: the NDT grid turns them into a voxel record
+// (finish_voxel); the voxel FILTER (vf_finalize) emits the centroid.  fin(S, points, slot, cell) -> counted as "valid".
+struct K1RecordFin {
+  int min_pts;
+  double eig_ratio;
+  VoxelRec* __restrict__ recs;
+  VoxelSide* __restrict__ centroids;
+  int* __restrict__ lut;
+  const GridGeom* g;
+  __device__ __forceinline__ bool operator()(const VoxelSums& S, int n_c, int r, int cell) const {
+    const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
+    return finish_voxel(S, n_c, 0, r, cell, min_pts, eig_ratio, recs, centroids, lut, *g, nodump);
+  }
+};
+
 // One bucket, finished by one block: bucket k holds nb points (src), the first of them is point bb of the bucket order.
 // k1_lds: the dynamic LDS described at the launch (3 C words of per-cell state, 3 words per point of a pass, 5 rows of wmax
 // u16 counters).
-template <class Src>
+template <class Src, class Fin>
 __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, const unsigned bb, const unsigned nb, unsigned* k1_lds,
                                                    const GridGeom& g, const K1Deal& deal, int C, int min_pts,
-                                                   double eig_ratio, int lds_cap, int wmax /* cells one pass may span (power of two <= C) */,
-                                                   int* __restrict__ sorted_idx,
-                                                   VoxelRec* __restrict__ recs, VoxelSide* __restrict__ centroids, int* __restrict__ lut,
+                                                   int lds_cap, int wmax /* cells one pass may span (power of two <= C) */,
+                                                   int* __restrict__ sorted_idx /* or null */, const Fin& fin,
                                                    unsigned* __restrict__ bucket_valid /* [K]: valid voxels of every bucket */,
                                                    unsigned* __restrict__ scratch /* 5 x n words */, unsigned n_total,
                                                    unsigned long long* __restrict__ st /* development aid: 8 words per bucket, or null */) {
@@ -1353,7 +1367,7 @@ __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, 
         ox[q] = p[u].x;
         oy[q] = p[u].y;
         oz[q] = p[u].z;
-        sorted_idx[bb + q] = __float_as_int(p[u].w);
+        if (sorted_idx) sorted_idx[bb + q] = __float_as_int(p[u].w);
       }
     }
     __syncthreads();
@@ -1363,7 +1377,6 @@ __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, 
     k1_scan_cells(cnt, cstart, C, s_u3);
     lap(0);
   }
-  const FinalizeDump nodump{nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned n_ok = 0;
   // The bucket is finished in passes over runs of cells [c_lo, c_hi) that hold at most lds_cap points -- one pass for a
   // bucket of a uniform cloud, several for a crowded one (clustered data: a ground plane fills "its" buckets with many
@@ -1461,7 +1474,7 @@ __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, 
             px[q] = p[u].x;
             py[q] = p[u].y;
             pz[q] = p[u].z;
-            sorted_idx[bb + base + q] = __float_as_int(p[u].w);
+            if (sorted_idx) sorted_idx[bb + base + q] = __float_as_int(p[u].w);
           }
         }
         __syncthreads();
@@ -1493,7 +1506,7 @@ __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, 
         }
         for (; i < n_pass; i++) S.add(px[i], py[i], pz[i]);
         const int r = static_cast<int>((bb + base) / static_cast<unsigned>(min_pts));
-        n_ok += finish_voxel(S, static_cast<int>(n_pass), 0, r, k1_cell(k, c_lo, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+        n_ok += fin(S, static_cast<int>(n_pass), r, k1_cell(k, c_lo, deal)) ? 1u : 0u;
       }
       c_lo = c_hi;
       __syncthreads();
@@ -1591,7 +1604,7 @@ __device__ __forceinline__ void k1_finalize_bucket(const Src& src, const int k, 
         }
         for (; i < n_c; i++) S.add(ox[beg + i], oy[beg + i], oz[beg + i]);
       }
-      n_ok += finish_voxel(S, n_c, 0, r, k1_cell(k, c, deal), min_pts, eig_ratio, recs, centroids, lut, g, nodump) ? 1u : 0u;
+      n_ok += fin(S, n_c, r, k1_cell(k, c, deal)) ? 1u : 0u;
     }
     c_lo = c_hi;
     __syncthreads();  // the LDS arrays are reused by the next pass
@@ -1630,8 +1643,142 @@ __global__ __launch_bounds__(kBlock) void k1_finalize(const float4* __restrict__
   const K1Deal deal(map & 255, map >> 8);
   const int k = blockIdx.x;
   const unsigned bb = bucket_base[k], be = bucket_base[k + 1];
-  k1_finalize_bucket(k1_src(bpts, cloud, bb), k, bb, be - bb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
-                     bucket_valid, scratch, n_total, st);
+  k1_finalize_bucket(k1_src(bpts, cloud, bb), k, bb, be - bb, k1_lds, g, deal, C, min_pts, lds_cap, wmax, sorted_idx,
+                     K1RecordFin{min_pts, eig_ratio, recs, centroids, lut, &g}, bucket_valid, scratch, n_total, st);
+}
+
+// ---------------------------------------------------------------------------
+// N1 / N2 on the bucket front end: pcl::VoxelGrid's centroid filter for dense grids.  k1_hist / k1_colscan / k1_scatter as
+// for the NDT grid (order-preserving: every bucket, and after the stable placement every cell, holds its points in
+// ascending point index -- the order PCL adds them in), then
+//   vf_finalize      one block per bucket (k1_finalize_bucket with a finish of its own): a cell's f32 sums in point order ->
+//                    its centroid, staged at the position of the cell's first point in the bucket order (unique, no scan
+//                    over voxels); the positions of a bucket that start no cell are marked; and one BYTE of an occupancy
+//                    bitmap per run of eight cells -- the block owns its runs, so the bitmap is written whole, without a
+//                    clearing pass and without atomics
+//   vf_bitmap_prefix voxels before every 32-cell word of the bitmap: chunk c's block counts the bits of all the chunks
+//                    before it by itself (the bitmap is a few hundred KB out of L2: cheaper than a second launch for the
+//                    chunk sums), then scans its own chunk; the last chunk leaves the total
+//   vf_place         every staged centroid to its ordinal: voxels before its word + set bits below its own in the word ->
+//                    the output is dense and in ascending voxel index, PCL's order
+// The general chain (k_count ... k_voxel_centroids) walks the whole cell space three times and gathers every point through
+// an index; this form reads the points three times and the cell space never: 1 M points 228 -> 106 us, 2 M 346 -> 148 us per
+// call.  For clouds with about a point per cell (an accumulated map) a bucket's share of the cell space -- thousands of cells --
+// makes vf_finalize LDS-bound (two blocks per CU) and the chain is as fast: the host takes this form for dense clouds only.
+// ---------------------------------------------------------------------------
+struct VfCentroidFin {
+  int* __restrict__ st_cell;      // [n] voxel index at the position of a cell's first point, -1 elsewhere
+  float4* __restrict__ st_cent;   // [n] its centroid
+  __device__ __forceinline__ bool operator()(const VoxelSums& S, int n_c, int r, int cell) const {
+    const float nf = static_cast<float>(n_c);
+    st_cent[r] = make_float4(S.fx / nf, S.fy / nf, S.fz / nf, 1.0f);  // [PCL] centroid /= n, f32 sums in point order
+    st_cell[r] = cell;
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void vf_finalize(const float4* __restrict__ bpts, GridGeom g, int map, int K, int C, int lds_cap, int wmax,
+                                                      const unsigned* __restrict__ bucket_base, int* __restrict__ st_cell,
+                                                      float4* __restrict__ st_cent, unsigned char* __restrict__ bitmap,
+                                                      unsigned* __restrict__ bucket_valid, unsigned* __restrict__ scratch, unsigned n_total) {
+  extern __shared__ unsigned k1_lds[];
+  const K1Deal deal(map & 255, map >> 8);  // (run length 8: a run is a byte of the bitmap)
+  const int k = blockIdx.x;
+  const unsigned bb = bucket_base[k], be = bucket_base[k + 1], nb = be - bb;
+  for (unsigned j = threadIdx.x; j < nb; j += kBlock) st_cell[bb + j] = -1;
+  __syncthreads();  // (the marks are out before the finish writes the cells' own)
+  k1_finalize_bucket(K1GlobalSrc{bpts + bb, nullptr}, k, bb, nb, k1_lds, g, deal, C, 1, lds_cap, wmax, nullptr, VfCentroidFin{st_cell, st_cent},
+                     bucket_valid, scratch, n_total, nullptr);
+  __syncthreads();
+  // the bucket's runs -> their bytes of the bitmap (k1_lds[0 .. C): the cells' point counts, left by the finish)
+  const unsigned* cnt = k1_lds;
+  const long long n_runs = (g.n_cells + 7) >> 3;
+  for (int r = threadIdx.x; r < (C >> 3); r += kBlock) {
+    const long long run = static_cast<long long>(r) * K + k;  // k1_cell: cell = (run << 3) | i
+    if (run >= n_runs) continue;
+    unsigned bits = 0;
+    if (nb) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) bits |= (cnt[8 * r + i] > 0u ? 1u : 0u) << i;
+    }
+    bitmap[run] = static_cast<unsigned char>(bits);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) {  // the bytes behind the last run that still belong to the last word
+    const long long idx = n_runs + threadIdx.x, n_bytes = ((n_runs + 3) >> 2) << 2;
+    if (idx < n_bytes) bitmap[idx] = 0;
+  }
+}
+
+constexpr int kVfChunkWords = 4096;  // words (of 32 cells) one block of vf_bitmap_prefix scans
+__global__ __launch_bounds__(kBlock) void vf_bitmap_prefix(const unsigned* __restrict__ words, int n_words, unsigned* __restrict__ wprefix,
+                                                           unsigned* __restrict__ total /* [2]: -, voxels */) {
+  __shared__ unsigned s_w[kBlock / kWave];
+  __shared__ unsigned s_base;
+  const int lo = blockIdx.x * kVfChunkWords, hi = min(n_words, lo + kVfChunkWords);
+  // voxels in the chunks before mine (16-byte loads, eight in flight per thread: the loop is nothing but their latency)
+  unsigned before = 0;
+  {
+    const uint4* w4 = reinterpret_cast<const uint4*>(words);
+    const int n4 = lo / 4;  // (lo is a multiple of the chunk size)
+    for (int w0 = threadIdx.x; w0 < n4; w0 += 8 * kBlock) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = (w0 + u * kBlock < n4) ? w4[w0 + u * kBlock] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int u = 0; u < 8; u++) before += __popc(v[u].x) + __popc(v[u].y) + __popc(v[u].z) + __popc(v[u].w);
+    }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) before += __shfl_xor(before, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < kBlock / kWave; w++) t += s_w[w];
+    s_base = t;
+  }
+  __syncthreads();
+  // my chunk: 16 consecutive words per thread
+  constexpr int kPer = kVfChunkWords / kBlock;
+  unsigned v[kPer], sum = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    const int w = lo + threadIdx.x * kPer + i;
+    v[i] = (w < hi) ? __popc(words[w]) : 0u;
+    sum += v[i];
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  unsigned inc = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned a = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += a;
+  }
+  __syncthreads();
+  if (lane == kWave - 1) s_w[wave] = inc;
+  __syncthreads();
+  unsigned run = s_base + inc - sum, chunk_total = 0;
+  for (int w = 0; w < kBlock / kWave; w++) {
+    if (w < wave) run += s_w[w];
+    chunk_total += s_w[w];
+  }
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    const int w = lo + threadIdx.x * kPer + i;
+    if (w < hi) wprefix[w] = run;
+    run += v[i];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) total[1] = s_base + chunk_total;
+}
+
+__global__ __launch_bounds__(kBlock) void vf_place(const int* __restrict__ st_cell, const float4* __restrict__ st_cent, const unsigned* __restrict__ n_binned,
+                                                   const unsigned* __restrict__ words, const unsigned* __restrict__ wprefix, float4* __restrict__ out) {
+  const unsigned n = *n_binned;
+  for (unsigned r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+    const int cell = st_cell[r];
+    if (cell < 0) continue;
+    const unsigned w = static_cast<unsigned>(cell) >> 5, bit = static_cast<unsigned>(cell) & 31u;
+    out[wprefix[w] + __popc(words[w] & ((1u << bit) - 1u))] = st_cent[r];
+  }
 }
 
 // A bucket of at most kSmallFinish points, finished without any per-cell table: a thread per point, the point's place in
@@ -1938,7 +2085,7 @@ __global__ __launch_bounds__(kSmallThreads) void k1_small(const float4* __restri
   if (nb <= static_cast<unsigned>(small_finish))  // (uniform)
     k1_finish_small(lsrc, k, bb, nb, k1_lds, g, deal, min_pts, eig_ratio, sorted_idx, recs, centroids, lut, bucket_valid);
   else
-    k1_finalize_bucket(lsrc, k, bb, nb, k1_lds, g, deal, C, min_pts, eig_ratio, lds_cap, wmax, sorted_idx, recs, centroids, lut,
+    k1_finalize_bucket(lsrc, k, bb, nb, k1_lds, g, deal, C, min_pts, lds_cap, wmax, sorted_idx, K1RecordFin{min_pts, eig_ratio, recs, centroids, lut, &g},
                        bucket_valid, scratch, static_cast<unsigned>(n), st);
   mark(3);
 }
@@ -2322,6 +2469,53 @@ hipError_t launch_grid_build_small(const float4* pts, int n, int dense, const Gr
   hipLaunchKernelGGL(k1_small, dim3(K), dim3(kSmallThreads), fin_lds(lds_cap) + list_bytes, stream, pts, n, dense, g, P.shift, K, C, min_pts, eig_ratio,
                      lds_cap, wmax, list_cap, static_cast<unsigned>(fin_lds(lds_cap) / sizeof(unsigned)), small_finish, S.bucket_base, S.bpts, sorted_idx, recs,
                      centroids, lut, S.bucket_base + K + 1, S.order, counts, S.stamps);
+  return hipGetLastError();
+}
+
+// The voxel filter on the bucket front end (vf_finalize's header).  false: not for this grid (the caller takes the general chain).
+bool filter_buckets_plan(long long n_cells, int n_points, GridBuildPlan& P) {
+  if (!grid_build_plan(n_cells, n_points, P)) return false;
+  return (P.shift & 255) == 3;  // a run of eight cells is a byte of the occupancy bitmap
+}
+size_t filter_buckets_bitmap_words(long long n_cells) { return static_cast<size_t>(((n_cells + 7) / 8 + 3) / 4 + 1); }
+hipError_t launch_filter_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& P, const GridBuildScratch& S,
+                                 int* st_cell, float4* st_cent, unsigned* bitmap_words, unsigned* wprefix, unsigned* counts /* [0] binned, [1] voxels */,
+                                 float4* out, hipStream_t stream) {
+  const int K = P.n_buckets, C = P.cells_per_bucket;
+  const size_t lds_scatter = (static_cast<size_t>(K) + 2) * sizeof(unsigned) +
+                             static_cast<size_t>(K) * sizeof(unsigned short) + static_cast<size_t>(kK1Waves) * K * sizeof(unsigned short);
+  if (lds_scatter > kK1MaxDynamicLds || P.n_blocks > kColGroups * kColRows) return hipErrorInvalidValue;
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vf_finalize), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    return true;
+  }();
+  (void)once;
+  unsigned* total = S.cntmat + static_cast<size_t>(P.n_blocks) * K;
+  hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
+                     P.pts_per_block, S.cntmat, static_cast<int*>(nullptr), 0ll);
+  hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
+  hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
+                     total, S.bucket_base, S.bpts, counts, static_cast<unsigned long long*>(nullptr), 0);
+  const int wmax = std::min(C, 1024);
+  auto fin_lds = [&](int cap) { return (static_cast<size_t>(3) * C + 3 * static_cast<size_t>(cap)) * sizeof(unsigned) + 5 * static_cast<size_t>(wmax) * 2; };
+  int lds_cap = 256;
+  for (const size_t budget : {static_cast<size_t>(44 * 1024), static_cast<size_t>(70 * 1024), kK1MaxDynamicLds}) {
+    int cap = kK1LdsCap;
+    while (cap > 256 && fin_lds(cap) > budget) cap -= 256;
+    lds_cap = cap;
+    if (fin_lds(cap) <= budget && cap >= 1024) break;
+  }
+  static const int cap_env = [] { const char* v = getenv("NDT_K1_LDS_CAP"); return v ? std::max(256, atoi(v)) / 256 * 256 : 0; }();
+  if (cap_env > 0) lds_cap = std::min(lds_cap, cap_env);
+  if (fin_lds(lds_cap) > kK1MaxDynamicLds) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vf_finalize, dim3(K), dim3(kBlock), fin_lds(lds_cap), stream, S.bpts, g, P.shift, K, C, lds_cap, wmax, S.bucket_base, st_cell, st_cent,
+                     reinterpret_cast<unsigned char*>(bitmap_words), S.bucket_base + K + 1, S.order, static_cast<unsigned>(n));
+  const int n_words = static_cast<int>(((g.n_cells + 7) / 8 + 3) / 4);
+  const int n_chunks = (n_words + kVfChunkWords - 1) / kVfChunkWords;
+  hipLaunchKernelGGL(vf_bitmap_prefix, dim3(n_chunks), dim3(kBlock), 0, stream, bitmap_words, n_words, wprefix, counts);
+  hipLaunchKernelGGL(vf_place, dim3(std::max(1, std::min(2048, (n + kBlock - 1) / kBlock))), dim3(kBlock), 0, stream, st_cell, st_cent, counts, bitmap_words,
+                     wprefix, out);
   return hipGetLastError();
 }
 

@@ -156,6 +156,14 @@ struct GridBuildScratch {
 };
 // counts: device [4] = {points binned, occupied voxels, candidate voxels, valid voxels}.  The build fills [0] and [3];
 // [1], [2] and the leaf arrays come from launch_grid_leaves (on demand).  Record slots: n / min_pts + 1.
+// pcl::VoxelGrid's centroid filter on the same front end (ndt_grid_kernels.hip "N1 / N2 on the bucket front end"): out receives
+// one centroid per occupied voxel in ascending voxel index; counts[1] = how many.  st_cell / st_cent: n entries each; bitmap_words
+// / wprefix: filter_buckets_bitmap_words(n_cells) words each.
+bool filter_buckets_plan(long long n_cells, int n_points, GridBuildPlan& plan);
+size_t filter_buckets_bitmap_words(long long n_cells);
+hipError_t launch_filter_buckets(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, const GridBuildScratch& scratch,
+                                 int* st_cell, float4* st_cent, unsigned* bitmap_words, unsigned* wprefix, unsigned* counts, float4* out,
+                                 hipStream_t stream);
 // the same grid from ONE launch, for small clouds (every block scans the whole cloud and finishes its own bucket); scratch.cntmat unused
 bool grid_build_small_applies(int n_points, const GridBuildPlan& plan);
 hipError_t launch_grid_build_small(const float4* pts, int n, int dense, const GridGeom& g, const GridBuildPlan& plan, int min_pts,
