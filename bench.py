@@ -684,6 +684,26 @@ def node_rows(reg, ndt, clouds, np):
     v2 = h.mapSize()
     b1 = n_raw * 16 + v1 * 16
     b2 = m_in * 16 + v2 * 16
+    # ... and N1 on a 1 M-point scan of the same scene (dense clouds from 128 k points take K1's bucket front end)
+    big = {}
+    try:
+        n_big = 1000000
+        wb = clouds.target_surfaces(n_big, seed=78, extent=60.0)[:, :3].astype(np.float32)
+        db = torch.from_numpy(np.ascontiguousarray(np.c_[wb, np.ones(n_big)].astype(np.float32))).cuda()
+        torch.cuda.synchronize()
+        kb = {}
+
+        def n1b(i):
+            c, _ = h.voxelGridFilterCloudDevice(db.data_ptr(), n_big, 16, leaf)
+            kb["n"] = len(c)
+        t_b = med(n1b, 12)
+        bb = n_big * 16 + kb["n"] * 16
+        big = {"us_per_call": t_b * 1e6, "points_in": n_big, "voxels_out": kb["n"], "algorithmic_bytes": bb,
+               "roofline": {"bound": "hbm", "achieved": bb / t_b / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bb / t_b / 1e9 / HBM_PEAK_GBS},
+               "what": "ndt_cloud_voxel_filter of a 1 M-point scan in HBM: k1_hist / k1_colscan / k1_scatter / vf_finalize / vf_bitmap_prefix / vf_place"}
+        del db
+    except Exception as e:
+        big = {"error": repr(e)}
     return {"workload": "raw scan of %d points over a 60 m scene, %.1f m leaf; map of ~%d points" % (n_raw, leaf, m_before),
             "n1_voxel_filter": {"us_per_call": t_n1 * 1e6, "points_in": n_raw, "voxels_out": v1, "algorithmic_bytes": b1,
                                 "roofline": {"bound": "hbm", "achieved": b1 / t_n1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b1 / t_n1 / 1e9 / HBM_PEAK_GBS},
@@ -692,7 +712,8 @@ def node_rows(reg, ndt, clouds, np):
             "n2_map_update": {"us_per_call": t_n2 * 1e6, "points_in": m_in, "voxels_out": v2, "algorithmic_bytes": b2,
                               "roofline": {"bound": "hbm", "achieved": b2 / t_n2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b2 / t_n2 / 1e9 / HBM_PEAK_GBS},
                               "what": "ndt_map_update_cloud: transform of the scan into the map's tail + voxel filter of map and scan"},
-            "note": "both are chains of ~10 small launches paced by launch and completion latencies, not by bytes: the fractions say so"}
+            "n1_voxel_filter_1m_points": big,
+            "note": "at the nodes' size both are chains of ~10 small launches paced by launch and completion latencies, not by bytes: the fractions say so"}
 
 
 # =====================================================================================================
