@@ -395,3 +395,44 @@ def test_config4_pyramid_on_a_streamed_sequence(mods, cfg_b, large_golden, seq16
     assert (rot < 2e-4).all() and (tr < 2e-2).all(), (rot.tolist(), tr.tolist())
     r2 = pyr.run_sequence(seq_dir, overlap=False)
     assert all(np.array_equal(a, b) for a, b in zip(r["T"], r2["T"]))
+
+
+def test_voxel_filter_and_map_update_at_scan_and_map_sizes(mods):
+    """N1 / N2 at sizes the grid fuzzer (up to 60 k points) does not reach: a 1 M-point scan through the voxel filter's bucket
+    front end (dense clouds from 128 k points) and through the general chain (an accumulated map: a point per cell), host buffers
+    and resident clouds, against the oracle's restatement of pcl::VoxelGrid -- array_equal; then a map grown to several hundred
+    thousand points scan by scan against the oracle's transformPointCloud / += / VoxelGrid loop."""
+    ndt, po, clouds, _ = mods
+    rng = np.random.default_rng(17)
+    scan = clouds.target_surfaces(1000000, seed=31, extent=60.0)[:, :3].astype(np.float32)
+    g = ndt.NormalDistributionsTransform()
+    for leaf in (0.5, 0.2):
+        ref, ov = po.voxel_grid_filter(scan, leaf)
+        assert not ov
+        got = g.voxelGridFilter(scan, leaf)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        c, ovc = g.voxelGridFilterCloud(scan, leaf)
+        assert not ovc and np.array_equal(c.numpy(), ref)
+        c.release()
+    # non-finite points in a cloud that is not dense, 32-byte records
+    wide = np.zeros((len(scan), 8), np.float32)
+    wide[:, :3] = scan
+    wide[::7777, 1] = np.nan
+    wide[5::9999, 2] = np.inf
+    ref, _ = po.voxel_grid_filter(wide, 0.5, is_dense=False)
+    assert np.array_equal(g.voxelGridFilter(wide, 0.5, is_dense=False), ref)
+    # the map: eight 100 k-point scans of the scene from eight poses, filtered at 0.3, accumulated at 0.5
+    world = clouds.target_surfaces(400000, seed=32, extent=60.0)[:, :3].astype(np.float32)
+    ref_map = np.zeros((0, 3), np.float32)
+    g.mapClear()
+    for k in range(8):
+        pose = clouds.make_T([0.4 * k, 0.1 * k, 0.01 * k], np.deg2rad([0.1 * k, -0.05 * k, 1.5 * k])).astype(np.float32)
+        raw = (world[rng.choice(len(world), 100000, replace=False)] + rng.normal(0, 0.01, (100000, 3))).astype(np.float32)
+        fc, _ = g.voxelGridFilterCloud(raw, 0.3)
+        f_ref = po.voxel_grid_filter(raw, 0.3)[0]
+        n_map, ovm = g.mapUpdateCloud(fc, pose, 0.5)
+        moved = po.transform_cloud(np.c_[f_ref, np.ones(len(f_ref), np.float32)], pose)[:, :3]
+        ref_map, ov_ref = po.voxel_grid_filter(np.concatenate([ref_map, moved]), 0.5)
+        assert not ovm and not ov_ref and n_map == len(ref_map), k
+        fc.release()
+    assert len(ref_map) > 100000 and np.array_equal(g.mapGet(), ref_map)
