@@ -65,19 +65,82 @@ struct ndt_pcd_sequence {
   }
 };
 
+namespace {
+// Page-locked scan buffers outlive the sequence that asked for them: page-locking a 2 M-point scan's 40 MB costs ~10 ms and
+// giving it back ~6 ms, and a sequence takes six of them -- a node that opens a sequence per batch of files (or a benchmark
+// per pass: 16 scans of 60 ms) paid more for its buffers than for the registrations.  Blocks go back to a process-wide list
+// (at most NDT_PINNED_CACHE_MB megabytes, default 512; 0 = none kept) and are handed out again to whoever asks for that
+// much or a little less; whatever the list holds at exit goes with the process.
+class PinnedCache {
+ public:
+  static PinnedCache& instance() {
+    static PinnedCache* c = new PinnedCache();  // (never destroyed: the runtime may be gone before static destructors run)
+    return *c;
+  }
+  void* take(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      size_t best = free_.size();
+      for (size_t k = 0; k < free_.size(); k++)
+        if (free_[k].bytes >= bytes && free_[k].bytes <= bytes + bytes / 2 + (1u << 20) && (best == free_.size() || free_[k].bytes < free_[best].bytes)) best = k;
+      if (best != free_.size()) {
+        const Block b = free_[best];
+        free_.erase(free_.begin() + static_cast<long>(best));
+        kept_ -= b.bytes;
+        out_.push_back(b);
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu_);
+    out_.push_back(Block{p, bytes});
+    return p;
+  }
+  void give(void* p) {
+    if (!p) return;
+    Block b{p, 0};
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t k = 0; k < out_.size(); k++)
+        if (out_[k].p == p) {
+          b = out_[k];
+          out_.erase(out_.begin() + static_cast<long>(k));
+          break;
+        }
+      if (b.bytes && kept_ + b.bytes <= cap_) {
+        kept_ += b.bytes;
+        free_.push_back(b);
+        return;
+      }
+    }
+    (void)hipHostFree(p);
+  }
+
+ private:
+  struct Block {
+    void* p;
+    size_t bytes;
+  };
+  PinnedCache() {
+    const char* v = std::getenv("NDT_PINNED_CACHE_MB");
+    cap_ = static_cast<size_t>(v ? std::max(0, std::atoi(v)) : 512) << 20;
+  }
+  std::mutex mu_;
+  std::vector<Block> free_, out_;
+  size_t kept_ = 0, cap_ = 0;
+};
+}  // namespace
+
 ndt_status ndt_pcd_sequence_open(const char* directory, ndt_pcd_sequence_handle* out) {
   if (!directory || !out) return fail(NDT_ERR_INVALID, "bad arguments");
   // page-locked when a device is there (the scans go straight into ndt_set_input_* / ndt_voxel_grid_filter uploads),
   // pageable otherwise -- reading files needs no GPU
   const bool pinned = usable_devices() > 0;
-  auto alloc = [pinned](size_t bytes) -> void* {
-    void* p = nullptr;
-    if (pinned && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
-    return nullptr;
-  };
   auto seq = new ndt_pcd_sequence();
   if (pinned)
-    seq->seq.reset(new ndt::PcdSequence(directory, alloc, [](void* p) { (void)hipHostFree(p); }));
+    seq->seq.reset(new ndt::PcdSequence(directory, [](size_t bytes) { return PinnedCache::instance().take(bytes); },
+                                        [](void* p) { PinnedCache::instance().give(p); }));
   else
     seq->seq.reset(new ndt::PcdSequence(directory, [](size_t bytes) { return std::malloc(bytes); }, [](void* p) { std::free(p); }));
   *out = seq;

@@ -15,6 +15,8 @@
 #include "ndt_pcd.hpp"
 
 #include <emmintrin.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 namespace ndt {
 namespace {
@@ -252,15 +254,31 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
       // in page faults as the read itself); records whose x / y / z are 4-byte floats -- what every PCL writer produces
       // for PointXYZ* -- are copied without the per-scalar type dispatch
       const size_t chunk = 32768;
-      body.resize(std::min(chunk, std::max<size_t>(h.points, 1)) * h.record);
+      // The body mapped where the page cache has it (NDT_PCD_MMAP=0: read through the chunk buffer): the read's copy out of
+      // the page cache is half of the memory traffic of parsing a file, and the readers of a sequence share the host's
+      // memory bandwidth (ndt_sequence.hpp).  A file that cannot be mapped (a pipe, an odd file system) is read.
+      static const bool use_mmap = [] { const char* v = std::getenv("NDT_PCD_MMAP"); return !v || std::atoi(v) != 0; }();
+      const unsigned char* mapped = nullptr;
+      size_t map_len = 0, map_skew = 0;
+      if (use_mmap && raw_bytes > 0 && h.body_bytes >= raw_bytes) {
+        const long page = sysconf(_SC_PAGESIZE);
+        map_skew = static_cast<size_t>(h.body_offset) % static_cast<size_t>(page);
+        map_len = raw_bytes + map_skew;
+        void* m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), static_cast<off_t>(static_cast<size_t>(h.body_offset) - map_skew));
+        if (m != MAP_FAILED) {
+          mapped = static_cast<const unsigned char*>(m);
+          (void)madvise(m, map_len, MADV_SEQUENTIAL);
+        }
+      }
+      if (!mapped) body.resize(std::min(chunk, std::max<size_t>(h.points, 1)) * h.record);
       const Field &fx = h.fields[ix], &fy = h.fields[iy], &fz = h.fields[iz];
       const bool f32 = fx.type == 'F' && fx.size == 4 && fy.type == 'F' && fy.size == 4 && fz.type == 'F' && fz.size == 4;
       const bool wide = stride >= 16;
       uint32_t nonfinite = 0;
       for (size_t i0 = 0; i0 < h.points && !rc; i0 += chunk) {
         const size_t m = std::min(chunk, h.points - i0);
-        if (std::fread(body.data(), h.record, m, f) != m) { rc = 2; err = std::string(path) + ": truncated binary body"; break; }
-        const unsigned char* r = body.data();
+        if (!mapped && std::fread(body.data(), h.record, m, f) != m) { rc = 2; err = std::string(path) + ": truncated binary body"; break; }
+        const unsigned char* r = mapped ? mapped + map_skew + i0 * h.record : body.data();
         unsigned char* d = o + i0 * stride;
         if (f32 && wide && h.record == 12 && fx.offset == 0 && fy.offset == 4 && fz.offset == 8) {
           // the plain "x y z" record of pcl::PCDWriter for PointXYZ: one unaligned 16-byte load per point (the last record of
@@ -276,7 +294,7 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
             bad = _mm_or_si128(bad, _mm_cmpeq_epi32(_mm_and_si128(_mm_castps_si128(v), expo), expo));
           }
           if (_mm_movemask_epi8(bad) & 0x0fff) nonfinite = 1;
-          for (; i < m; i++, r += 12, d += stride) {
+          for (; i < m; i++, r += 12, d += stride) {  // (the file's last record: 16 bytes from there could leave the mapping)
             uint32_t v[4];
             std::memcpy(v, r, 12);
             v[3] = 0x3f800000u;
@@ -302,6 +320,7 @@ int pcd_read_xyz(const char* path, void* out, size_t capacity, size_t stride, si
         }
       }
       if (nonfinite) dense = false;
+      if (mapped) (void)munmap(const_cast<unsigned char*>(mapped), map_len);
     } else {
       uint32_t sizes[2];
       if (std::fread(sizes, 4, 2, f) != 2) { rc = 2; err = std::string(path) + ": truncated compressed header"; }

@@ -673,6 +673,19 @@ class PcdSequence:
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 4))
         return a[:, :3].copy(), bool(dense.value), num.value
 
+    def stage(self, device=0):
+        """From now on the reading threads copy every scan to `device` as soon as its file is parsed (next_device)."""
+        check(self._L.ndt_pcd_sequence_stage(self._h, int(device)))
+
+    def next_device(self):
+        """-> (device address, host address, n, is_dense, file_number) of the next staged scan (16-byte records, valid until
+        the following call of a next* method), or None when nothing is queued."""
+        d, p, n, dense, num = C.c_void_p(), C.c_void_p(), C.c_size_t(0), C.c_int(1), C.c_int(-1)
+        check(self._L.ndt_pcd_sequence_next_device(self._h, C.byref(d), C.byref(p), C.byref(n), C.byref(dense), C.byref(num)))
+        if not p.value:
+            return None
+        return d.value, p.value, n.value, bool(dense.value), num.value
+
     def next_raw(self):
         """-> (host address of n x (x, y, z, 1.0f) records, n, is_dense, file_number) or None.  The records sit in one of
         the sequence's two (page-locked) buffers and stay valid until the following call of next / next_raw."""
