@@ -231,6 +231,34 @@ def test_reader_survives_mutated_files_under_sanitizers(tmp_path):
     assert "no crash" in out.stdout
 
 
+def test_mapped_and_read_bodies_parse_alike(ndt, tmp_path):
+    """A binary body parsed from a mapping of the file (the default) and through the chunk buffer (NDT_PCD_MMAP=0) gives the
+    same records: 12-byte and wider records, more than one 32768-point chunk, a NaN in the last record."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(5)
+    xyz = rng.standard_normal((70001, 3)).astype(np.float32)
+    xyz[-1, 1] = np.nan
+    plain = str(tmp_path / "plain.pcd")
+    ndt.pcd_write_xyz(plain, xyz)
+    wide = str(tmp_path / "wide.pcd")
+    rec = np.zeros(len(xyz), dtype=[("i", "<f4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("t", "<f8")])
+    rec["x"], rec["y"], rec["z"], rec["i"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], 7.0
+    with open(wide, "wb") as f:
+        f.write(("# .PCD v0.7\nVERSION 0.7\nFIELDS intensity x y z stamp\nSIZE 4 4 4 4 8\nTYPE F F F F F\nCOUNT 1 1 1 1 1\n"
+                 "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (len(xyz), len(xyz))).encode())
+        f.write(rec.tobytes())
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from toyslam_amd import ndt; "
+            "a, d = ndt.pcd_read_xyz(sys.argv[1]); sys.stdout.buffer.write(bytes([int(d)]) + np.ascontiguousarray(a).tobytes())" % root)
+    for path in (plain, wide):
+        outs = [subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NDT_PCD_MMAP=m), capture_output=True, check=True).stdout
+                for m in ("1", "0")]
+        assert outs[0] == outs[1] and outs[0][0] == 0  # (not dense: the NaN)
+        got = np.frombuffer(outs[0][1:], dtype=np.float32).reshape(len(xyz), -1)[:, :3]
+        assert np.array_equal(got, xyz, equal_nan=True)
+
+
 # ------------------------------------------------------------------ numbered scans of a directory (the mapping node's input)
 def test_extract_file_number_follows_the_node(ndt):
     """extract_file_number (ndt_omp_mapping_node.cpp:231-239): std::stoi of what follows the last underscore, -1 otherwise."""
