@@ -25,6 +25,14 @@ namespace {
 // inter-kernel gap of the two-kernel path (~5 us per evaluation at 100k points).
 // The counter is reset by the last block, so it is 0 again at the next launch.
 // ---------------------------------------------------------------------------
+#ifdef NDT_DIAG_BLOCK_CLOCKS  // (diagnostic build: when every block of the one-launch kernel started and its waves ended)
+__device__ unsigned long long g_block_clocks[4096][4];
+__device__ __forceinline__ unsigned long long wall_ticks() {  // the constant 100 MHz clock (s_memtime is per shader engine)
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
 constexpr int kFusedShards = 16;  // shard counters of the fused kernel's ticket: counter[32 * (1 + s)], top counter[0]
 template <int NNB, bool WANT_H, int TPB>
 __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restrict__ src, int n, GridView gv, EvalParams P,
@@ -45,6 +53,10 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
     pack_tables(P, sT, threadIdx.x, TPB);
   }
   __syncthreads();
+#ifdef NDT_DIAG_BLOCK_CLOCKS
+  __shared__ unsigned long long s_wave_end[kWaves];
+  const unsigned long long t_block_start = wall_ticks();
+#endif
   double acc[kNumAcc];
 #pragma unroll
   for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
@@ -56,9 +68,24 @@ __global__ __launch_bounds__(TPB) void k_derivatives_fused(const float4* __restr
   else derivatives_body<NNB == 27 ? 7 : NNB, WANT_H, false, false, true, true>(src, n, gv, sP, sT, first, gridDim.x * ppb, acc);  // (LIMIT, REC4: 126 VGPRs)
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#ifdef NDT_DIAG_BLOCK_CLOCKS
+  if (lane == 0) s_wave_end[wave] = wall_ticks();
+#endif
   const double tot = wave_fold<kNumAcc>(acc);
   if ((lane & 1) == 0) lds[wave * 32 + fold_index(lane)] = tot;
   __syncthreads();
+#ifdef NDT_DIAG_BLOCK_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int w = 0; w < kWaves; w++) { lo = min(lo, s_wave_end[w]); hi = max(hi, s_wave_end[w]); }
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_block_clocks[blockIdx.x][0] = t_block_start;
+    g_block_clocks[blockIdx.x][1] = lo;
+    g_block_clocks[blockIdx.x][2] = hi;
+    g_block_clocks[blockIdx.x][3] = xcc;
+  }
+#endif
   if (wave == 0) {
     if (lane < kEvalStride) {
       double v = 0.0;
@@ -625,6 +652,11 @@ hipError_t launch_derivatives_fused(const float4* src, int n, const GridView& gv
   return hipGetLastError();
 }
 
+#ifdef NDT_DIAG_BLOCK_CLOCKS
+extern "C" int ndt_diag_block_clocks_read(unsigned long long* out, int n_blocks) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_clocks), static_cast<size_t>(n_blocks) * 4 * sizeof(unsigned long long)));
+}
+#endif
 size_t server_mailbox_bytes() { return sizeof(ServerMailbox); }
 
 // host side of the mailbox protocol (pinned, coherent host memory): the 32 tagged words are built
