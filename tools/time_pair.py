@@ -3,6 +3,8 @@ scan -- setInputTarget, setInputSource, align (with and without fetching the ali
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
+torch.cuda.init()  # (before the library touches the device: initialised later, torch finds no GPU)
 from toyslam_amd import ndt
 d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pair_0p1.npz"))
 t, s = d["target"], d["source"]
@@ -23,7 +25,6 @@ per_scan = med(scan)
 print("per scan (target + source + align + result) %.0f us" % per_scan)
 # the host's part of the two set calls with the GPU idle when they start, and call + the GPU's completion (the back-to-back
 # figures below are paced by the GPU: a call returns once its work is queued and the page-locked slot of four calls ago is free)
-import torch
 def split(f, n=60):
     a, b = [], []
     for _ in range(n):
