@@ -959,6 +959,36 @@ def test_small_cloud_grid_regimes_against_the_oracle(env):
     assert "grid fuzz done, mismatches: 0" in r.stdout, r.stdout[-1500:]
 
 
+# ------------------------------------------------------------------ scans staged to HBM by the sequence's reading threads
+def test_staged_sequence_hands_out_the_files_records(mods, pair, tmp_path):
+    """ndt_pcd_sequence_stage / _next_device: the records a sequence copied to the device itself are the file's -- a source
+    set from the device address registers like the host records of the same file (same bits), file after file, and a second
+    pass over the directory (page-locked buffers taken back from the process-wide list) hands out the same."""
+    ndt, _, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(11)
+    scans = [(s + rng.normal(0, 0.01, s.shape)).astype(np.float32) for _ in range(4)]
+    for k, c in enumerate(scans):
+        clouds.write_pcd_xyz(str(tmp_path / ("cloud_%d.pcd" % (k + 1))), c)
+    g, href = ndt.NormalDistributionsTransform(), ndt.NormalDistributionsTransform()
+    g.setInputTarget(t)
+    href.setInputTarget(t)
+    for _pass in range(2):
+        seq = ndt.PcdSequence(str(tmp_path))
+        seq.stage(0)
+        assert seq.poll(0) == 4
+        for k in range(4):
+            d_ptr, h_ptr, n, dense, num = seq.next_device()
+            assert n == len(scans[k]) and dense and num == k + 1
+            g.setInputSourceDevice(d_ptr, n, 16)
+            g.align()
+            href.setInputSource(scans[k])
+            href.align()
+            assert np.array_equal(g.getFinalTransformation(), href.getFinalTransformation()) and g.getFinalNumIteration() == href.getFinalNumIteration()
+        assert seq.next_device() is None
+        del seq
+
+
 # ------------------------------------------------------------------ clouds that stay in HBM (ndt_cloud)
 def test_resident_clouds_equal_host_buffers(mods, pair):
     """The node loop's steps with the filtered scan staying in HBM as an ndt_cloud -- prefilter, source of one registration,
