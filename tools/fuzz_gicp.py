@@ -95,9 +95,10 @@ while time.time() < t_end:
             # the registration is not a continuous function of its input.  Ask the oracle itself: the same case with ONE
             # source coordinate moved by one ulp.
             own = 0.0
-            for trial in range(4):
+            rng2 = np.random.default_rng(cases)  # (the extra trials draw from a stream of their own: the case sequence stays what it was)
+            for trial in range(16):
                 src2 = src.copy()
-                j = int(rng.integers(len(src2)))
+                j = int((rng if trial < 4 else rng2).integers(len(src2)))
                 src2[j, trial % 3] = np.nextafter(src2[j, trial % 3], np.float32(np.inf if trial % 2 == 0 else -np.inf))
                 o2 = po.OracleGICP(**kw)
                 o2.setInputTarget(tgt); o2.setInputSource(src2)
