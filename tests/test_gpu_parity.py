@@ -1194,6 +1194,70 @@ def test_concurrent_handles_share_one_gpu(mods, pair):
     assert not bad
 
 
+def test_resident_clouds_across_threads_and_handles(mods, pair):
+    """ndt_cloud objects under four host threads: every thread runs the node loop's steps on a handle of its own (prefilter
+    into a cloud, source, a target cloud that ALL threads share and that another handle made, registration, map update,
+    release by whichever thread is last), while scan sequences are opened and closed beside them (the page-locked buffer
+    list) -- every registration and every map are the one-thread run's bits, nothing hangs."""
+    import threading
+    ndt, po, clouds = mods
+    t, s = pair
+    rng = np.random.default_rng(21)
+    raw_s = (np.repeat(s, 3, axis=0) + rng.normal(0, 0.02, (3 * len(s), 3))).astype(np.float32)
+    maker = ndt.NormalDistributionsTransform()
+    shared_target, _ = maker.voxelGridFilterCloud((np.repeat(t, 3, axis=0) + rng.normal(0, 0.02, (3 * len(t), 3))).astype(np.float32), 0.5)
+
+    def loop(g, reps, out):
+        for _ in range(reps):
+            c, _ov = g.voxelGridFilterCloud(raw_s, 0.5)
+            g.setInputTargetCloud(shared_target)
+            g.setInputSourceCloud(c)
+            g.align()
+            g.mapClear()
+            n_map, _ = g.mapUpdateCloud(c, g.getFinalTransformation(), 0.5)
+            out.append((g.getFinalTransformation().copy(), g.getFinalNumIteration(), n_map, len(c)))
+            c.release()
+
+    ref = []
+    loop(ndt.NormalDistributionsTransform(), 1, ref)
+    outs = [[] for _ in range(4)]
+    handles = [ndt.NormalDistributionsTransform() for _ in range(4)]
+    threads = [threading.Thread(target=loop, args=(handles[i], 40, outs[i])) for i in range(4)]
+    stop = threading.Event()
+
+    def churn_sequences(tmp):
+        while not stop.is_set():
+            q = ndt.PcdSequence(tmp)
+            q.poll(0)
+            while q.next_raw() is not None:
+                pass
+            del q
+
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for k in range(3):
+            clouds.write_pcd_xyz(os.path.join(tmp, "cloud_%d.pcd" % (k + 1)), raw_s[: 20000 + 1000 * k])
+        churn = threading.Thread(target=churn_sequences, args=(tmp,))
+        churn.start()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=180)
+        stop.set()
+        churn.join(timeout=60)
+    assert not any(th.is_alive() for th in threads) and not churn.is_alive(), "a thread did not return"
+    for o in outs:
+        assert len(o) == 40
+        for T, it, n_map, n_c in o:
+            assert np.array_equal(T, ref[0][0]) and (it, n_map, n_c) == ref[0][1:]
+    del maker  # (the handle that made the shared target goes first; the cloud outlives it)
+    g = ndt.NormalDistributionsTransform()
+    g.setInputTargetCloud(shared_target)
+    g.setInputSource(s)
+    g.align()
+    shared_target.release()
+
+
 # ------------------------------------------------------------------ HBM-resident entry points
 def test_device_resident_entry_points_equal_host_ones(mods, pair):
     """Every *_device entry point (clouds handed over as device pointers: prefilter, target, source,
