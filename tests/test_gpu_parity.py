@@ -959,6 +959,22 @@ def test_small_cloud_grid_regimes_against_the_oracle(env):
     assert "grid fuzz done, mismatches: 0" in r.stdout, r.stdout[-1500:]
 
 
+def test_source_ordering_by_radix_passes_is_the_counting_sorts_order():
+    """The ordering of big sources (lattice-cell order, a cell's points in the order they came in, non-finite points dropped)
+    by stable radix passes of K1's order-preserving scatter and by the counting sort it replaces: the f64 sums of an evaluation
+    over the ordered scan and the registration are the same bits (tools/probes/order_check.py in two processes; sources of
+    300 to 90 k points, with NaN coordinates, forced through the ordering at every size)."""
+    import subprocess
+    import sys
+    outs = []
+    for extra in (dict(NDT_ORDER="chain"), dict(NDT_ORDER_RADIX_FROM="0")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "order_check.py"), "small"], env=dict(os.environ, NDT_SORT_SOURCE="1", **extra),
+                           capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln.split("|")[0] for ln in r.stdout.splitlines() if "eval hash" in ln])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
+
+
 # ------------------------------------------------------------------ scans staged to HBM by the sequence's reading threads
 def test_staged_sequence_hands_out_the_files_records(mods, pair, tmp_path):
     """ndt_pcd_sequence_stage / _next_device: the records a sequence copied to the device itself are the file's -- a source

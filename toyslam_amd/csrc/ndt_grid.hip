@@ -296,6 +296,27 @@ ndt_status order_range(ndt_context* h, const float4* d_pts, size_t n, float pitc
   geo.mul[1] = geo.div_b[0];
   geo.mul[2] = geo.div_b[0] * geo.div_b[1];
   geo.n_cells = static_cast<long long>(geo.div_b[0]) * geo.div_b[1] * geo.div_b[2];
+  // Big clouds: stable radix passes of K1's order-preserving scatter (launch_order_radix) -- the same order, point for point,
+  // as the counting sort below (NDT_ORDER=chain: that one always).
+  static const bool radix_on = [] { const char* v = getenv("NDT_ORDER"); return !v || std::strcmp(v, "chain") != 0; }();
+  static const size_t radix_from = [] { const char* v = getenv("NDT_ORDER_RADIX_FROM"); return v ? static_cast<size_t>(std::max(0, atoi(v))) : static_cast<size_t>(65536); }();
+  if (radix_on && n >= radix_from && ndt::order_radix_passes(geo.n_cells) <= 3) {
+    int digit_bits = 0;
+    const size_t words = ndt::order_radix_cntmat_words(geo.n_cells, ni, nullptr, nullptr, &digit_bits);
+    const int passes = ndt::order_radix_passes(geo.n_cells);
+    DevBuf<unsigned> cntmat, bucket_base, counts;
+    DevBuf<float4> tmp;
+    HIP_TRY(cntmat.reserve(words));
+    HIP_TRY(bucket_base.reserve((static_cast<size_t>(1) << digit_bits) + 1));
+    HIP_TRY(counts.reserve(4));
+    if (passes > 1) HIP_TRY(tmp.reserve(n));
+    HIP_TRY(ndt::launch_order_radix(d_pts, ni, geo, cntmat.p, bucket_base.p, tmp.p, d_out, counts.p, st));
+    unsigned kept = 0;
+    HIP_TRY(hipMemcpyAsync(&kept, counts.p + (passes - 1), sizeof(kept), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_out = kept;
+    return NDT_OK;
+  }
   DevBuf<unsigned> cell_count, block_sums, totals, leaf_start, rank;
   DevBuf<int> key, leaf_cell, leaf_count, leaf_rec, sorted_idx;
   HIP_TRY(cell_count.reserve(static_cast<size_t>(geo.n_cells)));

@@ -943,8 +943,10 @@ __device__ __forceinline__ unsigned wave_rank(int key, bool valid, unsigned long
 // (block, bucket) with a returning global atomic -- 250 k of them at 1 M points, 11 us of memory-side atomics, and runs in
 // the order the blocks happened to arrive); the look-up table is cleared on the side (nothing reads it before k1_finalize)
 __global__ __launch_bounds__(kK1Threads) void k1_hist(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
-                                                      int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells) {
+                                                      int ppb, unsigned* __restrict__ cntmat, int* __restrict__ lut, long long lut_cells,
+                                                      const unsigned* __restrict__ n_dev) {
   extern __shared__ unsigned k1_lds[];
+  if (n_dev) n = min(n, static_cast<int>(*n_dev));  // (a pass of launch_order_radix: the points an earlier pass kept)
   const K1Deal deal(map & 255, map >> 8);
   unsigned* h = k1_lds;
   const int slice = k1_slice(blockIdx.x, gridDim.x);
@@ -1027,8 +1029,10 @@ __global__ __launch_bounds__(kK1Threads) void k1_colscan(unsigned* __restrict__ 
 __global__ __launch_bounds__(kK1Threads) void k1_scatter(const float4* __restrict__ pts, int n, int dense, GridGeom g, int map, int K,
                                                          int ppb, const unsigned* __restrict__ cntmat, const unsigned* __restrict__ total,
                                                          unsigned* __restrict__ bucket_base, float4* __restrict__ bpts,
-                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st, int index_form) {
+                                                         unsigned* __restrict__ counts, unsigned long long* __restrict__ st, int index_form,
+                                                         const unsigned* __restrict__ n_dev) {
   extern __shared__ unsigned k1_lds[];
+  if (n_dev) n = min(n, static_cast<int>(*n_dev));
   const K1Deal deal(map & 255, map >> 8);
   __shared__ unsigned s_scan[kK1Waves];
   auto mark = [&](int q) {  // development aid (NDT_K1_STAMPS): thread 0's clock at the phase boundaries
@@ -2405,10 +2409,11 @@ hipError_t launch_grid_build_buckets(const float4* pts, int n, int dense, const 
   (void)once;
   unsigned* total = S.cntmat + static_cast<size_t>(P.n_blocks) * K;
   hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
-                     P.pts_per_block, S.cntmat, lut, g.lut_cells);
+                     P.pts_per_block, S.cntmat, lut, g.lut_cells, static_cast<const unsigned*>(nullptr));
   hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
-                     total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr, S.index_form ? 1 : 0);
+                     total, S.bucket_base, S.bpts, counts, S.stamps ? S.stamps + 8 * static_cast<size_t>(K) : nullptr, S.index_form ? 1 : 0,
+                     static_cast<const unsigned*>(nullptr));
   // LDS of k1_finalize: 3 C words of per-cell state + 5 words per point of a bucket that fits (at most kK1LdsCap points: eight
   // per thread, held in registers); bigger buckets (clustered data) go through their slices of the global scratch.
   // The kernel's registers allow three blocks per CU, so a pass gets what a third of the CU's LDS holds (the host does not
@@ -2493,10 +2498,10 @@ hipError_t launch_filter_buckets(const float4* pts, int n, int dense, const Grid
   (void)once;
   unsigned* total = S.cntmat + static_cast<size_t>(P.n_blocks) * K;
   hipLaunchKernelGGL(k1_hist, dim3(P.n_blocks), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, pts, n, dense, g, P.shift, K,
-                     P.pts_per_block, S.cntmat, static_cast<int*>(nullptr), 0ll);
+                     P.pts_per_block, S.cntmat, static_cast<int*>(nullptr), 0ll, static_cast<const unsigned*>(nullptr));
   hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, S.cntmat, P.n_blocks, K, total);
   hipLaunchKernelGGL(k1_scatter, dim3(P.n_blocks), dim3(kK1Threads), lds_scatter, stream, pts, n, dense, g, P.shift, K, P.pts_per_block, S.cntmat,
-                     total, S.bucket_base, S.bpts, counts, static_cast<unsigned long long*>(nullptr), 0);
+                     total, S.bucket_base, S.bpts, counts, static_cast<unsigned long long*>(nullptr), 0, static_cast<const unsigned*>(nullptr));
   const int wmax = std::min(C, 1024);
   auto fin_lds = [&](int cap) { return (static_cast<size_t>(3) * C + 3 * static_cast<size_t>(cap)) * sizeof(unsigned) + 5 * static_cast<size_t>(wmax) * 2; };
   int lds_cap = 256;
@@ -2516,6 +2521,60 @@ hipError_t launch_filter_buckets(const float4* pts, int n, int dense, const Grid
   hipLaunchKernelGGL(vf_bitmap_prefix, dim3(n_chunks), dim3(kBlock), 0, stream, bitmap_words, n_words, wprefix, counts);
   hipLaunchKernelGGL(vf_place, dim3(std::max(1, std::min(2048, (n + kBlock - 1) / kBlock))), dim3(kBlock), 0, stream, st_cell, st_cent, counts, bitmap_words,
                      wprefix, out);
+  return hipGetLastError();
+}
+
+// ---- a cloud in lattice-cell order by stable radix passes (order_range) ---------------------------------------------------
+// The points sorted by their cell of the lattice g (x fastest), the points of a cell in the order they came in, non-finite
+// points dropped: least-significant-digit-first passes of K1's order-preserving front end (k1_hist / k1_colscan / k1_scatter
+// with bucket = digit: K1Deal's (cell >> rb) mod K is a digit when K is a power of two).  Two passes of <= 11 bits for up to
+// 4 M cells, 32 bytes read and 16 written per point and pass -- instead of a rank per point by a returning atomic, a scatter
+// of indices, a sort of every crowded cell back into point order and a gather.  counts: [passes] words, the points kept;
+// counts[passes - 1] is the output's size.  tmp: n points (unused by a single pass); scratch as for a grid build.
+int order_radix_passes(long long n_cells) {
+  int bits = 1;
+  while ((1ll << bits) < n_cells) bits++;
+  return (bits + 10) / 11;
+}
+size_t order_radix_cntmat_words(long long n_cells, int n, int* n_blocks_out, int* ppb_out, int* digit_bits_out) {
+  int bits = 1;
+  while ((1ll << bits) < n_cells) bits++;
+  const int passes = (bits + 10) / 11, db = (bits + passes - 1) / passes;
+  long long ppb = std::max(512, std::min(kK1Round, pow2_ceil((n + 511) / 512)));
+  while ((n + ppb - 1) / ppb > kColGroups * kColRows) ppb += kK1Round;
+  const int nb = static_cast<int>(((n + ppb - 1) / ppb + 7) / 8 * 8);
+  if (n_blocks_out) *n_blocks_out = nb;
+  if (ppb_out) *ppb_out = static_cast<int>(ppb);
+  if (digit_bits_out) *digit_bits_out = db;
+  return (static_cast<size_t>(nb) + 1) * (static_cast<size_t>(1) << db);
+}
+hipError_t launch_order_radix(const float4* pts, int n, const GridGeom& g, unsigned* cntmat, unsigned* bucket_base, float4* tmp, float4* out,
+                              unsigned* counts, hipStream_t stream) {
+  int nb = 0, ppb = 0, db = 0;
+  (void)order_radix_cntmat_words(g.n_cells, n, &nb, &ppb, &db);
+  const int passes = order_radix_passes(g.n_cells), K = 1 << db;
+  const size_t lds_scatter = (static_cast<size_t>(K) + 2) * sizeof(unsigned) + static_cast<size_t>(K) * sizeof(unsigned short) +
+                             static_cast<size_t>(kK1Waves) * K * sizeof(unsigned short);
+  if (passes > 3 || lds_scatter > kK1MaxDynamicLds || nb > kColGroups * kColRows) return hipErrorInvalidValue;
+  static bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kK1MaxDynamicLds));
+    return true;
+  }();
+  (void)once;
+  unsigned* total = cntmat + static_cast<size_t>(nb) * K;
+  const float4* in = pts;
+  for (int p = 0; p < passes; p++) {
+    // (an odd number of passes ends in `out` when it starts there)
+    float4* dst = ((passes - p) & 1) ? out : tmp;
+    const int map = (p * db) | (K << 8);
+    const unsigned* n_dev = p ? counts + (p - 1) : nullptr;
+    hipLaunchKernelGGL(k1_hist, dim3(nb), dim3(kK1Threads), static_cast<size_t>(K) * sizeof(unsigned), stream, in, n, 0, g, map, K, ppb, cntmat,
+                       static_cast<int*>(nullptr), 0ll, n_dev);
+    hipLaunchKernelGGL(k1_colscan, dim3((K + kColCols - 1) / kColCols), dim3(kK1Threads), 0, stream, cntmat, nb, K, total);
+    hipLaunchKernelGGL(k1_scatter, dim3(nb), dim3(kK1Threads), lds_scatter, stream, in, n, 0, g, map, K, ppb, cntmat, total, bucket_base, dst, counts + p,
+                       static_cast<unsigned long long*>(nullptr), 0, n_dev);
+    in = dst;
+  }
   return hipGetLastError();
 }
 

@@ -302,6 +302,11 @@ hipError_t launch_calc_score(const float4* cloud, int n, const GridView& gv, dou
 hipError_t launch_voxel_centroids(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                                   int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals = nullptr,
                                   float4* d_big_pts = nullptr /* n points of scratch for crowded voxels */);
+// order_range's radix form: see ndt_grid_kernels.hip
+int order_radix_passes(long long n_cells);
+size_t order_radix_cntmat_words(long long n_cells, int n, int* n_blocks = nullptr, int* ppb = nullptr, int* digit_bits = nullptr);
+hipError_t launch_order_radix(const float4* pts, int n, const GridGeom& g, unsigned* cntmat, unsigned* bucket_base, float4* tmp, float4* out,
+                              unsigned* counts, hipStream_t stream);
 hipError_t launch_sort_gather(const float4* pts, const unsigned* leaf_start, const int* leaf_count, int n_leaves,
                               int* sorted_idx, float4* out, hipStream_t stream, const unsigned* d_totals = nullptr);
 hipError_t launch_derivatives_stamped(const float4* src, int n, const GridView& gv, const EvalParams& P, int n_blocks,
